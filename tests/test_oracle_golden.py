@@ -1,0 +1,143 @@
+"""CPU: pins oracle/np_unet.py and oracle/torch_cpu.py against vectors captured from the real reference
+(tests/golden/*.npz, written by oracle/gen_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_unet as O
+from oracle import torch_cpu as TC
+from conftest import rel_l2
+
+TOL = 2e-5   # fp32 re-association only
+
+
+def test_conv_relu_bn_op(golden):
+    g = golden('ops.npz')
+    x, w, b = g['cbr/x'], g['cbr/w'], g['cbr/b']
+    z = O.conv3x3_fwd(x, w, b)
+    assert rel_l2(z, g['cbr/z']) < TOL
+    y = O.relu_fwd(z)
+    u, cache, rm, rv = O.bn_train_fwd(y, g['cbr/gamma'], g['cbr/beta'], np.zeros(7, np.float32), np.ones(7, np.float32))
+    assert rel_l2(u, g['cbr/u']) < TOL
+    assert rel_l2(rm, g['cbr/rm']) < TOL and rel_l2(rv, g['cbr/rv']) < TOL
+    gy, gg, gb = O.bn_train_bwd(g['cbr/go'], g['cbr/gamma'], cache)
+    assert rel_l2(gg, g['cbr/ggamma']) < 1e-4 and rel_l2(gb, g['cbr/gbeta']) < 1e-4
+    gx, gw, gcb = O.conv3x3_bwd(x, w, gy * (y > 0))
+    assert rel_l2(gx, g['cbr/gx']) < 1e-4
+    assert rel_l2(gw, g['cbr/gw']) < 1e-4
+    assert rel_l2(gcb, g['cbr/gb']) < 1e-4
+
+
+def test_pool_convT_head_ops(golden):
+    g = golden('ops.npz')
+    y, idx = O.maxpool2x2_fwd(g['pool/x'])
+    assert np.array_equal(y, g['pool/y'])
+    assert np.array_equal(O.maxpool2x2_bwd(g['pool/go'], idx), g['pool/gx'])      # tie rule: first max
+    yt = O.convT2x2_fwd(g['convT/x'], g['convT/w'], g['convT/b'])
+    assert rel_l2(yt, g['convT/y']) < TOL
+    gx, gw, gb = O.convT2x2_bwd(g['convT/x'], g['convT/w'], g['convT/go'])
+    assert rel_l2(gx, g['convT/gx']) < TOL and rel_l2(gw, g['convT/gw']) < TOL and rel_l2(gb, g['convT/gb']) < TOL
+    yh = O.conv1x1_fwd(g['head/x'], g['head/w'], g['head/b'])
+    assert rel_l2(yh, g['head/y']) < TOL
+    gx, gw, gb = O.conv1x1_bwd(g['head/x'], g['head/w'], g['head/go'])
+    assert rel_l2(gx, g['head/gx']) < TOL and rel_l2(gw, g['head/gw']) < TOL and rel_l2(gb, g['head/gb']) < TOL
+
+
+def test_cross_entropy(golden):
+    g = golden('ops.npz')
+    loss, d = O.cross_entropy(g['ce/logits'], g['ce/labels'])
+    assert abs(loss - g['ce/loss']) < 1e-6 * abs(g['ce/loss']) + 1e-6
+    assert rel_l2(d, g['ce/dlogits']) < TOL
+    loss, d = O.cross_entropy(g['ce/logits'], g['ce_ign/labels'])
+    assert abs(loss - g['ce_ign/loss']) < 2e-6
+    assert rel_l2(d, g['ce_ign/dlogits']) < TOL
+
+
+def test_adam_and_schedule(golden):
+    g = golden('ops.npz')
+    p = g['adam/p0']
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    for i in range(3):
+        p, m, v = O.adam_step(p, g['adam/grads'][i], m, v, i + 1, 1e-2)
+        assert rel_l2(p, g[f'adam/p{i + 1}']) < 1e-6
+    assert rel_l2(m, g['adam/m3']) < 1e-6 and rel_l2(v, g['adam/v3']) < 1e-6
+    lrs = [O.poly_lr(1e-4, e + 1, 10, 0.9) for e in range(10)]
+    np.testing.assert_allclose(lrs, g['sched/lrs_n10'], rtol=1e-12, atol=1e-18)
+    assert lrs[-1] == 0.0   # the last epoch trains at lr 0
+
+
+def test_metrics(golden):
+    g = golden('metrics.npz')
+    for c in (21, 22):      # trainer.py:188 passes 22: the extra all-zero class is dropped by nanmean (Q5)
+        oa, pc, miu, mx, m = O.eval_metrics(g['target'], g['pred'], c)
+        np.testing.assert_allclose([oa, pc, miu, mx], g[f'm{c}'], rtol=1e-6)
+    assert np.array_equal(O.eval_metrics(g['target'], g['pred'], 21)[4], g['conf21'])
+
+
+def _state(g, tag):
+    return {k[len(tag) + 1:]: g[k] for k in g.files if k.startswith(tag + '/')}
+
+
+def test_numpy_unet_small_model(golden):
+    """Whole-model pin: UNet(2,3,4) 32x32 bs2 -- the reference's own smoke shape (models/unet.py:94-97)."""
+    import importlib.util, os
+    g = golden('unet_cd4_c2_32.npz')
+    P = _state(g, 'w0')
+    spec = importlib.util.spec_from_file_location('s', os.path.join(os.path.dirname(__file__), '..', 'continual-learning_amd', 'synth.py'))
+    S = importlib.util.module_from_spec(spec); spec.loader.exec_module(S)
+    x = S.images(1234, 2, 3, 32, 32)
+    y = S.labels(1234, 2, 32, 32, 2)
+    for k in list(P):
+        if k.endswith('.weight') and P[k].ndim == 1:   # BN: add fresh running stats
+            P[k[:-6] + 'running_mean'] = np.zeros_like(P[k])
+            P[k[:-6] + 'running_var'] = np.ones_like(P[k])
+    loss, logits, G, P1, st = O.train_step(P, {}, x, y, 1, 1e-3, 2, 3, 4)
+    assert logits.shape == (2, 2, 32, 32)
+    assert rel_l2(logits, g['logits']) < 1e-4
+    assert abs(loss - g['losses'][0]) < 1e-5
+    for k in O.param_keys(2, 3, 4):
+        assert rel_l2(G[k], g['g0/' + k]) < 2e-3, k        # tiny grads of conv biases before BN are ~0: see below
+    W1 = _state(g, 'w1')
+    for k, v in W1.items():
+        # Adam's first step is lr*sign-like (m/sqrt(v) = +-1): elements whose gradient is at rounding-noise
+        # level may move by up to 2*lr differently; bound the L2 error and the fraction of such elements.
+        assert rel_l2(P1[k], v) < 1e-3, k
+        assert np.mean(np.abs(P1[k] - v) > 1e-4) < 0.01, k
+    pred = logits.argmax(1)
+    assert np.array_equal(np.bincount(pred.reshape(-1), minlength=2), g['pred_hist'])
+    np.testing.assert_allclose(O.eval_metrics(y, pred, 2)[:4], g['metrics'], rtol=1e-5)
+
+
+@pytest.mark.parametrize('name,nc,cd,size', [('unet_cd4_c2_32.npz', 2, 4, 32), ('unet_cd8_c21_64.npz', 21, 8, 64)])
+def test_torch_counterpart(golden, name, nc, cd, size):
+    """oracle/torch_cpu.py reproduces the captured 3-step loss sequence, logits, grads and weights."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location('s', os.path.join(os.path.dirname(__file__), '..', 'continual-learning_amd', 'synth.py'))
+    S = importlib.util.module_from_spec(spec); spec.loader.exec_module(S)
+    g = golden(name)
+    torch.set_num_threads(4)
+    m = TC.build_unet(nc, 3, cd)
+    assert len(m.state_dict()) == 136
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))}
+    st = S.closed_form_state(shapes, 0)
+    sd = m.state_dict()
+    sd.update({k: torch.from_numpy(v) for k, v in st.items()})
+    m.load_state_dict(sd, strict=True)
+    if 'w0/enc1.0.weight' in g.files:
+        assert np.array_equal(st['enc1.0.weight'], g['w0/enc1.0.weight'])
+    m.train()
+    x = torch.from_numpy(S.images(1234, 2, 3, size, size))
+    y = torch.from_numpy(S.labels(1234, 2, size, size, nc))
+    opt = TC.make_optimizer(m, lr=float(g['lr']))
+    crit = torch.nn.CrossEntropyLoss()
+    losses = []
+    for s in range(3):
+        out, loss = TC.train_step(m, opt, crit, x, y)
+        losses.append(float(loss))
+        if s == 0:
+            assert rel_l2(out.detach().numpy(), g['logits']) < 1e-5
+            gn = np.array([float(p.grad.double().norm()) for p in m.parameters()])
+            np.testing.assert_allclose(gn, g['grad_norms'], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(losses, g['losses'], rtol=1e-5)
+    assert [n for n, _ in m.named_parameters()] == list(g['grad_names'])
