@@ -1,0 +1,88 @@
+"""ctypes binding of libclamd.so (the C ABI declared in include/clamd.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.  The product path never
+routes through torch operators or the CPU oracle for compute.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_longlong, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libclamd.so')
+
+F32, BF16 = 0, 1
+WGRAD_CONV3, WGRAD_PW, WGRAD_UP2 = 0, 1, 2
+
+_P, _I, _D, _LL, _SZ = c_void_p, c_int, c_double, c_longlong, c_size_t
+
+# name -> (restype, argtypes); must list EVERY symbol of include/clamd.h (tests/test_abi.py checks the header).
+SIGNATURES = {
+    'clamd_last_error': (c_char_p, []),
+    'clamd_version': (_I, []),
+    'clamd_sizeof_pack_job': (_I, []),
+    'clamd_sizeof_adam_tensor': (_I, []),
+    'clamd_adam_chunk_elems': (_I, []),
+    'clamd_stat_replicas': (_I, []),
+    'clamd_bn_bwd_nsums': (_I, []),
+    'clamd_conv3x3': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_conv1x1': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_conv1x1_logits': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_convT2x2_fwd': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_convT2x2_dgrad': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_wgrad_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
+    'clamd_wgrad': (_I, [_I, _P, _I, _P, _I, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_bn_finalize': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _P]),
+    'clamd_bn_apply': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_bn_bwd_reduce': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'clamd_bn_bwd_finalize': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _P]),
+    'clamd_bn_bwd_apply': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_channel_sum': (_I, [_P, _I, _P, _LL, _I, _I, _I, _P]),
+    'clamd_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _D, _I, _P]),
+    'clamd_nhwc_to_nchw': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'clamd_pack': (_I, [_P, _I, _I, _I, _P]),
+    'clamd_ce_workspace_bytes': (_SZ, []),
+    'clamd_ce_fwd_bwd': (_I, [_P, _P, _P, _I, _I, _D, _D, _P, _P, _P, _SZ, _I, _I, _I, _I, _LL, _D, _P]),
+    'clamd_adam_step': (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
+    'clamd_argmax_confusion': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'clamd_fill_f32': (_I, [_P, _LL, _D, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the library (once).  Raises RuntimeError if it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f'{LIB_PATH} is missing: the HIP extension has not been built '
+                           f'(python continual-learning_amd/build.py).  There is no CPU/torch fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().clamd_last_error().decode()
+        raise RuntimeError(f'libclamd {what} failed ({rc}): {msg}')
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point and raise on error."""
+    check(getattr(load(), name)(*args), name)
+
+
+def ptr(t):
+    """Raw device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

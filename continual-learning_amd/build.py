@@ -1,0 +1,62 @@
+"""Builds libclamd.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python continual-learning_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the snapshot.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(HERE, 'libclamd.so')
+SOURCES = ['igemm.hip', 'wgrad.hip', 'elementwise.hip', 'misc.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
+         '-I' + os.path.join(HERE, '..', 'include')]
+
+
+def _digest():
+    h = hashlib.sha256()
+    for root in (CSRC, os.path.join(HERE, '..', 'include')):
+        for f in sorted(os.listdir(root)):
+            if f.endswith(('.hip', '.h')):
+                h.update(f.encode())
+                h.update(open(os.path.join(root, f), 'rb').read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    stamp = os.path.join(HERE, 'csrc', '.build_stamp')
+    dig = _digest()
+    if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return OUT
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+
+    def cc(src):
+        obj = os.path.join(CSRC, src.replace('.hip', '.o'))
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr[-6000:]}')
+        if verbose and r.stderr.strip():
+            sys.stderr.write(r.stderr[-3000:])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(cc, SOURCES))
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs,
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n' + r.stderr[-4000:])
+    with open(stamp, 'w') as f:
+        f.write(dig)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

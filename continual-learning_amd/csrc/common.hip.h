@@ -1,0 +1,118 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the UNet train-step path.
+// Wave = 64 lanes; MFMA tiles are 32x32 (v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace clamd {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct bf16_t { uint16_t v; };   // storage type tag for bf16 tensors
+
+// ---- dtype traits -------------------------------------------------------------------------------
+template <typename T> struct DT;
+template <> struct DT<float> {
+    static constexpr int BYTES = 4;
+    static constexpr int VEC = 4;        // elements per 16-byte group
+    static constexpr int KC = 16;        // channels per 64-byte K-chunk
+    __device__ static inline float ld(const float* p) { return *p; }
+};
+template <> struct DT<bf16_t> {
+    static constexpr int BYTES = 2;
+    static constexpr int VEC = 8;
+    static constexpr int KC = 32;
+};
+
+__device__ inline float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even; plain cast form keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
+__device__ inline uint16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ inline uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// 8 consecutive channels <-> fp32 registers
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+    __device__ static inline void load(const float* p, float (&v)[8]) {
+        float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    __device__ static inline void store(float* p, const float (&v)[8]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct Vec8<bf16_t> {
+    __device__ static inline void load(const bf16_t* p, float (&v)[8]) {
+        uint4 u = *reinterpret_cast<const uint4*>(p);
+        v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+        v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+        v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+    __device__ static inline void store(bf16_t* p, const float (&v)[8]) {
+        uint4 u;
+        u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]);
+        u.z = pack2bf(v[4], v[5]); u.w = pack2bf(v[6], v[7]);
+        *reinterpret_cast<uint4*>(p) = u;
+    }
+};
+
+template <typename T> __device__ inline float ld1(const T* p);
+template <> __device__ inline float ld1<float>(const float* p) { return *p; }
+template <> __device__ inline float ld1<bf16_t>(const bf16_t* p) { return bf2f(p->v); }
+template <typename T> __device__ inline void st1(T* p, float v);
+template <> __device__ inline void st1<float>(float* p, float v) { *p = v; }
+template <> __device__ inline void st1<bf16_t>(bf16_t* p, float v) { p->v = f2bf(v); }
+
+// ---- MFMA step on one 16-byte A group and one 16-byte B group ------------------------------------
+// bf16: 8 k-values per lane -> one 32x32x16 MFMA.
+// f32 : 4 k-values per lane -> four 32x32x2 MFMAs; MFMA j contracts k-pair {j (lanes 0-31), 4+j (lanes 32-63)}
+//       of the 8 channels the two half-waves loaded, identically for A and B, so any 8-channel block is
+//       summed exactly once (bit-exact f32 fma chain per the ISA).
+template <typename T> __device__ inline void mma16(const uint4& a, const uint4& b, f32x16& acc);
+template <> __device__ inline void mma16<bf16_t>(const uint4& a, const uint4& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                  acc, 0, 0, 0);
+}
+template <> __device__ inline void mma16<float>(const uint4& a, const uint4& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+// Predicated 16-byte global load (returns zeros when !ok).  Written as a by-value helper on purpose: a ternary
+// between `*ptr` and a zero VARIABLE is an lvalue conditional and hipcc lowers it to a select between the global
+// address and the private (scratch) address of the zero -- flat loads and scratch traffic in the hot loop.
+__device__ inline uint4 ldg16(const void* p, bool ok) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (ok) v = *reinterpret_cast<const uint4*>(p);
+    return v;
+}
+
+// Row of accumulator register `reg` (0..15) for lane half h in a 32x32 MFMA tile; column = lane & 31.
+__device__ inline int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// ---- XCD-aware block remap (8 XCDs, blocks dealt round-robin): give each XCD a contiguous id range so
+// neighbouring tiles share that XCD's L2.  Bijective for any grid size.  Speed only, never correctness.
+__device__ inline int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+constexpr int STAT_REPLICAS = 16;   // per-channel atomic accumulators are replicated to spread contention
+
+}  // namespace clamd

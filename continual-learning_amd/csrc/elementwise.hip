@@ -1,0 +1,451 @@
+// HBM-bound kernels of the UNet train step: BatchNorm finalise / apply
+// (+ fused 2x2 max-pool, + write into a concat slice), the BatchNorm+ReLU backward reductions and apply
+// (+ fused max-pool backward routing), layout conversion, per-channel sums.
+// All activations are NHWC with an explicit channel pitch (ldc) so a tensor can be a channel slice of a
+// concat buffer; every thread moves 8 channels (16 B bf16 / 32 B f32) per pixel, lanes along channels first.
+#include "common.hip.h"
+#include "clamd_internal.h"
+
+namespace clamd {
+
+// ------------------------------------------------------------------------------------------------
+// BN finalise: replicas of (sum, sumsq) -> mean / invstd / scale / shift, running-stat update.
+// Reference: nn.BatchNorm2d train mode, models/unet.py:15 (momentum 0.1, eps 1e-5, unbiased running var).
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var,
+                                   float* scale, float* shift, float* save_mean, float* save_istd,
+                                   int Cp, int C, float count, float momentum, float eps) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cp) return;
+    float mean, var;
+    if (stats) {
+        float s = 0.f, q = 0.f;
+        for (int r = 0; r < STAT_REPLICAS; ++r) {
+            s += stats[(r * 2 + 0) * Cp + c];
+            q += stats[(r * 2 + 1) * Cp + c];
+        }
+        mean = s / count;
+        var = fmaxf(q / count - mean * mean, 0.f);
+    } else {   // eval mode (trainer.py:271): normalise with the running statistics, update nothing
+        mean = c < C ? running_mean[c] : 0.f;
+        var = c < C ? running_var[c] : 1.f;
+    }
+    float istd = rsqrtf(var + eps);
+    istd = istd * (1.5f - 0.5f * (var + eps) * istd * istd);   // one Newton step: rsqrtf is approximate
+    float g = c < C ? gamma[c] : 0.f, b = c < C ? beta[c] : 0.f;
+    float sc = g * istd;
+    scale[c] = sc;
+    shift[c] = b - mean * sc;
+    save_mean[c] = mean;
+    save_istd[c] = istd;
+    if (c < C && running_mean && stats) {
+        float unb = count > 1.f ? var * (count / (count - 1.f)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN apply: out = y*scale + shift (written into `out` with its own pitch: possibly a concat slice), and
+// optionally pooled = max over the 2x2 window of `out` (nn.MaxPool2d(2,2), models/unet.py:12,80).
+template <typename T, bool POOL>
+__global__ void bn_apply_kernel(const T* __restrict__ y, int y_ldc, const float* __restrict__ scale,
+                                const float* __restrict__ shift, T* out, int out_ldc, T* pooled, int p_ldc,
+                                int B, int H, int W, int Cp) {
+    const int G = Cp >> 3;
+    const long long nitem = POOL ? (long long)B * (H / 2) * (W / 2) * G : (long long)B * H * W * G;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < nitem;
+         it += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(it % G);
+        const long long pix = it / G;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; sh[j] = shift[cg * 8 + j]; }
+        if constexpr (!POOL) {
+            float v[8];
+            Vec8<T>::load(y + pix * y_ldc + cg * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = __fmaf_rn(v[j], sc[j], sh[j]);
+            Vec8<T>::store(out + pix * out_ldc + cg * 8, v);
+        } else {
+            const int w2 = W / 2, h2 = H / 2;
+            const int px = (int)(pix % w2), py = (int)((pix / w2) % h2), b = (int)(pix / ((long long)w2 * h2));
+            float m[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long p = ((long long)b * H + 2 * py + (q >> 1)) * W + 2 * px + (q & 1);
+                float v[8];
+                Vec8<T>::load(y + p * y_ldc + cg * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = __fmaf_rn(v[j], sc[j], sh[j]);
+                    m[j] = (q == 0 || v[j] > m[j]) ? v[j] : m[j];
+                }
+                Vec8<T>::store(out + p * out_ldc + cg * 8, v);
+            }
+            Vec8<T>::store(pooled + pix * p_ldc + cg * 8, m);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of [ReLU -> BatchNorm(train)] (+ optional max-pool routing of a second gradient source).
+//   g_u  = ga[p]  (+ gp[pool cell] if p is the arg-max of its 2x2 window of u = y*scale+shift)
+//   sums: s0 = sum g_u, s1 = sum g_u*y, s2 = sum g_u*[y>0], s3 = sum [y>0], s4 = sum y
+//   g_z  = [y>0] * (k0*g_u + k1*y + k2)
+// The window arg-max is recomputed bit-identically to bn_apply_kernel (same fmaf, first max wins).
+template <typename T>
+__device__ inline void load_gu(const T* ga, int ga_ldc, const T* gp, int gp_ldc, const T* y, int y_ldc,
+                               const float (&sc)[8], const float (&sh)[8], int b, int py, int px, int H, int W,
+                               int cg, float (&g)[4][8], float (&yy)[4][8]) {
+    float best[8];
+    int arg[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long p = ((long long)b * H + 2 * py + (q >> 1)) * W + 2 * px + (q & 1);
+        Vec8<T>::load(y + p * y_ldc + cg * 8, yy[q]);
+        if (ga) Vec8<T>::load(ga + p * ga_ldc + cg * 8, g[q]);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[q][j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float u = __fmaf_rn(yy[q][j], sc[j], sh[j]);
+            if (q == 0 || u > best[j]) { best[j] = u; arg[j] = q; }
+        }
+    }
+    float gpv[8];
+    const long long pp = ((long long)b * (H / 2) + py) * (W / 2) + px;
+    Vec8<T>::load(gp + pp * gp_ldc + cg * 8, gpv);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[q][j] += (arg[j] == q) ? gpv[j] : 0.f;
+}
+
+constexpr int NSUM = 5;
+
+template <typename T, bool POOL>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ ga, int ga_ldc,
+                                                            const T* __restrict__ gp, int gp_ldc,
+                                                            const T* __restrict__ y, int y_ldc,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* sums,
+                                                            int B, int H, int W, int Cp) {
+    __shared__ float red[256 * 8];
+    const int G = Cp >> 3;
+    const int tid = threadIdx.x;
+    float acc[NSUM][8];
+#pragma unroll
+    for (int s = 0; s < NSUM; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[s][j] = 0.f;
+    const int cg = tid % G;
+    const int rows = 256 / G, prow = tid / G;
+    {
+        float sc[8], sh[8];
+        if constexpr (POOL) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; sh[j] = shift[cg * 8 + j]; }
+        }
+        const long long npix = POOL ? (long long)B * (H / 2) * (W / 2) : (long long)B * H * W;
+        for (long long pix = (long long)blockIdx.x * rows + prow; pix < npix; pix += (long long)gridDim.x * rows) {
+            if constexpr (!POOL) {
+                float g[8], v[8];
+                Vec8<T>::load(ga + pix * ga_ldc + cg * 8, g);
+                Vec8<T>::load(y + pix * y_ldc + cg * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pos = v[j] > 0.f ? 1.f : 0.f;
+                    acc[0][j] += g[j]; acc[1][j] += g[j] * v[j]; acc[2][j] += g[j] * pos;
+                    acc[3][j] += pos; acc[4][j] += v[j];
+                }
+            } else {
+                const int w2 = W / 2, h2 = H / 2;
+                const int px = (int)(pix % w2), py = (int)((pix / w2) % h2), b = (int)(pix / ((long long)w2 * h2));
+                float g[4][8], v[4][8];
+                load_gu<T>(ga, ga_ldc, gp, gp_ldc, y, y_ldc, sc, sh, b, py, px, H, W, cg, g, v);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float pos = v[q][j] > 0.f ? 1.f : 0.f;
+                        acc[0][j] += g[q][j]; acc[1][j] += g[q][j] * v[q][j]; acc[2][j] += g[q][j] * pos;
+                        acc[3][j] += pos; acc[4][j] += v[q][j];
+                    }
+            }
+        }
+    }
+    // block reduction over the threads that share a channel group, one sum kind at a time
+    float* dst = sums + (size_t)(blockIdx.x % STAT_REPLICAS) * NSUM * Cp;
+#pragma unroll
+    for (int s = 0; s < NSUM; ++s) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = acc[s][j];
+        __syncthreads();
+        // channel c's contributions live at red[(r*G + c/8)*8 + c%8], r = 0..rows-1
+        for (int c = tid; c < Cp; c += 256) {
+            const int g8 = c >> 3, j = c & 7;
+            float t = 0.f;
+            for (int r = 0; r < rows; ++r) t += red[(r * G + g8) * 8 + j];
+            atomicAdd(dst + s * Cp + c, t);
+        }
+    }
+}
+
+// sums (replicated) -> k0,k1,k2 per channel, and the parameter gradients d_gamma, d_beta, d_convbias.
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                       const float* __restrict__ save_mean, const float* __restrict__ save_istd,
+                                       float* k012, float* dgamma, float* dbeta, float* dbias, int Cp, int C,
+                                       float count) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cp) return;
+    float s[NSUM];
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k) {
+        float t = 0.f;
+        for (int r = 0; r < STAT_REPLICAS; ++r) t += sums[((size_t)r * NSUM + k) * Cp + c];
+        s[k] = t;
+    }
+    const float mu = save_mean[c], istd = save_istd[c];
+    const float g = c < C ? gamma[c] : 0.f;
+    const float inv_n = 1.f / count;
+    const float k0 = g * istd;
+    const float c2 = istd * istd * (s[1] * inv_n - mu * s[0] * inv_n);
+    const float k1 = -k0 * c2;
+    const float k2 = k0 * (mu * c2 - s[0] * inv_n);
+    k012[c] = k0; k012[Cp + c] = k1; k012[2 * Cp + c] = k2;
+    if (c < C) {
+        dgamma[c] = istd * (s[1] - mu * s[0]);
+        dbeta[c] = s[0];
+        dbias[c] = k0 * s[2] + k1 * s[4] + k2 * s[3];
+    }
+}
+
+template <typename T, bool POOL>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ ga, int ga_ldc, const T* __restrict__ gp, int gp_ldc,
+                                    const T* __restrict__ y, int y_ldc, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, const float* __restrict__ k012, T* gz,
+                                    int gz_ldc, int B, int H, int W, int Cp) {
+    const int G = Cp >> 3;
+    const long long nitem = POOL ? (long long)B * (H / 2) * (W / 2) * G : (long long)B * H * W * G;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < nitem;
+         it += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(it % G);
+        const long long pix = it / G;
+        float k0[8], k1[8], k2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            k0[j] = k012[cg * 8 + j]; k1[j] = k012[Cp + cg * 8 + j]; k2[j] = k012[2 * Cp + cg * 8 + j];
+        }
+        if constexpr (!POOL) {
+            float g[8], v[8];
+            Vec8<T>::load(ga + pix * ga_ldc + cg * 8, g);
+            Vec8<T>::load(y + pix * y_ldc + cg * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = v[j] > 0.f ? (k0[j] * g[j] + k1[j] * v[j] + k2[j]) : 0.f;
+            Vec8<T>::store(gz + pix * gz_ldc + cg * 8, g);
+        } else {
+            float sc[8], sh[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sc[j] = scale[cg * 8 + j]; sh[j] = shift[cg * 8 + j]; }
+            const int w2 = W / 2, h2 = H / 2;
+            const int px = (int)(pix % w2), py = (int)((pix / w2) % h2), b = (int)(pix / ((long long)w2 * h2));
+            float g[4][8], v[4][8];
+            load_gu<T>(ga, ga_ldc, gp, gp_ldc, y, y_ldc, sc, sh, b, py, px, H, W, cg, g, v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long p = ((long long)b * H + 2 * py + (q >> 1)) * W + 2 * px + (q & 1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    g[q][j] = v[q][j] > 0.f ? (k0[j] * g[q][j] + k1[j] * v[q][j] + k2[j]) : 0.f;
+                Vec8<T>::store(gz + p * gz_ldc + cg * 8, g[q]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-channel sum of an NHWC tensor (bias gradients of convT / head): out[c] += sum_p g[p,c] (atomic, out
+// must be zeroed by the caller).
+template <typename T>
+__global__ void __launch_bounds__(256) channel_sum_kernel(const T* __restrict__ g, int ldc, float* out,
+                                                          long long npix, int Cp, int C) {
+    __shared__ float red[256 * 8];
+    const int G = Cp >> 3, tid = threadIdx.x;
+    const int cg = tid % G, rows = 256 / G, prow = tid / G;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long pix = (long long)blockIdx.x * rows + prow; pix < npix; pix += (long long)gridDim.x * rows) {
+        float v[8];
+        Vec8<T>::load(g + pix * ldc + cg * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = acc[j];
+    __syncthreads();
+    for (int c = tid; c < G * 8; c += 256) {
+        const int g8 = c >> 3, j = c & 7;
+        float t = 0.f;
+        for (int r = 0; r < rows; ++r) t += red[(r * G + g8) * 8 + j];
+        if (c < C) atomicAdd(out + c, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layout conversion at the drop-in boundary (visible tensors are NCHW fp32).
+// NCHW f32 [B,C,H,W] -> NHWC T [B,H,W,ldc] with channels >= C zero-filled up to Cp.  One thread per (pixel, 8ch).
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* dst, int ldc, int B, int C, int H, int W,
+                                    int Cp, float mul) {
+    const int G = Cp >> 3;
+    const long long hw = (long long)H * W, nitem = (long long)B * hw * G;
+    // lanes along pixels (coalesced NCHW reads); each lane writes 16/32 contiguous bytes
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < nitem;
+         it += (long long)gridDim.x * blockDim.x) {
+        const long long pixb = it % (B * hw);
+        const int cg = (int)(it / (B * hw));
+        const long long b = pixb / hw, p = pixb % hw;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cg * 8 + j;
+            v[j] = c < C ? src[(b * C + c) * hw + p] * mul : 0.f;
+        }
+        Vec8<T>::store(dst + pixb * ldc + cg * 8, v);
+    }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int ldc, float* dst, int B, int C, int H, int W) {
+    const long long hw = (long long)H * W, n = (long long)B * C * hw;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < n;
+         it += (long long)gridDim.x * blockDim.x) {
+        const long long p = it % hw;
+        const int c = (int)((it / hw) % C);
+        const long long b = it / (hw * C);
+        dst[it] = ld1<T>(src + (b * hw + p) * ldc + c);
+    }
+}
+
+}  // namespace clamd
+
+using namespace clamd;
+
+static inline int ew_grid(long long nitem, int cap = 4096) {
+    long long g = (nitem + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+static bool pow2_channels(int Cp) { return Cp >= 32 && Cp <= 2048 && (Cp & (Cp - 1)) == 0; }
+
+extern "C" {
+
+int clamd_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float* scale, float* shift, float* save_mean, float* save_istd,
+                      int Cp, int C, double count, double momentum, double eps, void* stream) {
+    if (Cp <= 0 || C > Cp) return clamd_fail("bn_finalize: bad channel counts");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, gamma,
+                       beta, running_mean, running_var, scale, shift, save_mean, save_istd, Cp, C, (float)count,
+                       (float)momentum, (float)eps);
+    return clamd_check_launch("bn_finalize");
+}
+
+int clamd_bn_apply(const void* y, int y_ldc, const float* scale, const float* shift, void* out, int out_ldc,
+                   void* pooled, int p_ldc, int B, int H, int W, int Cp, int dtype, void* stream) {
+    if (!pow2_channels(Cp)) return clamd_fail("bn_apply: physical channels must be a power of two in [32,2048]");
+    if (pooled && ((H | W) & 1)) return clamd_fail("bn_apply: pooling needs even H, W");
+    const long long nitem = (pooled ? (long long)B * (H / 2) * (W / 2) : (long long)B * H * W) * (Cp / 8);
+    dim3 g(ew_grid(nitem, 8192)), b(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T, P) hipLaunchKernelGGL((bn_apply_kernel<T, P>), g, b, 0, s, (const T*)y, y_ldc, scale, shift, \
+                                        (T*)out, out_ldc, (T*)pooled, p_ldc, B, H, W, Cp)
+    if (dtype == CLAMD_BF16) { if (pooled) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
+    else if (dtype == CLAMD_F32) { if (pooled) LAUNCH(float, true); else LAUNCH(float, false); }
+    else return clamd_fail("bn_apply: bad dtype");
+#undef LAUNCH
+    return clamd_check_launch("bn_apply");
+}
+
+int clamd_bn_bwd_reduce(const void* ga, int ga_ldc, const void* gp, int gp_ldc, const void* y, int y_ldc,
+                        const float* scale, const float* shift, float* sums, int B, int H, int W, int Cp,
+                        int dtype, void* stream) {
+    if (!pow2_channels(Cp)) return clamd_fail("bn_bwd_reduce: physical channels must be a power of two in [32,2048]");
+    if (!gp && !ga) return clamd_fail("bn_bwd_reduce: no gradient source");
+    const int rows = 256 / (Cp / 8) > 0 ? 256 / (Cp / 8) : 1;
+    const long long npix = gp ? (long long)B * (H / 2) * (W / 2) : (long long)B * H * W;
+    long long gb = (npix + rows - 1) / rows;
+    dim3 g((unsigned)(gb > 2048 ? 2048 : gb)), b(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T, P) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, P>), g, b, 0, s, (const T*)ga, ga_ldc, \
+                                        (const T*)gp, gp_ldc, (const T*)y, y_ldc, scale, shift, sums, B, H, W, Cp)
+    if (dtype == CLAMD_BF16) { if (gp) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
+    else if (dtype == CLAMD_F32) { if (gp) LAUNCH(float, true); else LAUNCH(float, false); }
+    else return clamd_fail("bn_bwd_reduce: bad dtype");
+#undef LAUNCH
+    return clamd_check_launch("bn_bwd_reduce");
+}
+
+int clamd_bn_bwd_finalize(const float* sums, const float* gamma, const float* save_mean, const float* save_istd,
+                          float* k012, float* dgamma, float* dbeta, float* dbias, int Cp, int C, double count,
+                          void* stream) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Cp + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums,
+                       gamma, save_mean, save_istd, k012, dgamma, dbeta, dbias, Cp, C, (float)count);
+    return clamd_check_launch("bn_bwd_finalize");
+}
+
+int clamd_bn_bwd_apply(const void* ga, int ga_ldc, const void* gp, int gp_ldc, const void* y, int y_ldc,
+                       const float* scale, const float* shift, const float* k012, void* gz, int gz_ldc, int B,
+                       int H, int W, int Cp, int dtype, void* stream) {
+    if (!pow2_channels(Cp)) return clamd_fail("bn_bwd_apply: physical channels must be a power of two in [32,2048]");
+    const long long nitem = (gp ? (long long)B * (H / 2) * (W / 2) : (long long)B * H * W) * (Cp / 8);
+    dim3 g(ew_grid(nitem, 8192)), b(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T, P) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, P>), g, b, 0, s, (const T*)ga, ga_ldc, \
+                                        (const T*)gp, gp_ldc, (const T*)y, y_ldc, scale, shift, k012, (T*)gz, gz_ldc, B, H, W, Cp)
+    if (dtype == CLAMD_BF16) { if (gp) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
+    else if (dtype == CLAMD_F32) { if (gp) LAUNCH(float, true); else LAUNCH(float, false); }
+    else return clamd_fail("bn_bwd_apply: bad dtype");
+#undef LAUNCH
+    return clamd_check_launch("bn_bwd_apply");
+}
+
+int clamd_channel_sum(const void* g, int ldc, float* out, long long npix, int Cp, int C, int dtype, void* stream) {
+    if (!pow2_channels(Cp)) return clamd_fail("channel_sum: physical channels must be a power of two in [32,2048]");
+    const int rows = 256 / (Cp / 8) > 0 ? 256 / (Cp / 8) : 1;
+    long long gb = (npix + rows - 1) / rows;
+    dim3 gr((unsigned)(gb > 1024 ? 1024 : gb)), b(256);
+    if (dtype == CLAMD_BF16)
+        hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, gr, b, 0, (hipStream_t)stream, (const bf16_t*)g, ldc, out, npix, Cp, C);
+    else if (dtype == CLAMD_F32)
+        hipLaunchKernelGGL(channel_sum_kernel<float>, gr, b, 0, (hipStream_t)stream, (const float*)g, ldc, out, npix, Cp, C);
+    else return clamd_fail("channel_sum: bad dtype");
+    return clamd_check_launch("channel_sum");
+}
+
+int clamd_nchw_to_nhwc(const float* src, void* dst, int ldc, int B, int C, int H, int W, int Cp, double mul,
+                       int dtype, void* stream) {
+    if (Cp % 8 || C > Cp) return clamd_fail("nchw_to_nhwc: bad channel counts");
+    const long long nitem = (long long)B * H * W * (Cp / 8);
+    dim3 g(ew_grid(nitem, 8192)), b(256);
+    if (dtype == CLAMD_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, src, (bf16_t*)dst, ldc, B, C, H, W, Cp, (float)mul);
+    else if (dtype == CLAMD_F32)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, g, b, 0, (hipStream_t)stream, src, (float*)dst, ldc, B, C, H, W, Cp, (float)mul);
+    else return clamd_fail("nchw_to_nhwc: bad dtype");
+    return clamd_check_launch("nchw_to_nhwc");
+}
+
+int clamd_nhwc_to_nchw(const void* src, int ldc, float* dst, int B, int C, int H, int W, int dtype, void* stream) {
+    const long long n = (long long)B * C * H * W;
+    dim3 g(ew_grid(n, 8192)), b(256);
+    if (dtype == CLAMD_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, (const bf16_t*)src, ldc, dst, B, C, H, W);
+    else if (dtype == CLAMD_F32)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, g, b, 0, (hipStream_t)stream, (const float*)src, ldc, dst, B, C, H, W);
+    else return clamd_fail("nhwc_to_nchw: bad dtype");
+    return clamd_check_launch("nhwc_to_nchw");
+}
+
+}  // extern "C"

@@ -1,0 +1,391 @@
+// Implicit-GEMM convolution kernels for gfx950 (SURVEY.md §8a rows A3, A7, A9 and their data-gradients in A11).
+//
+//   out[pixel m, n] = sum_{tap t} sum_{k} A_t[m, k] * Wp[t][n][k]        M = B*H*W pixels, fp32 accumulate
+//
+// One 256-thread workgroup (4 waves) owns a TH x TW = 256-pixel spatial tile x 64 output channels; each wave owns
+// 64 pixels x 64 channels = 2x2 MFMA tiles of 32x32 (v_mfma_f32_32x32x16_bf16, or v_mfma_f32_32x32x2_f32 for
+// the exact-fp32 path).  Per K-step the block stages through LDS
+//   * the (TH+2)x(TW+2) input halo tile of one 64-byte channel chunk (32 bf16 / 16 f32 channels), re-used by all
+//     nine taps (zero padding is materialised here, so the MFMA loop is branch-free), and
+//   * the 9 x 64 x 64-byte filter slab of that chunk,
+// both in a [16-byte group][row] layout so every ds_read_b128 of a fragment walks consecutive 16-B slots
+// (conflict-free), with the row count padded to == 2 (mod 8) so the staging ds_write_b128 are conflict-free too.
+// Global loads for K-step k+1 are issued into registers before the MFMA loop of K-step k (issue-early /
+// write-late), two workgroups per CU overlap each other's barriers.
+//
+// A-operand gathers (MODE):  CONV3 3x3/s1/p1 halo tile;  PW 1x1;  UP2 = the data-gradient of ConvTranspose2d(k2,s2):
+//                            K runs over (dy,dx,c) and pixel (y,x) reads input pixel (2y+dy, 2x+dx).
+// Epilogues (EPI):  NHWC  (+bias, ReLU, per-channel sum / sum-of-squares for BatchNorm, store T),
+//                   UP2   (ConvTranspose2d forward: column n = (dy,dx,co) is scattered to pixel (2y+dy,2x+dx)),
+//                   NCHW  (logits head: fp32 NCHW, only the logical classes).
+#include "common.hip.h"
+#include "clamd_internal.h"
+
+namespace clamd {
+
+enum { MODE_CONV3 = 0, MODE_PW = 1, MODE_UP2 = 2 };
+enum { EPI_NHWC = 0, EPI_UP2 = 1, EPI_NCHW = 2 };
+
+struct IgemmParams {
+    const void* x; int x_ldc;
+    const void* w;          // packed [taps][Np][Kp], K innermost
+    const float* bias;      // indexed by n (NHWC/NCHW) or by n % aux (UP2 epilogue); may be null
+    void* y; int y_ldc;
+    float* stats;           // [STAT_REPLICAS][2][Np] or null
+    int B, H, W;            // pixel grid of the GEMM rows
+    int Kp, Np;
+    int relu;
+    int aux;                // EPI_UP2: convT Cout_p ; EPI_NCHW: logical classes ; MODE_UP2: channels per (dy,dx)
+    int m_fastest;
+};
+
+template <int MODE, int TW> struct Geo {
+    static constexpr int TH = 256 / TW;
+    static constexpr int NT = MODE == MODE_CONV3 ? 9 : 2;          // filter slabs per staged K-step
+    static constexpr int NIN = MODE == MODE_CONV3 ? 1 : NT;        // input slabs per staged K-step
+    static constexpr int HW_ = MODE == MODE_CONV3 ? TW + 2 : TW;
+    static constexpr int HH_ = MODE == MODE_CONV3 ? TH + 2 : TH;
+    static constexpr int NPIX = HW_ * HH_;
+    static constexpr int NPIXP = NPIX + ((10 - NPIX % 8) % 8);     // == 2 (mod 8)
+    static constexpr int NJ = (NPIX * 4 + 255) / 256;              // 16-B input loads per thread per slab
+    static constexpr int IN_SLOTS = NIN * 4 * NPIXP;
+    static constexpr int WG = 66;                                  // padded channel rows per group, == 2 (mod 8)
+    static constexpr int WT_SLOTS = NT * 4 * WG;
+    static constexpr int EPI_SLOTS = 4 * 32 * 68 / 4;              // fp32 transposition buffer, 4 waves x [32][68]
+    static constexpr int SLOTS = IN_SLOTS + WT_SLOTS > EPI_SLOTS ? IN_SLOTS + WT_SLOTS : EPI_SLOTS;
+};
+
+template <typename T, int MODE, int EPI, int TW>
+__global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
+    using G = Geo<MODE, TW>;
+    constexpr int TH = G::TH, NT = G::NT, NIN = G::NIN, HW_ = G::HW_, NPIX = G::NPIX, NPIXP = G::NPIXP, NJ = G::NJ;
+    constexpr int KC = DT<T>::KC, VEC = DT<T>::VEC;
+    __shared__ uint4 smem[G::SLOTS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const T* __restrict__ xg = (const T*)p.x;
+    const T* __restrict__ wg = (const T*)p.w;
+
+    // ---- which tile -------------------------------------------------------------------------------
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int ntm = tiles_x * tiles_y * p.B, ntn = (p.Np + 63) >> 6;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    if (p.m_fastest) { tm = bid % ntm; tn = bid / ntm; } else { tn = bid % ntn; tm = bid / ntn; }
+    const int x0 = (tm % tiles_x) * TW, y0 = ((tm / tiles_x) % tiles_y) * TH, b = tm / (tiles_x * tiles_y);
+    const int n0 = tn * 64;
+
+    // ---- per-thread staging descriptors (constant over the K loop) ---------------------------------
+    const int g4 = tid & 3;
+    int in_off[NJ];   // element offset of this thread's 16-B group at channel 0, or -1
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int pix = (tid >> 2) + 64 * j;
+        const int hy = pix / HW_, hx = pix - hy * HW_;
+        int off = -1;
+        if (pix < NPIX) {
+            if constexpr (MODE == MODE_CONV3) {
+                const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) off = ((b * p.H + yy) * p.W + xx) * p.x_ldc + g4 * VEC;
+            } else if constexpr (MODE == MODE_PW) {
+                const int yy = y0 + hy, xx = x0 + hx;
+                if (yy < p.H && xx < p.W) off = ((b * p.H + yy) * p.W + xx) * p.x_ldc + g4 * VEC;
+            } else {
+                const int yy = y0 + hy, xx = x0 + hx;
+                if (yy < p.H && xx < p.W) off = ((b * 2 * p.H + 2 * yy) * 2 * p.W + 2 * xx) * p.x_ldc + g4 * VEC;
+            }
+        }
+        in_off[j] = off;
+    }
+    const int wco = tid >> 2;
+    const bool w_ok = n0 + wco < p.Np;
+    const long long w_row = (long long)(n0 + wco) * p.Kp + g4 * VEC;   // + tap*Np*Kp + k0
+
+    uint4 rin[NIN][NJ], rw[NT];
+
+// Global -> register staging of K-step `ks` (macro, not a lambda: the register arrays must stay in VGPRs).
+#define IGEMM_GLOAD(ks_)                                                                                          \
+    do {                                                                                                          \
+        if constexpr (MODE == MODE_CONV3) {                                                                       \
+            const int k0_ = (ks_) * KC;                                                                           \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                        \
+                rin[0][j] = ldg16(xg + in_off[j] + k0_, in_off[j] >= 0);                                          \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
+                rw[t] = ldg16(wg + (long long)t * p.Np * p.Kp + w_row + k0_, w_ok);                               \
+        } else {                                                                                                  \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                      \
+                const int k0_ = ((ks_) * NT + t) * KC;                                                            \
+                const bool kok_ = k0_ < p.Kp;                                                                     \
+                int koff_ = k0_;                                                                                  \
+                if constexpr (MODE == MODE_UP2) {                                                                 \
+                    const int q_ = k0_ / p.aux, c0_ = k0_ - q_ * p.aux;                                           \
+                    koff_ = ((q_ >> 1) * 2 * p.W + (q_ & 1)) * p.x_ldc + c0_;                                     \
+                }                                                                                                 \
+                _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                    \
+                    rin[t][j] = ldg16(xg + in_off[j] + koff_, kok_ && in_off[j] >= 0);                            \
+                rw[t] = ldg16(wg + w_row + k0_, kok_ && w_ok);                                                    \
+            }                                                                                                     \
+        }                                                                                                         \
+    } while (0)
+
+#define IGEMM_LDS_STORE()                                                                                         \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int t = 0; t < NIN; ++t)                                                           \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                      \
+                const int pix_ = (tid >> 2) + 64 * j;                                                             \
+                if (pix_ < NPIX) smem[t * 4 * NPIXP + g4 * NPIXP + pix_] = rin[t][j];                             \
+            }                                                                                                     \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) smem[G::IN_SLOTS + (t * 4 + g4) * G::WG + wco] = rw[t];    \
+    } while (0)
+
+    // ---- fragment addresses ---------------------------------------------------------------------------
+    int apix[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = 64 * wave + 32 * mt + r;
+        apix[mt] = (m / TW) * HW_ + (m % TW);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = MODE == MODE_CONV3 ? p.Kp / KC : (p.Kp + KC * NT - 1) / (KC * NT);
+    IGEMM_GLOAD(0);
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks) __syncthreads();          // every wave finished reading the previous K-step's tiles
+        IGEMM_LDS_STORE();
+        __syncthreads();
+        if (ks + 1 < nk) IGEMM_GLOAD(ks + 1);   // in flight during the MFMA loop below
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int in_base = MODE == MODE_CONV3 ? (t / 3) * HW_ + (t % 3) : t * 4 * NPIXP;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int g = kk * 2 + h;
+                const uint4 a0 = smem[in_base + g * NPIXP + apix[0]];
+                const uint4 a1 = smem[in_base + g * NPIXP + apix[1]];
+                const uint4 b0 = smem[G::IN_SLOTS + (t * 4 + g) * G::WG + r];
+                const uint4 b1 = smem[G::IN_SLOTS + (t * 4 + g) * G::WG + 32 + r];
+                mma16<T>(a0, b0, acc[0][0]);
+                mma16<T>(a0, b1, acc[0][1]);
+                mma16<T>(a1, b0, acc[1][0]);
+                mma16<T>(a1, b1, acc[1][1]);
+            }
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------------
+    // accumulator (mt, nt, reg): pixel m = 64*wave + 32*mt + acc_row(reg,h), channel n = n0 + 32*nt + r
+    float bcol[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = n0 + 32 * nt + r;
+        const int bi = EPI == EPI_UP2 ? n % p.aux : n;
+        bcol[nt] = (p.bias && n < p.Np) ? p.bias[bi] : 0.f;
+    }
+    unsigned vmask = 0;   // bit (mt*16 + reg): the pixel of that accumulator row lies inside the image
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = 64 * wave + 32 * mt + acc_row(e, h);
+            if (y0 + m / TW < p.H && x0 + m % TW < p.W) vmask |= 1u << (mt * 16 + e);
+        }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[mt][nt][e] + bcol[nt];
+                if (p.relu) v = fmaxf(v, 0.f);
+                acc[mt][nt][e] = v;
+            }
+
+    if constexpr (EPI == EPI_NCHW) {
+        // logits: lane = class, 4 consecutive accumulator registers = 4 consecutive pixels along W
+        float* out = (float*)p.y;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + 32 * nt + r;
+            if (n >= p.aux) continue;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = 64 * wave + 32 * mt + 8 * q + 4 * h;
+                    const int yy = y0 + m / TW, xx = x0 + m % TW;
+                    if (yy >= p.H) continue;
+                    float* dst = out + (((long long)b * p.aux + n) * p.H + yy) * p.W + xx;
+                    if (xx + 3 < p.W && (p.W & 3) == 0) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1],
+                                                                      acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (xx + e < p.W) dst[e] = acc[mt][nt][4 * q + e];
+                    }
+                }
+        }
+        return;
+    } else {
+        __syncthreads();   // all waves are done with the staging tiles: LDS becomes the transposition buffer
+        float* ebuf = reinterpret_cast<float*>(smem);
+        if constexpr (EPI == EPI_NHWC) {
+            if (p.stats) {
+                float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float v = (vmask >> (mt * 16 + e)) & 1 ? acc[mt][nt][e] : 0.f;
+                            s1[nt] += v;
+                            s2[nt] += v * v;
+                        }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    s1[nt] += __shfl_xor(s1[nt], 32);
+                    s2[nt] += __shfl_xor(s2[nt], 32);
+                }
+                // [wave][2][64] partials at the top of the buffer (beyond the 4*32*68 transposition area? no:
+                // use a separate tail region that the transposition does not touch)
+                float* sbuf = ebuf + 4 * 32 * 68;
+                if (h == 0) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        sbuf[(wave * 2 + 0) * 64 + 32 * nt + r] = s1[nt];
+                        sbuf[(wave * 2 + 1) * 64 + 32 * nt + r] = s2[nt];
+                    }
+                }
+                __syncthreads();
+                if (tid < 128) {
+                    const int k = tid >> 6, c = tid & 63;
+                    const float t = sbuf[(0 * 2 + k) * 64 + c] + sbuf[(1 * 2 + k) * 64 + c] +
+                                    sbuf[(2 * 2 + k) * 64 + c] + sbuf[(3 * 2 + k) * 64 + c];
+                    if (n0 + c < p.Np)
+                        atomicAdd(p.stats + ((size_t)(blockIdx.x % STAT_REPLICAS) * 2 + k) * p.Np + n0 + c, t);
+                }
+            }
+        }
+        T* out = (T*)p.y;
+        float* wbuf = ebuf + wave * 32 * 68;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) wbuf[acc_row(e, h) * 68 + 32 * nt + r] = acc[mt][nt][e];
+            __syncthreads();
+            // 8 lanes per pixel row (8 channels each), 8 rows per pass, 4 passes
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + (lane >> 3), cgp = lane & 7;
+                const int m = 64 * wave + 32 * mt + row;
+                const int yy = y0 + m / TW, xx = x0 + m % TW;
+                const int n = n0 + cgp * 8;
+                if (yy < p.H && xx < p.W && n < p.Np) {
+                    float v[8];
+                    const float4 lo = *reinterpret_cast<const float4*>(wbuf + row * 68 + cgp * 8);
+                    const float4 hi = *reinterpret_cast<const float4*>(wbuf + row * 68 + cgp * 8 + 4);
+                    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+                    long long off;
+                    if constexpr (EPI == EPI_NHWC) {
+                        off = (((long long)b * p.H + yy) * p.W + xx) * p.y_ldc + n;
+                    } else {   // EPI_UP2
+                        const int q = n / p.aux, co = n - q * p.aux;
+                        off = (((long long)b * 2 * p.H + 2 * yy + (q >> 1)) * 2 * p.W + 2 * xx + (q & 1)) * p.y_ldc + co;
+                    }
+                    Vec8<T>::store(out + off, v);
+                }
+            }
+        }
+    }
+}
+
+// EPI_NHWC statistics scratch lives after the transposition area: make sure the static buffer covers it.
+static_assert(Geo<MODE_CONV3, 32>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4, "LDS too small for epilogue");
+static_assert(Geo<MODE_CONV3, 16>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4, "LDS too small for epilogue");
+static_assert(Geo<MODE_PW, 32>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4, "LDS too small for epilogue");
+static_assert(Geo<MODE_PW, 16>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4, "LDS too small for epilogue");
+
+template <typename T, int MODE, int EPI>
+static int launch_tw(const IgemmParams& p, hipStream_t s) {
+    const bool wide = p.W >= 32;
+    const int TW = wide ? 32 : 16, TH = 256 / TW;
+    const long long tiles = (long long)((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.B;
+    const long long nblk = tiles * ((p.Np + 63) / 64);
+    if (nblk <= 0 || nblk > 0x7fffffff) return clamd_fail("igemm: grid out of range");
+    if (wide) hipLaunchKernelGGL((igemm_kernel<T, MODE, EPI, 32>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((igemm_kernel<T, MODE, EPI, 16>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+    return clamd_check_launch("igemm");
+}
+
+template <int MODE, int EPI>
+static int launch(const IgemmParams& p, int dtype, hipStream_t s) {
+    if (dtype == CLAMD_BF16) return launch_tw<bf16_t, MODE, EPI>(p, s);
+    if (dtype == CLAMD_F32) return launch_tw<float, MODE, EPI>(p, s);
+    return clamd_fail("igemm: bad dtype");
+}
+
+static int check_common(const IgemmParams& p, const char* who) {
+    if (p.B <= 0 || p.H <= 0 || p.W <= 0) return clamd_fail("igemm: empty problem");
+    if (p.Kp % 32 || p.Np % 32 || p.x_ldc % 8 || p.y_ldc % 8) return clamd_fail("igemm: channel counts/pitches must be padded (K,N %32, ldc %8)");
+    // 32-bit element offsets inside the kernel
+    const long long in_elems = (long long)p.B * p.H * p.W * p.x_ldc * (who[0] == 'u' ? 4 : 1);
+    if (in_elems >= (1ll << 31)) return clamd_fail("igemm: input tensor exceeds 2^31 elements");
+    return 0;
+}
+
+}  // namespace clamd
+
+using namespace clamd;
+
+extern "C" {
+
+int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
+                  float* stats, int B, int H, int W, int Cin_p, int Cout_p, int relu, int m_fastest, int dtype,
+                  void* stream) {
+    IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, m_fastest};
+    if (int e = check_common(p, "conv3x3")) return e;
+    return launch<MODE_CONV3, EPI_NHWC>(p, dtype, (hipStream_t)stream);
+}
+
+int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc, int B,
+                  int H, int W, int Cin_p, int Cout_p, int dtype, void* stream) {
+    IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, nullptr, B, H, W, Cin_p, Cout_p, 0, 0, 0};
+    if (int e = check_common(p, "conv1x1")) return e;
+    return launch<MODE_PW, EPI_NHWC>(p, dtype, (hipStream_t)stream);
+}
+
+int clamd_conv1x1_logits(const void* x, int x_ldc, const void* w_packed, const float* bias, float* logits_nchw,
+                         int B, int H, int W, int Cin_p, int Cout_p, int num_classes, int dtype, void* stream) {
+    IgemmParams p{x, x_ldc, w_packed, bias, logits_nchw, 8, nullptr, B, H, W, Cin_p, Cout_p, 0, num_classes, 0};
+    if (int e = check_common(p, "conv1x1_logits")) return e;
+    if (num_classes > Cout_p) return clamd_fail("conv1x1_logits: num_classes > padded Cout");
+    return launch<MODE_PW, EPI_NCHW>(p, dtype, (hipStream_t)stream);
+}
+
+int clamd_convT2x2_fwd(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc, int B,
+                       int h, int w, int Cin_p, int Cout_p, int dtype, void* stream) {
+    IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, nullptr, B, h, w, Cin_p, 4 * Cout_p, 0, Cout_p, 0};
+    if (int e = check_common(p, "convT_fwd")) return e;
+    return launch<MODE_PW, EPI_UP2>(p, dtype, (hipStream_t)stream);
+}
+
+int clamd_convT2x2_dgrad(const void* gy, int gy_ldc, const void* w_packed, void* gx, int gx_ldc, int B, int h, int w,
+                         int Cin_p, int Cout_p, int dtype, void* stream) {
+    IgemmParams p{gy, gy_ldc, w_packed, nullptr, gx, gx_ldc, nullptr, B, h, w, 4 * Cout_p, Cin_p, 0, Cout_p, 0};
+    if (int e = check_common(p, "up2_dgrad")) return e;
+    return launch<MODE_UP2, EPI_NHWC>(p, dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,343 @@
+// Remaining pieces of the train-step path: error plumbing, weight re-packing (fp32 NCHW-style master parameters ->
+// the K-innermost compute-dtype layouts the implicit-GEMM kernels read), fused per-pixel cross-entropy forward+backward
+// (+ the build-defined distillation term), fused multi-tensor Adam (+ L2-to-old-weights, A13),
+// and the GPU-resident arg-max/confusion-matrix instrument.
+#include <string.h>
+#include <stdio.h>
+#include "common.hip.h"
+#include "clamd_internal.h"
+
+static thread_local char g_err[512] = "";
+
+int clamd_fail(const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return -1;
+}
+int clamd_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return -2;
+}
+
+namespace clamd {
+
+// ------------------------------------------------------------------------------------------------ pack
+struct PackJob {
+    const float* src;
+    void* dst;
+    int T, Np, Kp;               // physical extents iterated
+    int N, K;                    // logical extents
+    long long st, sn, sk;        // source strides (elements) of logical (t, n, k)
+    long long dt, dn, dk;        // destination strides (elements) of physical (t, n, k)
+    int n_seg0, n_seg0p;         // physical n -> logical: n < n_seg0p ? (n < n_seg0 ? n : pad) : n_seg0 + (n - n_seg0p)
+    int k_seg0, k_seg0p;
+    int flip;                    // read source tap T-1-t (spatially flipped filter for the data gradient)
+    int dst_f32;                 // destination element type: 1 = float, 0 = compute dtype of the launch
+    int block0;                  // first block of this job in the fused launch
+    int pad_;
+};
+
+__device__ inline int phys2log(int p, int seg0, int seg0p, int L) {
+    if (p < seg0p) return p < seg0 ? p : -1;
+    const int l = seg0 + (p - seg0p);
+    return l < L ? l : -1;
+}
+
+template <typename T>
+__global__ void pack_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    // locate the job of this block (jobs are sorted by block0)
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJob j = jobs[lo];
+    const long long total = (long long)j.T * j.Np * j.Kp;
+    const long long i = (long long)(blockIdx.x - j.block0) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % j.Kp), n = (int)((i / j.Kp) % j.Np), t = (int)(i / ((long long)j.Kp * j.Np));
+    const int kl = phys2log(k, j.k_seg0, j.k_seg0p, j.K), nl = phys2log(n, j.n_seg0, j.n_seg0p, j.N);
+    float v = 0.f;
+    if (kl >= 0 && nl >= 0) v = j.src[(j.flip ? j.T - 1 - t : t) * j.st + nl * j.sn + kl * j.sk];
+    const long long d = t * j.dt + n * j.dn + k * j.dk;
+    if (j.dst_f32) ((float*)j.dst)[d] = v;
+    else st1<T>((T*)j.dst + d, v);
+}
+
+// ------------------------------------------------------------------------------------------------ loss
+// logits NCHW fp32 [B,K,H,W]; labels int64 [B,H,W].  nn.CrossEntropyLoss() (trainer.py:113): mean over pixels
+// whose label != ignore_index.  Optional distillation (build-defined, parity unpinned):
+//   + lam * mean_px KL( softmax(z_old[:, :c_old]/T) || softmax(z[:, :c_old]/T) )
+__global__ void count_valid_kernel(const long long* __restrict__ labels, long long n, long long ignore_index,
+                                   int K, unsigned int* count) {
+    unsigned int c = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long l = labels[i];
+        c += (l != ignore_index && l >= 0 && l < K) ? 1u : 0u;
+    }
+    c = (unsigned int)wave_sum((float)c);   // <= 64 * iterations: exact in fp32 for the sizes used here
+    if ((threadIdx.x & 63) == 0) atomicAdd(count, c);
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(256) ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                 const float* __restrict__ old_logits, int K_old_total, int c_old,
+                                                 float inv_temp, float lam, float* __restrict__ dlogits,
+                                                 float* __restrict__ partial, const unsigned int* __restrict__ nvalid,
+                                                 int B, int K, long long HW, long long ignore_index, float grad_scale) {
+    __shared__ float red[2][4];
+    const long long npix = (long long)B * HW;
+    const float inv_valid = 1.f / (float)max(*nvalid, 1u);
+    const float inv_npix = 1.f / (float)npix;
+    float ce_sum = 0.f, kd_sum = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / HW, p = i - b * HW;
+        const float* z = logits + b * K * HW + p;
+        float v[KMAX];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            v[k] = k < K ? z[k * HW] : -INFINITY;
+            mx = fmaxf(mx, v[k]);
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) se += k < K ? expf(v[k] - mx) : 0.f;
+        const float lse = mx + logf(se);
+        const long long lab = labels[i];
+        const bool valid = lab != ignore_index && lab >= 0 && lab < K;
+        float picked = 0.f;
+        float g[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const float sm = k < K ? expf(v[k] - lse) : 0.f;
+            const bool hit = valid && k == (int)lab;
+            picked = hit ? v[k] : picked;
+            g[k] = valid ? (sm - (hit ? 1.f : 0.f)) * inv_valid : 0.f;
+        }
+        if (valid) ce_sum += lse - picked;
+        if (old_logits) {
+            const float* zo = old_logits + b * K_old_total * HW + p;
+            float o[KMAX];
+            float mo = -INFINITY, mn = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                o[k] = k < c_old ? zo[k * HW] * inv_temp : -INFINITY;
+                mo = fmaxf(mo, o[k]);
+                mn = fmaxf(mn, k < c_old ? v[k] * inv_temp : -INFINITY);
+            }
+            float so = 0.f, sn = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                so += k < c_old ? expf(o[k] - mo) : 0.f;
+                sn += k < c_old ? expf(v[k] * inv_temp - mn) : 0.f;
+            }
+            const float lo = mo + logf(so), ln = mn + logf(sn);
+            float kl = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < c_old) {
+                    const float lp = o[k] - lo, lq = v[k] * inv_temp - ln;
+                    const float pk = expf(lp);
+                    kl += pk * (lp - lq);
+                    g[k] += lam * inv_npix * inv_temp * (expf(lq) - pk);
+                }
+            kd_sum += kl;
+        }
+        float* d = dlogits + b * K * HW + p;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) d[k * HW] = g[k] * grad_scale;
+    }
+    ce_sum = wave_sum(ce_sum);
+    kd_sum = wave_sum(kd_sum);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = ce_sum; red[1][wave] = kd_sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+__global__ void ce_finalize_kernel(const float* __restrict__ partial, int nblocks, const unsigned int* nvalid,
+                                   float inv_npix, float lam, float* out3) {
+    __shared__ double red[2][256];
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { a += partial[2 * i]; b += partial[2 * i + 1]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float ce = (float)(red[0][0] / (double)max(*nvalid, 1u));
+        const float kd = (float)(red[1][0] * inv_npix * lam);
+        out3[0] = ce + kd; out3[1] = ce; out3[2] = kd;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+// torch.optim.Adam semantics (trainer.py:108-110,176): weight decay 0, amsgrad off, maximize off.
+//   m = lerp(m, g, 1-b1); v = v*b2 + (1-b2)*g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// hyper (device, fp32): [0] lr  [1] beta1  [2] beta2  [3] eps  [4] grad_scale  [5] l2_lambda
+// state (device): step counter (int), derived[0] = lr/bc1, derived[1] = sqrt(bc2)
+struct AdamTensor { float* p; const float* g; float* m; float* v; const float* old; long long n; };
+struct AdamChunk { int tensor; int chunk; };
+constexpr int ADAM_CHUNK = 4096;
+
+__global__ void adam_prepare_kernel(const float* hyper, int* step, float* derived) {
+    const int s = *step + 1;
+    *step = s;
+    const double b1 = hyper[1], b2 = hyper[2];
+    derived[0] = (float)((double)hyper[0] / (1.0 - pow(b1, (double)s)));
+    derived[1] = (float)sqrt(1.0 - pow(b2, (double)s));
+}
+
+__global__ void __launch_bounds__(256) adam_kernel(const AdamTensor* __restrict__ tensors,
+                                                   const AdamChunk* __restrict__ chunks,
+                                                   const float* __restrict__ hyper, const float* __restrict__ derived,
+                                                   float* l2_accum) {
+    const AdamChunk c = chunks[blockIdx.x];
+    const AdamTensor t = tensors[c.tensor];
+    const float b1 = hyper[1], b2 = hyper[2], eps = hyper[3], gs = hyper[4], l2 = hyper[5];
+    const float step_size = derived[0], bc2s = derived[1];
+    const float w1 = 1.f - b1, w2 = 1.f - b2;
+    const long long base = (long long)c.chunk * ADAM_CHUNK;
+    float l2sum = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < ADAM_CHUNK / 256; ++k) {
+        const long long i = base + k * 256 + threadIdx.x;
+        if (i < t.n) {
+            float g = t.g[i] * gs;
+            const float p = t.p[i];
+            if (t.old) { const float d = p - t.old[i]; g += 2.f * l2 * d; l2sum += d * d; }
+            float m = t.m[i], v = t.v[i];
+            // torch lerp: weight < 0.5 ? m + w*(g-m) : g - (g-m)*(1-w)
+            m = (w1 < 0.5f) ? m + w1 * (g - m) : g - (g - m) * (1.f - w1);
+            v = v * b2 + (w2 * g) * g;
+            const float denom = sqrtf(v) / bc2s + eps;
+            t.p[i] = p - step_size * (m / denom);
+            t.m[i] = m; t.v[i] = v;
+        }
+    }
+    if (l2_accum) {
+        l2sum = wave_sum(l2sum);
+        if ((threadIdx.x & 63) == 0 && l2sum != 0.f) atomicAdd(l2_accum, l2sum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ metrics
+// arg-max over classes (first maximum wins, as torch.max / argmax) fused with the confusion-matrix histogram
+// conf[K*t + p] += 1 for 0 <= t < K  (metrics.py:32-38).  pred is optional (int64 [B,H,W]).
+__global__ void argmax_confusion_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                        long long* pred, unsigned long long* conf, int B, int K, int Kc, long long HW) {
+    extern __shared__ unsigned int hist[];   // Kc*Kc
+    for (int i = threadIdx.x; i < Kc * Kc; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const long long npix = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / HW, p = i - b * HW;
+        const float* z = logits + b * K * HW + p;
+        float best = z[0];
+        int arg = 0;
+        for (int k = 1; k < K; ++k) {
+            const float v = z[k * HW];
+            if (v > best) { best = v; arg = k; }
+        }
+        if (pred) pred[i] = arg;
+        if (labels) {
+            const long long t = labels[i];
+            if (t >= 0 && t < Kc) atomicAdd(&hist[(int)t * Kc + arg], 1u);
+        }
+    }
+    __syncthreads();
+    if (conf)
+        for (int i = threadIdx.x; i < Kc * Kc; i += blockDim.x)
+            if (hist[i]) atomicAdd(&conf[i], (unsigned long long)hist[i]);
+}
+
+__global__ void fill_kernel(float* p, long long n, float v) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+}  // namespace clamd
+
+using namespace clamd;
+
+extern "C" {
+
+const char* clamd_last_error(void) { return g_err; }
+int clamd_version(void) { return 100; }
+int clamd_sizeof_pack_job(void) { return (int)sizeof(PackJob); }
+int clamd_sizeof_adam_tensor(void) { return (int)sizeof(AdamTensor); }
+int clamd_adam_chunk_elems(void) { return ADAM_CHUNK; }
+int clamd_stat_replicas(void) { return STAT_REPLICAS; }
+int clamd_bn_bwd_nsums(void) { return 5; }
+
+int clamd_pack(const void* jobs_dev, int njobs, int total_blocks, int dtype, void* stream) {
+    if (njobs <= 0 || total_blocks <= 0) return clamd_fail("pack: empty job table");
+    if (dtype == CLAMD_BF16)
+        hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs_dev, njobs);
+    else if (dtype == CLAMD_F32)
+        hipLaunchKernelGGL(pack_kernel<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs_dev, njobs);
+    else return clamd_fail("pack: bad dtype");
+    return clamd_check_launch("pack");
+}
+
+size_t clamd_ce_workspace_bytes(void) { return (size_t)(2 * 2048 + 4) * sizeof(float); }
+
+int clamd_ce_fwd_bwd(const float* logits, const long long* labels, const float* old_logits, int K_old_total, int c_old,
+                     double temperature, double lam, float* dlogits, float* loss3, void* workspace, size_t ws_bytes,
+                     int B, int K, int H, int W, long long ignore_index, double grad_scale, void* stream) {
+    if (K < 1 || K > 32) return clamd_fail("ce: number of classes must be in [1, 32]");
+    if (old_logits && (c_old < 1 || c_old > K || c_old > K_old_total)) return clamd_fail("ce: bad c_old");
+    if (ws_bytes < clamd_ce_workspace_bytes()) return clamd_fail("ce: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    unsigned int* nvalid = (unsigned int*)(partial + 2 * 2048);
+    const long long HW = (long long)H * W, npix = (long long)B * HW;
+    hipError_t me = hipMemsetAsync(nvalid, 0, sizeof(unsigned int), s);
+    if (me != hipSuccess) return clamd_fail("ce: memset failed");
+    int g = (int)((npix + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(count_valid_kernel, dim3(g > 256 ? 256 : g), dim3(256), 0, s, labels, npix, ignore_index, K, nvalid);
+    hipLaunchKernelGGL(ce_kernel<32>, dim3(g), dim3(256), 0, s, logits, labels, old_logits, K_old_total, c_old,
+                       (float)(1.0 / temperature), (float)lam, dlogits, partial, nvalid, B, K, HW, ignore_index, (float)grad_scale);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, partial, g, nvalid, (float)(1.0 / (double)npix),
+                       (float)lam, loss3);
+    return clamd_check_launch("ce_fwd_bwd");
+}
+
+int clamd_adam_step(const void* tensors_dev, const void* chunks_dev, int nchunks, const float* hyper_dev, int* step_dev,
+                    float* derived_dev, float* l2_accum_dev, void* stream) {
+    if (nchunks <= 0) return clamd_fail("adam: no chunks");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, s, hyper_dev, step_dev, derived_dev);
+    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, s, (const AdamTensor*)tensors_dev,
+                       (const AdamChunk*)chunks_dev, hyper_dev, derived_dev, l2_accum_dev);
+    return clamd_check_launch("adam_step");
+}
+
+int clamd_argmax_confusion(const float* logits, const long long* labels, long long* pred, unsigned long long* conf,
+                           int B, int K, int Kc, int H, int W, void* stream) {
+    if (K < 1 || Kc < 1 || Kc > 64) return clamd_fail("argmax_confusion: bad class counts");
+    const long long npix = (long long)B * H * W;
+    int g = (int)((npix + 255) / 256);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(argmax_confusion_kernel, dim3(g), dim3(256), Kc * Kc * sizeof(unsigned int), (hipStream_t)stream,
+                       logits, labels, pred, conf, B, K, Kc, (long long)H * W);
+    return clamd_check_launch("argmax_confusion");
+}
+
+int clamd_fill_f32(float* p, long long n, double v, void* stream) {
+    int g = (int)((n + 255) / 256);
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(fill_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, p, n, (float)v);
+    return clamd_check_launch("fill");
+}
+
+}  // extern "C"

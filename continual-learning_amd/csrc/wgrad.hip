@@ -1,0 +1,284 @@
+// Weight-gradient kernels for gfx950 (wgrad of the 3x3 convs, the 1x1 head and the
+// ConvTranspose2d up-path).  All three are one GEMM whose contraction runs over PIXELS:
+//
+//   dW[t][r][c] = sum_{pixels p} A[p, r] * B[nbr_t(p), c]      r: channels of A, c: channels of B, t: tap
+//
+//   CONV3: A = g_z (d loss / d conv output), B = conv input u, nbr_t(p) = p + (dy-1, dx-1), zero outside the image
+//   PW   : A = d logits,                     B = head input,   nbr(p) = p
+//   UP2  : A = convT input,                  B = d convT output, nbr_t(y,x) = (2y+dy, 2x+dx)
+//
+// Both MFMA operands are therefore "transposed" (k = pixel is the strided dimension of an NHWC tensor).  bf16 uses
+// ds_read_b64_tr_b16, which gathers 4 pixels x 16 channels per 16-lane group straight from a [pixel][channel]
+// LDS image (pixel stride 192 B so the four rows of a group land on distinct bank quarters); f32 needs one element
+// per lane (32x32x2 MFMA), read with conflict-free ds_read_b32.
+//
+// A 256-thread workgroup owns a 64(r) x 64(c) x taps output tile, wave (wr,wc) a 32x32 x taps slice held in up to
+// 9 accumulators, and loops over its share of the pixel tiles (split-K across workgroups).  Partial tiles are
+// written as fp32 slabs [split][tap][r][c] and summed by wgrad_reduce_kernel into the parameter's own layout
+// ([Cout][Cin][3][3] / [Cin][Cout][2][2]) -- deterministic, no float atomics.
+#include "common.hip.h"
+#include "clamd_internal.h"
+
+namespace clamd {
+
+enum { WG_CONV3 = 0, WG_PW = 1, WG_UP2 = 2 };
+
+struct WgradParams {
+    const void* a; int a_ldc;
+    const void* b; int b_ldc;
+    float* partial;        // [nsplit][NT][Rp][Cp]
+    int B, H, W;           // pixel grid of A
+    int Rp, Cp;            // physical channels of A / B
+    int nsplit, tiles_per_split;
+};
+
+template <typename T, int MODE, int TW> struct WGeo {
+    static constexpr int TH = (sizeof(T) == 2 ? 128 : 64) / (MODE == 2 ? 2 : 1) / TW;   // pixel tile rows (UP2: B tile is 4x)
+    static constexpr int NT = MODE == WG_CONV3 ? 9 : (MODE == WG_UP2 ? 4 : 1);
+    static constexpr int BW = MODE == WG_CONV3 ? TW + 2 : (MODE == WG_UP2 ? 2 * TW : TW);
+    static constexpr int BH = MODE == WG_CONV3 ? TH + 2 : (MODE == WG_UP2 ? 2 * TH : TH);
+    static constexpr int STRIDE = sizeof(T) == 2 ? 192 : 256;                   // bytes per pixel row (64 channels + pad)
+    static constexpr int APIX = TH * TW, BPIX = BH * BW;
+    static constexpr int GPP = 64 * sizeof(T) / 16;                             // 16-B groups per pixel (8 or 16)
+    static constexpr int NJA = (APIX * GPP + 255) / 256, NJB = (BPIX * GPP + 255) / 256;
+    static constexpr int BYTES = (APIX + BPIX) * STRIDE;
+};
+
+__device__ inline uint2 ds_tr16(const char* lds_addr) {
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_addr));
+    return __builtin_bit_cast(uint2, v);
+}
+
+template <typename T, int MODE, int TW>
+__global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
+    using G = WGeo<T, MODE, TW>;
+    constexpr int TH = G::TH, NT = G::NT, BW = G::BW, STRIDE = G::STRIDE, GPP = G::GPP, NJA = G::NJA, NJB = G::NJB;
+    constexpr int VEC = DT<T>::VEC;
+    __shared__ __attribute__((aligned(16))) char smem[G::BYTES];
+    char* const sa = smem;
+    char* const sb = smem + G::APIX * STRIDE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const T* __restrict__ ag = (const T*)p.a;
+    const T* __restrict__ bg = (const T*)p.b;
+
+    const int rt = (p.Rp + 63) >> 6, ct = (p.Cp + 63) >> 6;
+    int bid = blockIdx.x;
+    const int tr = bid % rt; bid /= rt;
+    const int tc = bid % ct; bid /= ct;
+    const int split = bid;
+    const int r0 = tr * 64, c0 = tc * 64;
+
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * p.B;
+    const int t_begin = split * p.tiles_per_split;
+    const int t_end = min(ntiles, t_begin + p.tiles_per_split);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    uint4 ra[NJA], rb[NJB];
+
+    auto gload = [&](int tile) {
+        const int x0 = (tile % tiles_x) * TW, y0 = ((tile / tiles_x) % tiles_y) * TH, b = tile / (tiles_x * tiles_y);
+#pragma unroll
+        for (int j = 0; j < NJA; ++j) {
+            const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;
+            const int yy = y0 + pix / TW, xx = x0 + pix % TW;
+            const bool ok = pix < G::APIX && yy < p.H && xx < p.W && r0 + g * VEC < p.Rp;
+            ra[j] = ldg16(ag + ((long long)(b * p.H + yy) * p.W + xx) * p.a_ldc + r0 + g * VEC, ok);
+        }
+#pragma unroll
+        for (int j = 0; j < NJB; ++j) {
+            const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;
+            const int hy = pix / BW, hx = pix % BW;
+            bool ok = pix < G::BPIX && c0 + g * VEC < p.Cp;
+            long long off;
+            if constexpr (MODE == WG_CONV3) {
+                const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+                ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                off = ((long long)(b * p.H + yy) * p.W + xx) * p.b_ldc;
+            } else if constexpr (MODE == WG_PW) {
+                const int yy = y0 + hy, xx = x0 + hx;
+                ok = ok && yy < p.H && xx < p.W;
+                off = ((long long)(b * p.H + yy) * p.W + xx) * p.b_ldc;
+            } else {
+                const int yy = 2 * y0 + hy, xx = 2 * x0 + hx;
+                ok = ok && yy < 2 * p.H && xx < 2 * p.W;
+                off = ((long long)(b * 2 * p.H + yy) * 2 * p.W + xx) * p.b_ldc;
+            }
+            rb[j] = ldg16(bg + off + c0 + g * VEC, ok);
+        }
+    };
+    auto lds_store = [&]() {
+#pragma unroll
+        for (int j = 0; j < NJA; ++j) {
+            const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;
+            if (pix < G::APIX) *reinterpret_cast<uint4*>(sa + pix * STRIDE + g * 16) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NJB; ++j) {
+            const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;
+            if (pix < G::BPIX) *reinterpret_cast<uint4*>(sb + pix * STRIDE + g * 16) = rb[j];
+        }
+    };
+
+    // B-tile pixel index of A-tile pixel (ty, tx) for tap t
+    auto bpix = [&](int ty, int tx, int t) -> int {
+        if constexpr (MODE == WG_CONV3) return (ty + t / 3) * BW + tx + t % 3;
+        else if constexpr (MODE == WG_PW) return ty * BW + tx;
+        else return (2 * ty + (t >> 1)) * BW + 2 * tx + (t & 1);
+    };
+
+    if (t_begin < t_end) gload(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        if (tile != t_begin) __syncthreads();
+        lds_store();
+        __syncthreads();
+        if (tile + 1 < t_end) gload(tile + 1);
+
+        if constexpr (sizeof(T) == 2) {
+            // bf16: k-group = 16 consecutive pixels of one tile row.  Transposed reads: lane -> (gq = lane>>4,
+            // q = (lane>>2)&3, pp = lane&3); it supplies the address of pixel (8*(gq>>1) + q) [+4 for the second
+            // read], channels 16*(gq&1) + 4*pp .. +3, and receives 4 pixels of channel 16*(gq&1) + (lane&15).
+            const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+            const int kq = 8 * (gq >> 1) + q;
+            const int a_ch = (32 * wr + 16 * (gq & 1) + 4 * pp) * 2;
+            const int b_ch = (32 * wc + 16 * (gq & 1) + 4 * pp) * 2;
+#pragma unroll 1
+            for (int ty = 0; ty < TH; ++ty)
+#pragma unroll
+                for (int xs = 0; xs < TW; xs += 16) {
+                    const char* ap = sa + (ty * TW + xs + kq) * STRIDE + a_ch;
+                    const uint2 alo = ds_tr16(ap), ahi = ds_tr16(ap + 4 * STRIDE);
+                    const uint4 af = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int step = MODE == WG_UP2 ? 2 : 1;
+                        const char* bp = sb + (bpix(ty, xs, t) + step * kq) * STRIDE + b_ch;
+                        const uint2 blo = ds_tr16(bp), bhi = ds_tr16(bp + 4 * step * STRIDE);
+                        const uint4 bf = make_uint4(blo.x, blo.y, bhi.x, bhi.y);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af),
+                                                                         __builtin_bit_cast(bf16x8, bf), acc[t], 0, 0, 0);
+                    }
+                }
+        } else {
+            // f32: one element per lane: A[channel lane&31][pixel lane>>5]
+            const int i = lane & 31, kh = lane >> 5;
+            const int step = MODE == WG_UP2 ? 2 : 1;
+#pragma unroll
+            for (int ty = 0; ty < TH; ++ty)
+#pragma unroll 4
+                for (int xs = 0; xs < TW; xs += 2) {
+                    const float av = *reinterpret_cast<const float*>(sa + (ty * TW + xs + kh) * STRIDE + (32 * wr + i) * 4);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float bv = *reinterpret_cast<const float*>(sb + (bpix(ty, xs, t) + step * kh) * STRIDE + (32 * wc + i) * 4);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                    }
+                }
+        }
+    }
+
+    // ---- store the partial slab: row = r0 + 32*wr + acc_row, col = c0 + 32*wc + (lane & 31) ------------
+    const int col = c0 + 32 * wc + (lane & 31), hh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = r0 + 32 * wr + acc_row(e, hh);
+            if (row < p.Rp && col < p.Cp)
+                p.partial[(((size_t)split * NT + t) * p.Rp + row) * p.Cp + col] = acc[t][e];
+        }
+}
+
+// out[rl][cl][t] = scale * sum_s partial[s][t][rp(rl)][cp(cl)]     (logical -> physical channel maps: two segments)
+struct ReduceParams {
+    const float* partial; float* out;
+    int nsplit, NT, Rp, Cp;
+    int R, C;                 // logical sizes
+    int r_seg0, r_seg0p;      // logical rows < r_seg0 map to themselves, the rest to r_seg0p + (r - r_seg0)
+    int c_seg0, c_seg0p;
+    int flip;                 // CONV3: out tap index = t (kernel tap (dy,dx) IS (ky,kx) for wgrad)
+};
+
+__global__ void wgrad_reduce_kernel(const ReduceParams p) {
+    const long long n = (long long)p.R * p.C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int cl = (int)(i % p.C), rl = (int)(i / p.C);
+        const int rp = rl < p.r_seg0 ? rl : p.r_seg0p + (rl - p.r_seg0);
+        const int cp = cl < p.c_seg0 ? cl : p.c_seg0p + (cl - p.c_seg0);
+        for (int t = 0; t < p.NT; ++t) {
+            float s = 0.f;
+            for (int k = 0; k < p.nsplit; ++k) s += p.partial[(((size_t)k * p.NT + t) * p.Rp + rp) * p.Cp + cp];
+            p.out[i * p.NT + t] = s;
+        }
+    }
+}
+
+template <typename T, int MODE>
+static int launch_wg(const WgradParams& p, hipStream_t s, int grid) {
+    if (p.W >= 32) hipLaunchKernelGGL((wgrad_kernel<T, MODE, 32>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<T, MODE, 16>), dim3(grid), dim3(256), 0, s, p);
+    return clamd_check_launch("wgrad");
+}
+
+}  // namespace clamd
+
+using namespace clamd;
+
+extern "C" {
+
+size_t clamd_wgrad_workspace_bytes(int mode, int B, int H, int W, int Rp, int Cp, int dtype) {
+    // upper bound used by callers to size the slab buffer: nsplit is capped at 512 blocks total (see below)
+    const int NT = mode == WG_CONV3 ? 9 : (mode == WG_UP2 ? 4 : 1);
+    const int rt = (Rp + 63) / 64, ct = (Cp + 63) / 64;
+    int nsplit = 512 / (rt * ct);
+    if (nsplit < 1) nsplit = 1;
+    (void)B; (void)H; (void)W; (void)dtype;
+    return (size_t)nsplit * NT * Rp * Cp * sizeof(float);
+}
+
+int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, float* workspace, size_t ws_bytes,
+                float* out, int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0,
+                int c_seg0p, int dtype, void* stream) {
+    if (mode < 0 || mode > 2) return clamd_fail("wgrad: bad mode");
+    if (Rp % 32 || Cp % 32 || a_ldc % 8 || b_ldc % 8) return clamd_fail("wgrad: channel counts/pitches must be padded");
+    if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("wgrad: empty problem");
+    const int NT = mode == WG_CONV3 ? 9 : (mode == WG_UP2 ? 4 : 1);
+    const int TW = W >= 32 ? 32 : 16;
+    const int TH = (dtype == CLAMD_BF16 ? 128 : 64) / (mode == WG_UP2 ? 2 : 1) / TW;
+    const int ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
+    const int rt = (Rp + 63) / 64, ct = (Cp + 63) / 64;
+    int nsplit = 512 / (rt * ct);
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > ntiles) nsplit = ntiles;
+    int per = (ntiles + nsplit - 1) / nsplit;
+    nsplit = (ntiles + per - 1) / per;
+    const size_t need = (size_t)nsplit * NT * Rp * Cp * sizeof(float);
+    if (need > ws_bytes) return clamd_fail("wgrad: workspace too small");
+    WgradParams p{a, a_ldc, b, b_ldc, workspace, B, H, W, Rp, Cp, nsplit, per};
+    const int grid = rt * ct * nsplit;
+    hipStream_t s = (hipStream_t)stream;
+    int e;
+    if (dtype == CLAMD_BF16) {
+        e = mode == WG_CONV3 ? launch_wg<bf16_t, WG_CONV3>(p, s, grid)
+          : mode == WG_PW    ? launch_wg<bf16_t, WG_PW>(p, s, grid) : launch_wg<bf16_t, WG_UP2>(p, s, grid);
+    } else if (dtype == CLAMD_F32) {
+        e = mode == WG_CONV3 ? launch_wg<float, WG_CONV3>(p, s, grid)
+          : mode == WG_PW    ? launch_wg<float, WG_PW>(p, s, grid) : launch_wg<float, WG_UP2>(p, s, grid);
+    } else return clamd_fail("wgrad: bad dtype");
+    if (e) return e;
+    ReduceParams rp{workspace, out, nsplit, NT, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p, 0};
+    const long long n = (long long)R * C;
+    int g = (int)((n + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, s, rp);
+    return clamd_check_launch("wgrad_reduce");
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+"""Per-pixel cross-entropy (+ build-defined continual-learning distillation) on libclamd's fused kernel.
+
+``CrossEntropyLoss()`` mirrors ``nn.CrossEntropyLoss()`` as the reference uses it (trainer.py:113,174): fp32 NCHW
+logits, int64 [B,H,W] labels, mean over non-ignored pixels, ignore_index -100.  Forward and backward are ONE kernel
+pass: the forward computes the loss and d loss / d logits; backward only scales it by the incoming gradient.
+
+``DistillationCrossEntropy`` adds  lam * mean_px KL(softmax(z_old[:, :c_old]/T) || softmax(z[:, :c_old]/T))  (LwF-style,
+SURVEY.md §8a row A12).  The reference has NO such code: this term is build-defined and its parity is
+pinned only by tests against this repo's own CPU restatement.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import call, ptr
+
+
+class _CEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, old_logits, c_old, temperature, lam, ignore_index):
+        if not logits.is_cuda:
+            raise RuntimeError('continual-learning_amd loss runs only on GPU tensors: there is no CPU fallback')
+        lib = _lib.load()
+        logits = logits.contiguous().float()
+        labels = labels.contiguous()
+        if labels.dtype != torch.int64:
+            raise TypeError('labels must be int64 (datasets/voc.py:72)')
+        B, K, H, W = logits.shape
+        if tuple(labels.shape) != (B, H, W):
+            raise ValueError(f'labels shape {tuple(labels.shape)} does not match logits {tuple(logits.shape)}')
+        dl = torch.empty_like(logits)
+        out3 = torch.empty(3, dtype=torch.float32, device=logits.device)
+        wsb = lib.clamd_ce_workspace_bytes()
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=logits.device)
+        kold = 0
+        if old_logits is not None:
+            old_logits = old_logits.contiguous().float()
+            kold = old_logits.shape[1]
+            if old_logits.shape[0] != B or tuple(old_logits.shape[2:]) != (H, W):
+                raise ValueError('old_logits must be [B, K_old, H, W]')
+        call('clamd_ce_fwd_bwd', ptr(logits), ptr(labels), ptr(old_logits), kold, int(c_old), float(temperature),
+             float(lam), ptr(dl), ptr(out3), ptr(ws), wsb, B, K, H, W, int(ignore_index), 1.0, _lib.stream_ptr())
+        ctx.save_for_backward(dl)
+        ctx.parts = out3
+        return out3[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        # g is the scalar upstream gradient (1.0 for loss.backward()); scaling happens in place on our own buffer
+        return dl.mul_(g), None, None, None, None, None, None
+
+
+class CrossEntropyLoss(nn.Module):
+    def __init__(self, ignore_index=-100):
+        super().__init__()
+        self.ignore_index = ignore_index
+
+    def forward(self, logits, labels):
+        return _CEFn.apply(logits, labels, None, 0, 1.0, 0.0, self.ignore_index)
+
+
+class DistillationCrossEntropy(nn.Module):
+    """CE(logits, labels) + lam * KL(old || new) over the first ``c_old`` classes at temperature T."""
+
+    def __init__(self, c_old, temperature=2.0, lam=1.0, ignore_index=-100):
+        super().__init__()
+        self.c_old, self.temperature, self.lam, self.ignore_index = c_old, temperature, lam, ignore_index
+
+    def forward(self, logits, labels, old_logits):
+        return _CEFn.apply(logits, labels, old_logits.detach(), self.c_old, self.temperature, self.lam, self.ignore_index)

@@ -1,0 +1,98 @@
+"""Thin host-side helpers over the C ABI: weight-packing job tables and single-kernel wrappers.
+
+Used by the UNet engine (unet.py) and by the per-kernel parity tests; every function here ends in a libclamd launch.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr
+
+TORCH_DT = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16}
+
+_PACK_DT = np.dtype({'names': ['src', 'dst', 'T', 'Np', 'Kp', 'N', 'K', 'st', 'sn', 'sk', 'dt', 'dn', 'dk',
+                               'n_seg0', 'n_seg0p', 'k_seg0', 'k_seg0p', 'flip', 'dst_f32', 'block0', 'pad_'],
+                     'formats': ['u8', 'u8', 'i4', 'i4', 'i4', 'i4', 'i4', 'i8', 'i8', 'i8', 'i8', 'i8', 'i8',
+                                 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4'],
+                     'offsets': [0, 8, 16, 20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 88, 92, 96, 100, 104, 108, 112, 116],
+                     'itemsize': 120})
+
+
+def cpad(c):
+    """Physical channel count: next power of two, at least 32 (kernels move 16-byte channel groups)."""
+    return max(32, 1 << (int(c) - 1).bit_length())
+
+
+class PackTable:
+    """Job table for clamd_pack: one fused launch re-packs every fp32 master parameter (see include/clamd.h)."""
+
+    def __init__(self):
+        self.jobs = []
+        self.dev_table = None
+
+    def add(self, src, dst, T, Np, Kp, N, K, st, sn, sk, dt, dn, dk, nseg=None, kseg=None, flip=0, f32=0):
+        nseg = nseg or (N, Np)
+        kseg = kseg or (K, Kp)
+        self.jobs.append((src.data_ptr(), dst.data_ptr(), T, Np, Kp, N, K, st, sn, sk, dt, dn, dk,
+                          nseg[0], nseg[1], kseg[0], kseg[1], flip, f32, 0, 0))
+
+    # ---- the layouts of include/clamd.h ----
+    def conv3x3(self, w, wf, wd, cin_segs, cout):
+        """w [Cout][Cin][3][3] fp32 -> wf [9][Cout_p][Cin_p] (forward) and wd [9][Cin_p][Cout_p] (data gradient,
+        taps flipped).  cin_segs: [(logical, physical), ...] one or two channel segments (concat inputs)."""
+        cin = sum(s[0] for s in cin_segs)
+        cin_p = sum(s[1] for s in cin_segs)
+        cout_p = cpad(cout)
+        seg = (cin_segs[0][0], cin_segs[0][1]) if len(cin_segs) == 2 else None
+        self.add(w, wf, 9, cout_p, cin_p, cout, cin, 1, cin * 9, 9, cout_p * cin_p, cin_p, 1, kseg=seg)
+        if wd is not None:
+            self.add(w, wd, 9, cin_p, cout_p, cin, cout, 1, 9, cin * 9, cin_p * cout_p, cout_p, 1, nseg=seg, flip=1)
+
+    def convT(self, w, wf, wd, cin, cout):
+        """w [Cin][Cout][2][2] -> wf [4][Cout_p][Cin_p] and wd [Cin_p][4][Cout_p]."""
+        cin_p, cout_p = cpad(cin), cpad(cout)
+        self.add(w, wf, 4, cout_p, cin_p, cout, cin, 1, 4, cout * 4, cout_p * cin_p, cin_p, 1)
+        if wd is not None:
+            self.add(w, wd, 4, cin_p, cout_p, cin, cout, 1, cout * 4, 4, cout_p, 4 * cout_p, 1)
+
+    def head(self, w, wf, wd, cin, k):
+        """w [K][Cin][1][1] -> wf [K_p][Cin_p] and wd [Cin_p][K_p]."""
+        cin_p, kp = cpad(cin), cpad(k)
+        self.add(w, wf, 1, kp, cin_p, k, cin, 0, cin, 1, 0, cin_p, 1)
+        if wd is not None:
+            self.add(w, wd, 1, cin_p, kp, cin, k, 0, 1, cin, 0, kp, 1)
+
+    def vector(self, v, dst, c):
+        """1-D fp32 vector -> zero-padded fp32 [cpad(c)]."""
+        self.add(v, dst, 1, 1, cpad(c), 1, c, 0, 0, 1, 0, 0, 1, f32=1)
+
+    def finalize(self, device):
+        assert _lib.load().clamd_sizeof_pack_job() == _PACK_DT.itemsize
+        arr = np.zeros(len(self.jobs), dtype=_PACK_DT)
+        blk = 0
+        for i, j in enumerate(self.jobs):
+            arr[i] = j
+            arr[i]['block0'] = blk
+            blk += (j[2] * j[3] * j[4] + 255) // 256
+        self.dev_table = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+        self.nblocks = blk
+        return self
+
+    def run(self, dcode, stream=None):
+        call('clamd_pack', ptr(self.dev_table), len(self.jobs), self.nblocks, dcode, stream or _lib.stream_ptr())
+
+
+# ---- single-kernel wrappers (tests, small tools) ----------------------------------------------------------------
+def to_nhwc(x_nchw, dcode, cp=None):
+    B, C, H, W = x_nchw.shape
+    cp = cp or cpad(C)
+    out = torch.empty(B, H, W, cp, dtype=TORCH_DT[dcode], device=x_nchw.device)
+    call('clamd_nchw_to_nhwc', ptr(x_nchw.contiguous().float()), ptr(out), cp, B, C, H, W, cp, 1.0, dcode, _lib.stream_ptr())
+    return out
+
+
+def from_nhwc(t, C, dcode):
+    B, H, W, ldc = t.shape
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=t.device)
+    call('clamd_nhwc_to_nchw', ptr(t), ldc, ptr(out), B, C, H, W, dcode, _lib.stream_ptr())
+    return out

@@ -1,0 +1,108 @@
+"""Trainer counterpart for the hot loop of the reference (trainer.py:105-129 build_model, :132-265 train_val).
+
+Same construction and ordering as the reference:
+  model  = UNet(num_classes, in_dim=3, conv_dim=64)                       trainer.py:107 (num_classes is a knob here, Q8)
+  optim  = Adam(model.parameters(), lr, betas=[beta1, beta2])             trainer.py:108-110 -> FusedAdam
+  sched  = LambdaLR(optim, lambda n: (1 - n/n_iters) ** lr_exp)           trainer.py:111-112
+  c_loss = CrossEntropyLoss()                                             trainer.py:113
+  per epoch: scheduler.step() FIRST (trainer.py:147), then for each batch
+      outputs = model(inputs); zero_grad(); loss = c_loss(outputs, labels); loss.backward(); optim.step()   :172-176
+Out of scope here: JPEG dumps, prints, checkpoint files; the every-10th-iteration statistics
+(trainer.py:177-189) are computed on the GPU by metrics.argmax_confusion instead of .cpu() round trips.
+Continual learning (config 4): ``begin_task2(c_old, ...)`` snapshots the model and switches the criterion to
+DistillationCrossEntropy and/or enables the L2-to-old-weights term (both build-defined).
+"""
+import copy
+import warnings
+from types import SimpleNamespace
+
+import torch
+from torch.optim.lr_scheduler import LambdaLR
+
+from .loss import CrossEntropyLoss, DistillationCrossEntropy
+from .metrics import argmax_confusion, metrics_from_confusion
+from .optim import FusedAdam
+from .unet import UNet
+
+
+def default_config(**kw):
+    """Defaults of main.py:64-105 for the flags the hot path reads."""
+    cfg = dict(n_iters=10000, train_batch_size=2, lr=1e-4, lr_exp=0.9, beta1=0.5, beta2=0.99, h_image_size=512,
+               w_image_size=256, num_classes=21, conv_dim=64, compute_dtype='fp32', stats_every=10)
+    cfg.update(kw)
+    return SimpleNamespace(**cfg)
+
+
+class Trainer:
+    def __init__(self, train_data_loader, cfg, device='cuda'):
+        self.cfg = cfg
+        self.train_data_loader = train_data_loader
+        self.device = torch.device(device)
+        self.start_epoch = 0
+        self.old_model = None
+        self.build_model()
+
+    def build_model(self):
+        cfg = self.cfg
+        self.model = UNet(num_classes=cfg.num_classes, in_dim=3, conv_dim=cfg.conv_dim,
+                          compute_dtype=cfg.compute_dtype).to(self.device)
+        self.optim = FusedAdam(self.model.parameters(), lr=cfg.lr, betas=[cfg.beta1, cfg.beta2])
+        self.scheduler = LambdaLR(self.optim, lr_lambda=lambda n: (1 - n / cfg.n_iters) ** cfg.lr_exp)
+        self.c_loss = CrossEntropyLoss().to(self.device)
+
+    def reset_grad(self):
+        self.optim.zero_grad()
+
+    def begin_task2(self, c_old, distill_lambda=1.0, temperature=2.0, l2_lambda=0.0):
+        """Freeze a snapshot of the current model (task 1) and regularise further training towards it."""
+        self.old_model = copy.deepcopy(self.model).eval()
+        for p in self.old_model.parameters():
+            p.requires_grad_(False)
+        self.distill = DistillationCrossEntropy(c_old, temperature, distill_lambda) if distill_lambda > 0 else None
+        if l2_lambda > 0:
+            self.optim.set_l2_anchor([p.detach().clone() for p in self.old_model.parameters()], l2_lambda)
+
+    def train_step(self, inputs, labels):
+        """trainer.py:172-176."""
+        outputs = self.model(inputs)
+        self.reset_grad()
+        if self.old_model is not None and getattr(self, 'distill', None) is not None:
+            with torch.no_grad():
+                old = self.old_model(inputs)
+            loss = self.distill(outputs, labels, old)
+        else:
+            loss = self.c_loss(outputs, labels)
+        loss.backward()
+        self.optim.step()
+        return outputs, loss
+
+    def train_epoch(self, epoch):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')          # torch warns that scheduler.step() precedes optim.step(); the
+            self.scheduler.step()                    # reference does exactly that (trainer.py:147)
+        conf = None
+        losses = []
+        for i, (images, masks) in enumerate(self.train_data_loader):
+            inputs = images.to(self.device, non_blocking=True)
+            labels = masks.to(self.device, non_blocking=True)
+            outputs, loss = self.train_step(inputs, labels)
+            if i % self.cfg.stats_every == 0:
+                c, _ = argmax_confusion(outputs.detach(), labels, self.cfg.num_classes)
+                conf = c if conf is None else conf + c
+                losses.append(loss.detach())
+        stats = {}
+        if conf is not None:
+            oa, pc, miu, mx = metrics_from_confusion(conf)
+            stats = dict(loss=float(torch.stack(losses).mean()), pixel_acc=float(oa), class_acc=float(pc),
+                         mean_iu=float(miu), max_class_acc=float(mx), lr=self.optim.param_groups[0]['lr'])
+        return stats
+
+    def train_val(self, epochs=None):
+        epoch = self.start_epoch
+        out = []
+        end = self.cfg.n_iters if epochs is None else min(self.cfg.n_iters, epoch + epochs)
+        while epoch < end:
+            out.append(self.train_epoch(epoch))
+            epoch += 1
+        self.start_epoch = epoch
+        return out

@@ -1,0 +1,401 @@
+"""Drop-in ``UNet(num_classes, in_dim=3, conv_dim=64)`` whose forward/backward run on libclamd's HIP kernels.
+
+Mirrors the reference module surface (models/unet.py:40-92): same constructor, the same 82 parameters in the same
+registration order, the same 136 ``state_dict`` keys ('enc1.0.weight', 'enc2.block.1.weight', 'dec1.block.6.weight',
+'last.6.bias', ...), fp32 NCHW in / fp32 NCHW logits out, ``.train()/.eval()`` BatchNorm semantics, autograd-attached.
+The child modules (nn.Conv2d, nn.BatchNorm2d, ...) are only PARAMETER CONTAINERS with torch's default init; their own
+``forward`` is never called.  ``UNet.forward`` runs the whole network as ONE ``torch.autograd.Function`` whose forward
+and backward are fixed schedules of C-ABI kernel launches on NHWC activations (fp32 or bf16) kept in buffers owned by
+PyTorch's allocator.  There is no CPU path: calling it with CPU tensors raises.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import call, ptr
+from .ops import PackTable, cpad
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def stage_table(num_classes, in_dim=3, conv_dim=64):
+    """Structure of models/unet.py:49-72: (name, wrapped_in_block, pool_first, conv/bn module indices, tail)."""
+    d = conv_dim
+    t = [dict(name='enc1', wrapped=False, pool=False, convs=[(0, 2, in_dim, d), (3, 5, d, d)], tail=None)]
+    c = d
+    for i in (2, 3, 4):
+        t.append(dict(name=f'enc{i}', wrapped=True, pool=True, convs=[(1, 3, c, 2 * c), (4, 6, 2 * c, 2 * c)], tail=None))
+        c *= 2
+    for i, (cin, mid, cout) in enumerate([(8 * d, 16 * d, 8 * d), (16 * d, 8 * d, 4 * d), (8 * d, 4 * d, 2 * d),
+                                          (4 * d, 2 * d, d)], 1):
+        t.append(dict(name=f'dec{i}', wrapped=True, pool=False, convs=[(0, 2, cin, mid), (3, 5, mid, mid)],
+                      tail=('convT', 6, mid, cout)))
+    t.append(dict(name='last', wrapped=False, pool=False, convs=[(0, 2, 2 * d, d), (3, 5, d, d)],
+                  tail=('head', 6, d, num_classes)))
+    return t
+
+
+class _Stage(nn.Module):
+    """Gives the 'encN.block.K' / 'decN.block.K' key names of models/unet.py:8-38."""
+
+    def __init__(self, layers):
+        super().__init__()
+        self.block = nn.Sequential(*layers)
+
+
+def _stage_modules(st):
+    layers = [nn.MaxPool2d(2, 2)] if st['pool'] else []
+    for _, _, cin, cout in st['convs']:
+        layers += [nn.Conv2d(cin, cout, 3, 1, 1), nn.ReLU(), nn.BatchNorm2d(cout)]
+    if st['tail'] is not None:
+        kind, _, cin, cout = st['tail']
+        layers.append(nn.ConvTranspose2d(cin, cout, 2, 2) if kind == 'convT' else nn.Conv2d(cin, cout, 1, 1))
+    return layers
+
+
+_DTYPES = {'fp32': (_lib.F32, torch.float32), 'float32': (_lib.F32, torch.float32),
+           'bf16': (_lib.BF16, torch.bfloat16), 'bfloat16': (_lib.BF16, torch.bfloat16)}
+
+
+class UNet(nn.Module):
+    """models/unet.py:40-92.  ``compute_dtype``: 'fp32' (exact-fp32 MFMA, the reference's arithmetic) or 'bf16'
+    (bf16 activations/packed weights, fp32 accumulation, fp32 master weights and BatchNorm statistics)."""
+
+    def __init__(self, num_classes, in_dim=3, conv_dim=64, compute_dtype='fp32'):
+        super().__init__()
+        self.num_classes, self.in_dim, self.conv_dim = num_classes, in_dim, conv_dim
+        if compute_dtype not in _DTYPES:
+            raise ValueError(f'compute_dtype must be one of {sorted(_DTYPES)}')
+        self.compute_dtype = compute_dtype
+        self._table = stage_table(num_classes, in_dim, conv_dim)
+        for st in self._table:
+            layers = _stage_modules(st)
+            self.add_module(st['name'], _Stage(layers) if st['wrapped'] else nn.Sequential(*layers))
+        self._engines = {}
+        self.grad_sync = None          # set by ddp.GradSync to overlap RCCL all-reduce with backward
+
+    def _seq(self, st):
+        m = getattr(self, st['name'])
+        return m.block if st['wrapped'] else m
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError('continual-learning_amd.UNet runs only on an MI355X GPU tensor: there is no CPU fallback')
+        if x.dim() != 4 or x.shape[1] != self.in_dim:
+            raise ValueError(f'expected input [B,{self.in_dim},H,W], got {tuple(x.shape)}')
+        B, _, H, W = x.shape
+        assert H % 16 == 0 and W % 16 == 0, 'input size(H, W) must be a multiple of 16 (four 2x2 pools and matching skip concats)'
+        key = (B, H, W, x.device.index)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = _Engine(self, B, H, W, x.device)
+            self._engines = {key: eng}     # one shape at a time: activations are sized for it
+        params = [p for p in self.parameters()]
+        return _UNetFn.apply(x.contiguous().float(), eng, *params)
+
+    def extra_repr(self):
+        return f'num_classes={self.num_classes}, in_dim={self.in_dim}, conv_dim={self.conv_dim}, compute={self.compute_dtype}'
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eng, *params):
+        logits = eng.forward(x, params)
+        ctx.eng = eng
+        ctx.gen = eng.generation
+        ctx.nparams = len(params)
+        return logits
+
+    @staticmethod
+    def backward(ctx, gout):
+        eng = ctx.eng
+        if ctx.gen != eng.generation:
+            raise RuntimeError('UNet.backward: the saved activations were overwritten by a later forward of the same module')
+        grads = eng.backward(gout.contiguous().float())
+        return (None, None) + tuple(grads)
+
+
+class _Conv:
+    """One Conv3x3 -> ReLU -> BatchNorm unit and everything it needs in both directions."""
+    pass
+
+
+class _Engine:
+    def __init__(self, model, B, H, W, device):
+        lib = _lib.load()
+        self.model = model
+        self.B, self.H, self.W, self.dev = B, H, W, device
+        self.dcode, self.tdtype = _DTYPES[model.compute_dtype]
+        self.R = lib.clamd_stat_replicas()
+        self.NS = lib.clamd_bn_bwd_nsums()
+        self.generation = 0
+        self.esize = 4 if self.dcode == _lib.F32 else 2
+        K, d = model.num_classes, model.conv_dim
+        self.K, self.Kp = K, cpad(K)
+        T = self.tdtype
+        dev = device
+
+        def act(level, c):
+            return torch.zeros(B, H >> level, W >> level, c, dtype=T, device=dev)
+
+        named = dict(model.named_parameters())
+        bufs = dict(model.named_buffers())
+        self.param_names = [n for n, _ in model.named_parameters()]
+        # flat gradient buffer in REVERSE registration order (= order gradients are produced): contiguous buckets
+        sizes = [named[n].numel() for n in self.param_names]
+        self.gflat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self.gview, off = {}, 0
+        self.goffset = {}
+        for n in reversed(self.param_names):
+            k = named[n].numel()
+            self.gview[n] = self.gflat[off:off + k].view(named[n].shape)
+            self.goffset[n] = (off, k)
+            off += k
+
+        # ---- geometry: stages -> conv units ----------------------------------------------------------
+        self.x_in = act(0, cpad(model.in_dim))
+        convs, self.stages = [], []
+        C = [d, 2 * d, 4 * d, 8 * d]                      # encoder output channels, levels 0..3
+        self.cat = [act(l, 2 * cpad(C[l])) for l in range(4)]
+        self.gcat = [act(l, 2 * cpad(C[l])) for l in range(4)]
+        self.pool = [act(l + 1, cpad(C[l])) for l in range(4)]
+        self.gpool = [act(l + 1, cpad(C[l])) for l in range(4)]
+        stat_sizes = []
+
+        def unit(prefix, ci, bi, level, cin_segs, cout, xin, xin_ldc, first_of_net=False):
+            u = _Conv()
+            u.name = f'{prefix}.{ci}'
+            u.w, u.b = named[f'{prefix}.{ci}.weight'], named[f'{prefix}.{ci}.bias']
+            u.gamma, u.beta = named[f'{prefix}.{bi}.weight'], named[f'{prefix}.{bi}.bias']
+            u.rm, u.rv = bufs[f'{prefix}.{bi}.running_mean'], bufs[f'{prefix}.{bi}.running_var']
+            u.nbt = bufs[f'{prefix}.{bi}.num_batches_tracked']
+            u.keys = (f'{prefix}.{ci}.weight', f'{prefix}.{ci}.bias', f'{prefix}.{bi}.weight', f'{prefix}.{bi}.bias')
+            u.level, u.h, u.w_ = level, H >> level, W >> level
+            u.cin_segs = cin_segs                                  # [(logical, physical), ...] one or two segments
+            u.cin = sum(s[0] for s in cin_segs)
+            u.cin_p = sum(s[1] for s in cin_segs)
+            u.cout, u.cout_p = cout, cpad(cout)
+            u.xin, u.xin_ldc = xin, xin_ldc
+            u.first = first_of_net
+            u.y = act(level, u.cout_p)
+            u.gz = act(level, u.cout_p)
+            u.wf = torch.zeros(9 * u.cout_p * u.cin_p, dtype=T, device=dev)
+            u.wd = None if first_of_net else torch.zeros(9 * u.cin_p * u.cout_p, dtype=T, device=dev)
+            u.bias_p = torch.zeros(u.cout_p, dtype=torch.float32, device=dev)
+            u.vec = torch.zeros(7, u.cout_p, dtype=torch.float32, device=dev)   # scale, shift, mean, istd, k0, k1, k2
+            u.stat_off = sum(stat_sizes)
+            stat_sizes.append(self.R * (2 + self.NS) * u.cout_p)
+            u.m_fastest = 1 if 9 * u.cout_p > B * u.h * u.w_ else 0
+            convs.append(u)
+            return u
+
+        table = model._table
+        prev = (self.x_in, self.x_in.shape[-1], [(model.in_dim, cpad(model.in_dim))])
+        for k in range(4):                                         # encoders
+            st = table[k]
+            pre = st['name'] + ('.block' if st['wrapped'] else '')
+            (c0, b0, cin, cout), (c1, b1, _, _) = st['convs']
+            ua = act(k, cpad(cout))
+            a = unit(pre, c0, b0, k, prev[2], cout, prev[0], prev[1], first_of_net=(k == 0))
+            a.out, a.out_ldc, a.pooled, a.g_out, a.g_out_ldc, a.g_pool = ua, ua.shape[-1], None, None, None, None
+            b = unit(pre, c1, b1, k, [(cout, cpad(cout))], cout, ua, ua.shape[-1])
+            b.out, b.out_ldc, b.pooled = self.cat[k], self.cat[k].shape[-1], self.pool[k]
+            a.g_in = None if k == 0 else self.gpool[k - 1]           # dgrad target of conv a (grad w.r.t. pooled input)
+            b.g_in = act(k, cpad(cout))                             # grad w.r.t. ua
+            a.g_src = (b.g_in, b.g_in.shape[-1], None)               # where conv a's BN-output gradient comes from
+            b.g_src = (self.gcat[k], self.gcat[k].shape[-1], self.gpool[k])
+            self.stages.append(dict(kind='enc', convs=(a, b)))
+            prev = (self.pool[k], self.pool[k].shape[-1], [(cout, cpad(cout))])
+        spec = [(8 * d, 16 * d, 8 * d), (16 * d, 8 * d, 4 * d), (8 * d, 4 * d, 2 * d), (4 * d, 2 * d, d), (2 * d, d, None)]
+        for j in range(5):                                         # decoders + last
+            st = table[4 + j]
+            pre = st['name'] + ('.block' if st['wrapped'] else '')
+            level = 4 - j
+            (c0, b0, cin, mid), (c1, b1, _, _) = st['convs']
+            if j == 0:
+                xin, segs, g_in_a = self.pool[3], [(8 * d, cpad(8 * d))], self.gpool[3]
+            else:
+                half = C[level]
+                xin, segs, g_in_a = self.cat[level], [(half, cpad(half)), (half, cpad(half))], self.gcat[level]
+            ua, ub = act(level, cpad(mid)), act(level, cpad(mid))
+            a = unit(pre, c0, b0, level, segs, mid, xin, xin.shape[-1])
+            a.out, a.out_ldc, a.pooled = ua, ua.shape[-1], None
+            b = unit(pre, c1, b1, level, [(mid, cpad(mid))], mid, ua, ua.shape[-1])
+            b.out, b.out_ldc, b.pooled = ub, ub.shape[-1], None
+            a.g_in, b.g_in = g_in_a, act(level, cpad(mid))
+            g_ub = act(level, cpad(mid))
+            a.g_src = (b.g_in, b.g_in.shape[-1], None)
+            b.g_src = (g_ub, g_ub.shape[-1], None)
+            kind, ti, tcin, tcout = st['tail']
+            tail = _Conv()
+            tail.kind = kind
+            tail.w, tail.b = named[f'{pre}.{ti}.weight'], named[f'{pre}.{ti}.bias']
+            tail.keys = (f'{pre}.{ti}.weight', f'{pre}.{ti}.bias')
+            tail.cin, tail.cin_p, tail.cout = tcin, cpad(tcin), tcout
+            tail.x, tail.g_x, tail.level = ub, g_ub, level
+            if kind == 'convT':
+                tail.cout_p = cpad(tcout)
+                tail.wf = torch.zeros(4 * tail.cout_p * tail.cin_p, dtype=T, device=dev)
+                tail.wd = torch.zeros(tail.cin_p * 4 * tail.cout_p, dtype=T, device=dev)
+                up = self.cat[level - 1]
+                tail.y_slice = up[..., tail.cout_p:]               # second half of the concat buffer one level up
+                tail.gy_slice = self.gcat[level - 1][..., tail.cout_p:]
+                tail.y_ldc = up.shape[-1]
+            else:
+                tail.cout_p = self.Kp
+                tail.wf = torch.zeros(tail.cout_p * tail.cin_p, dtype=T, device=dev)
+                tail.wd = torch.zeros(tail.cin_p * tail.cout_p, dtype=T, device=dev)
+                self.dl = act(0, self.Kp)
+            tail.bias_p = torch.zeros(tail.cout_p, dtype=torch.float32, device=dev)
+            self.stages.append(dict(kind='dec', convs=(a, b), tail=tail))
+        self.convs = convs
+        self.stat_arena = torch.zeros(sum(stat_sizes), dtype=torch.float32, device=dev)
+        for u in convs:
+            o = u.stat_off
+            u.stats = self.stat_arena[o:o + self.R * 2 * u.cout_p]
+            u.sums = self.stat_arena[o + self.R * 2 * u.cout_p:o + self.R * (2 + self.NS) * u.cout_p]
+        self.nbts = [u.nbt for u in convs]
+        # split-K slabs of the weight-gradient kernels
+        ws = 0
+        for u in convs:
+            ws = max(ws, lib.clamd_wgrad_workspace_bytes(_lib.WGRAD_CONV3, B, u.h, u.w_, u.cout_p, u.cin_p, self.dcode))
+        for s in self.stages:
+            t = s.get('tail')
+            if t is not None:
+                mode = _lib.WGRAD_UP2 if t.kind == 'convT' else _lib.WGRAD_PW
+                rp, cp_ = (t.cin_p, t.cout_p) if t.kind == 'convT' else (t.cout_p, t.cin_p)
+                ws = max(ws, lib.clamd_wgrad_workspace_bytes(mode, B, H >> t.level, W >> t.level, rp, cp_, self.dcode))
+        self.ws = torch.empty(ws // 4 + 16, dtype=torch.float32, device=dev)
+        self.ws_bytes = ws
+        self._build_pack_table()
+        self._ptrs = None
+
+    # ------------------------------------------------------------------------------------------ pack table
+    def _build_pack_table(self):
+        tab = PackTable()
+        for u in self.convs:
+            tab.conv3x3(u.w, u.wf, u.wd, u.cin_segs, u.cout)
+            tab.vector(u.b, u.bias_p, u.cout)
+        for s in self.stages:
+            t = s.get('tail')
+            if t is None:
+                continue
+            if t.kind == 'convT':
+                tab.convT(t.w, t.wf, t.wd, t.cin, t.cout)
+            else:
+                tab.head(t.w, t.wf, t.wd, t.cin, t.cout)
+            tab.vector(t.b, t.bias_p, t.cout)
+        self.pack_table = tab.finalize(self.dev)
+        self._param_ptrs = [p.data_ptr() for p in self.model.parameters()]
+
+    def _check_ptrs(self, params):
+        cur = [p.data_ptr() for p in params]
+        if cur != self._param_ptrs:
+            # parameters were re-allocated (.to(), load from a different storage): rebuild the job table
+            named = dict(zip(self.param_names, params))
+            for u in self.convs:
+                u.w, u.b, u.gamma, u.beta = (named[k] for k in u.keys)
+            for s in self.stages:
+                t = s.get('tail')
+                if t is not None:
+                    t.w, t.b = named[t.keys[0]], named[t.keys[1]]
+            self._build_pack_table()
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, x, params):
+        m = self.model
+        training = m.training
+        self.generation += 1
+        self._check_ptrs(params)
+        s = _lib.stream_ptr()
+        B, H, W, dc = self.B, self.H, self.W, self.dcode
+        if training:
+            self.stat_arena.zero_()
+        self.pack_table.run(dc, s)
+        call('clamd_nchw_to_nhwc', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
+             self.x_in.shape[-1], 1.0, dc, s)
+        for st in self.stages:
+            for u in st['convs']:
+                self._conv_fwd(u, training, s)
+            t = st.get('tail')
+            if t is None:
+                continue
+            h, w = H >> t.level, W >> t.level
+            if t.kind == 'convT':
+                call('clamd_convT2x2_fwd', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(t.y_slice), t.y_ldc,
+                     B, h, w, t.cin_p, t.cout_p, dc, s)
+            else:
+                logits = torch.empty(B, self.K, H, W, dtype=torch.float32, device=self.dev)
+                call('clamd_conv1x1_logits', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(logits), B, h, w,
+                     t.cin_p, t.cout_p, self.K, dc, s)
+        if training:
+            torch._foreach_add_(self.nbts, 1)
+        return logits
+
+    def _conv_fwd(self, u, training, s):
+        B, dc = self.B, self.dcode
+        v = u.vec
+        call('clamd_conv3x3', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
+             ptr(u.stats) if training else None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, u.m_fastest, dc, s)
+        call('clamd_bn_finalize', ptr(u.stats) if training else None, ptr(u.gamma), ptr(u.beta), ptr(u.rm), ptr(u.rv),
+             ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), u.cout_p, u.cout, float(B * u.h * u.w_), BN_MOMENTUM, BN_EPS, s)
+        call('clamd_bn_apply', ptr(u.y), u.cout_p, ptr(v[0]), ptr(v[1]), ptr(u.out), u.out_ldc,
+             ptr(u.pooled), u.pooled.shape[-1] if u.pooled is not None else 0, B, u.h, u.w_, u.cout_p, dc, s)
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward(self, gout):
+        m = self.model
+        s = _lib.stream_ptr()
+        B, H, W, dc = self.B, self.H, self.W, self.dcode
+        g = self.gview
+        sync = m.grad_sync
+        for u in self.convs:
+            u.sums.zero_()
+        for st in reversed(self.stages):
+            t = st.get('tail')
+            if t is not None:
+                h, w = H >> t.level, W >> t.level
+                g[t.keys[1]].zero_()
+                if t.kind == 'head':
+                    call('clamd_nchw_to_nhwc', ptr(gout), ptr(self.dl), self.Kp, B, self.K, H, W, self.Kp, 1.0, dc, s)
+                    call('clamd_wgrad', _lib.WGRAD_PW, ptr(self.dl), self.Kp, ptr(t.x), t.x.shape[-1], ptr(self.ws),
+                         self.ws_bytes, ptr(g[t.keys[0]]), B, h, w, t.cout_p, t.cin_p, t.cout, t.cin,
+                         t.cout, 0, t.cin, 0, dc, s)
+                    call('clamd_channel_sum', ptr(self.dl), self.Kp, ptr(g[t.keys[1]]), B * h * w, self.Kp, t.cout, dc, s)
+                    call('clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], B, h, w,
+                         t.cout_p, t.cin_p, dc, s)
+                else:
+                    call('clamd_wgrad', _lib.WGRAD_UP2, ptr(t.x), t.x.shape[-1], ptr(t.gy_slice), t.y_ldc, ptr(self.ws),
+                         self.ws_bytes, ptr(g[t.keys[0]]), B, h, w, t.cin_p, t.cout_p, t.cin, t.cout,
+                         t.cin, 0, t.cout, 0, dc, s)
+                    call('clamd_channel_sum', ptr(t.gy_slice), t.y_ldc, ptr(g[t.keys[1]]), B * 4 * h * w, t.cout_p,
+                         t.cout, dc, s)
+                    call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1], B, h, w,
+                         t.cin_p, t.cout_p, dc, s)
+            for u in reversed(st['convs']):
+                self._conv_bwd(u, s)
+            if sync is not None:
+                sync.stage_done(self, st)
+        return [g[n] for n in self.param_names]
+
+    def _conv_bwd(self, u, s):
+        B, dc = self.B, self.dcode
+        v = u.vec
+        ga, ga_ldc, gp = u.g_src
+        count = float(B * u.h * u.w_)
+        g = self.gview
+        call('clamd_bn_bwd_reduce', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.cout_p,
+             ptr(v[0]), ptr(v[1]), ptr(u.sums), B, u.h, u.w_, u.cout_p, dc, s)
+        call('clamd_bn_bwd_finalize', ptr(u.sums), ptr(u.gamma), ptr(v[2]), ptr(v[3]), ptr(v[4]), ptr(g[u.keys[2]]),
+             ptr(g[u.keys[3]]), ptr(g[u.keys[1]]), u.cout_p, u.cout, count, s)
+        call('clamd_bn_bwd_apply', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.cout_p,
+             ptr(v[0]), ptr(v[1]), ptr(v[4]), ptr(u.gz), u.cout_p, B, u.h, u.w_, u.cout_p, dc, s)
+        if len(u.cin_segs) == 2:
+            c_seg0, c_seg0p = u.cin_segs[0]
+        else:
+            c_seg0, c_seg0p = u.cin, 0
+        call('clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
+             ptr(g[u.keys[0]]), B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, 0, c_seg0, c_seg0p, dc, s)
+        if u.g_in is not None:
+            call('clamd_conv3x3', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
+                 B, u.h, u.w_, u.cout_p, u.cin_p, 0, 1 if 9 * u.cin_p > B * u.h * u.w_ else 0, dc, s)

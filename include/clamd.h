@@ -1,0 +1,125 @@
+/* clamd.h -- C ABI of libclamd.so: the MI355X (gfx950) kernels behind the UNet segmentation train step of
+ * LorenzoFramba/Continual-Learning.
+ *
+ * The reference defines NO FFI for this path: its hot loop (trainer.py:168-176) calls PyTorch modules
+ * (models/unet.py:8-92) whose kernels live in ATen/cuDNN.  This header is therefore the interface a maintainer
+ * would bind INSTEAD of those torch operators; each entry point names the reference call site it replaces.
+ * INTEGRATION.md shows the ctypes binding and the torch.autograd.Function glue.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, ints, doubles; `stream` is a hipStream_t passed as void*.
+ *   - every call only ENQUEUES work on `stream`; no allocation, no host synchronisation, graph-capturable.
+ *     Buffers are owned by the caller (PyTorch's allocator) and only borrowed for the enqueue.
+ *   - return 0 on success, negative on error; clamd_last_error() returns the (thread-local) message.
+ *   - activations are NHWC in the compute dtype with an explicit channel pitch `ldc` (elements) so that a
+ *     tensor may be a channel slice of a concat buffer (replaces torch.cat, models/unet.py:83-87).
+ *     Physical channel counts (`*_p`) are padded to a power of two >= 32; padded channels hold zeros.
+ *   - dtype: CLAMD_F32 computes with v_mfma_f32_32x32x2_f32 (exact fp32), CLAMD_BF16 stores activations and
+ *     packed weights as bf16 and accumulates in fp32 (v_mfma_f32_32x32x16_bf16).
+ */
+#ifndef CLAMD_H
+#define CLAMD_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { CLAMD_F32 = 0, CLAMD_BF16 = 1 };
+enum { CLAMD_WGRAD_CONV3 = 0, CLAMD_WGRAD_PW = 1, CLAMD_WGRAD_UP2 = 2 };
+
+const char* clamd_last_error(void);
+int clamd_version(void);
+/* layout constants the host side needs to build device tables */
+int clamd_sizeof_pack_job(void);
+int clamd_sizeof_adam_tensor(void);
+int clamd_adam_chunk_elems(void);
+int clamd_stat_replicas(void);
+int clamd_bn_bwd_nsums(void);
+
+/* ---- implicit-GEMM convolutions (igemm.hip) ---------------------------------------------------------------
+ * nn.Conv2d(k3,s1,p1)+bias followed by nn.ReLU (models/unet.py:13-14,16-17,28-29,31-32,50-51,53-54,66-67,69-70):
+ *   y = relu?(conv3x3(x, w) + bias), and (if stats != NULL) per-channel sum / sum-of-squares of y accumulated
+ *   into stats[replica][2][Cout_p] for the following nn.BatchNorm2d (unet.py:15,...).  The same entry point run
+ *   on the flipped/transposed packing computes the data gradient of that conv (loss.backward(), trainer.py:175).
+ *   w_packed: [9][Cout_p][Cin_p] compute dtype, Cin innermost (see clamd_pack).  m_fastest: block order hint. */
+int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
+                  float* stats, int B, int H, int W, int Cin_p, int Cout_p, int relu, int m_fastest, int dtype,
+                  void* stream);
+/* 1x1 convolution, NHWC output (data gradient of the head, unet.py:72). w_packed [1][Cout_p][Cin_p]. */
+int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc, int B,
+                  int H, int W, int Cin_p, int Cout_p, int dtype, void* stream);
+/* the head nn.Conv2d(conv_dim, num_classes, k1) (unet.py:72): logits written as fp32 NCHW [B,num_classes,H,W]. */
+int clamd_conv1x1_logits(const void* x, int x_ldc, const void* w_packed, const float* bias, float* logits_nchw,
+                         int B, int H, int W, int Cin_p, int Cout_p, int num_classes, int dtype, void* stream);
+/* nn.ConvTranspose2d(k2,s2)+bias (unet.py:34): x [B,h,w,Cin_p] -> y [B,2h,2w,(ldc)] channels [0,Cout_p) of the
+ * slice y points at.  w_packed [4][Cout_p][Cin_p] (tap q = 2*dy+dx). */
+int clamd_convT2x2_fwd(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc, int B,
+                       int h, int w, int Cin_p, int Cout_p, int dtype, void* stream);
+/* data gradient of the above: gy [B,2h,2w,...] -> gx [B,h,w,Cin_p].  w_packed [Cin_p][4][Cout_p]. */
+int clamd_convT2x2_dgrad(const void* gy, int gy_ldc, const void* w_packed, void* gx, int gx_ldc, int B, int h, int w,
+                         int Cin_p, int Cout_p, int dtype, void* stream);
+
+/* ---- weight gradients (wgrad.hip) --------------------------------------------------------------------------
+ * out[r][c][t] = sum_pixels a[p, r] * b[nbr_t(p), c]  written in the parameter's own fp32 layout:
+ *   CONV3: a = d(conv output), b = conv input  -> d weight [Cout][Cin][3][3]
+ *   PW   : a = d logits,       b = head input  -> d weight [K][Cin][1][1]
+ *   UP2  : a = convT input,    b = d(convT output) -> d weight [Cin][Cout][2][2]
+ * R,C logical sizes; logical index l maps to physical l (l < seg0) or seg0p + (l - seg0): concat inputs keep each
+ * half padded separately.  workspace: fp32 split-K slabs, size >= clamd_wgrad_workspace_bytes(). */
+size_t clamd_wgrad_workspace_bytes(int mode, int B, int H, int W, int Rp, int Cp, int dtype);
+int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, float* workspace, size_t ws_bytes,
+                float* out, int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0,
+                int c_seg0p, int dtype, void* stream);
+
+/* ---- BatchNorm / ReLU / MaxPool / concat plumbing (elementwise.hip) ------------------------------------------
+ * nn.BatchNorm2d train mode (unet.py:15): stats -> scale/shift (+ running stats, momentum 0.1, unbiased var). */
+int clamd_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float* scale, float* shift, float* save_mean, float* save_istd,
+                      int Cp, int C, double count, double momentum, double eps, void* stream);
+/* out = y*scale+shift into `out` (possibly a concat slice: replaces torch.cat, unet.py:83-87); pooled (optional)
+ * = nn.MaxPool2d(2,2) of out (unet.py:12,80). */
+int clamd_bn_apply(const void* y, int y_ldc, const float* scale, const float* shift, void* out, int out_ldc,
+                   void* pooled, int p_ldc, int B, int H, int W, int Cp, int dtype, void* stream);
+/* backward of ReLU->BatchNorm (+ max-pool routing of `gp`, the gradient w.r.t. the pooled tensor):
+ * reduce -> 5 per-channel sums (replicated), finalize -> k0,k1,k2 + d gamma, d beta, d conv-bias, apply -> g_z. */
+int clamd_bn_bwd_reduce(const void* ga, int ga_ldc, const void* gp, int gp_ldc, const void* y, int y_ldc,
+                        const float* scale, const float* shift, float* sums, int B, int H, int W, int Cp,
+                        int dtype, void* stream);
+int clamd_bn_bwd_finalize(const float* sums, const float* gamma, const float* save_mean, const float* save_istd,
+                          float* k012, float* dgamma, float* dbeta, float* dbias, int Cp, int C, double count,
+                          void* stream);
+int clamd_bn_bwd_apply(const void* ga, int ga_ldc, const void* gp, int gp_ldc, const void* y, int y_ldc,
+                       const float* scale, const float* shift, const float* k012, void* gz, int gz_ldc, int B,
+                       int H, int W, int Cp, int dtype, void* stream);
+/* out[c] += sum_pixels g[p,c]  (bias gradients of convT / head). */
+int clamd_channel_sum(const void* g, int ldc, float* out, long long npix, int Cp, int C, int dtype, void* stream);
+/* boundary layout conversion: visible tensors are fp32 NCHW; replaces images.to(device) layout
+ * handling (trainer.py:168) and feeds grad_output into the backward. */
+int clamd_nchw_to_nhwc(const float* src, void* dst, int ldc, int B, int C, int H, int W, int Cp, double mul,
+                       int dtype, void* stream);
+int clamd_nhwc_to_nchw(const void* src, int ldc, float* dst, int B, int C, int H, int W, int dtype, void* stream);
+
+/* ---- parameters, loss, optimiser, metrics (misc.hip) ---------------------------------------------------------
+ * clamd_pack: one fused launch re-packing every fp32 master parameter into the layouts above (job table built by
+ * the host). */
+int clamd_pack(const void* jobs_dev, int njobs, int total_blocks, int dtype, void* stream);
+/* nn.CrossEntropyLoss() forward+backward (trainer.py:113,174-175) on fp32 NCHW logits / int64 labels, plus the
+ * build-defined distillation term when old_logits != NULL.  loss3 = {total, ce, kd}. */
+size_t clamd_ce_workspace_bytes(void);
+int clamd_ce_fwd_bwd(const float* logits, const long long* labels, const float* old_logits, int K_old_total, int c_old,
+                     double temperature, double lam, float* dlogits, float* loss3, void* workspace, size_t ws_bytes,
+                     int B, int K, int H, int W, long long ignore_index, double grad_scale, void* stream);
+/* torch.optim.Adam.step over all parameters in one launch (trainer.py:108-110,176); hyper/step/derived live on the
+ * device so a captured graph can be replayed with a new learning rate. */
+int clamd_adam_step(const void* tensors_dev, const void* chunks_dev, int nchunks, const float* hyper_dev, int* step_dev,
+                    float* derived_dev, float* l2_accum_dev, void* stream);
+/* argmax over classes + confusion matrix (trainer.py:183-188, metrics.py:32-38). */
+int clamd_argmax_confusion(const float* logits, const long long* labels, long long* pred, unsigned long long* conf,
+                           int B, int K, int Kc, int H, int W, void* stream);
+int clamd_fill_f32(float* p, long long n, double v, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

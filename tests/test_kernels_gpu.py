@@ -1,0 +1,462 @@
+"""GPU parity tests, one kernel family at a time, THROUGH THE C ABI (ctypes -> libclamd.so), checked against the
+CPU oracle (oracle/np_unet.py) on the same seeded inputs and against golden vectors captured from the reference.
+
+Tolerances: fp32 path (exact-fp32 MFMA) differs from the oracle only by summation order -> rel L2 < 2e-5.
+bf16 path: the oracle is run on bf16-rounded inputs/weights, so what remains is accumulation order plus the bf16
+rounding of the stored output (2^-9 relative per element) -> rel L2 < 6e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import np_unet as O
+
+pytestmark = pytest.mark.gpu
+
+DT = [('fp32', 0), ('bf16', 1)]
+TOL = {0: 2e-5, 1: 6e-3}
+
+
+@pytest.fixture(scope='module')
+def C():
+    import continual_learning_amd as C
+    C._lib.load()
+    return C
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to('cuda', dtype)
+
+
+def rb(a, dcode):
+    """Round a numpy fp32 array to the compute dtype and back (identity for fp32)."""
+    if dcode == 0:
+        return a.astype(np.float32)
+    return torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def rnd(rng, *shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+def phys_map(segs):
+    """[(logical, physical), ...] -> list: physical index -> logical index or -1."""
+    out, base = [], 0
+    for lg, ph in segs:
+        out += [base + i if i < lg else -1 for i in range(ph)]
+        base += lg
+    return out
+
+
+def nhwc_with_segs(C, x_nchw, segs, dcode):
+    """Builds the padded NHWC tensor of a (possibly two-segment concat) activation."""
+    pm = phys_map(segs)
+    B, _, H, W = x_nchw.shape
+    full = np.zeros((B, len(pm), H, W), np.float32)
+    for p, l in enumerate(pm):
+        if l >= 0:
+            full[:, p] = x_nchw[:, l]
+    return C.ops.to_nhwc(dev(full), dcode, cp=len(pm))
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name,dcode', DT)
+def test_layout_roundtrip(C, name, dcode):
+    rng = np.random.default_rng(0)
+    x = rb(rnd(rng, 2, 5, 6, 10), dcode)
+    t = C.ops.to_nhwc(dev(x), dcode)
+    assert t.shape == (2, 6, 10, 32)
+    back = C.ops.from_nhwc(t, 5, dcode).cpu().numpy()
+    assert np.array_equal(back, x)
+    assert float(t[..., 5:].float().abs().max()) == 0.0        # padded channels are zero
+
+
+@pytest.mark.parametrize('name,dcode', DT)
+def test_pack_layouts(C, name, dcode):
+    rng = np.random.default_rng(1)
+    T = C.ops.TORCH_DT[dcode]
+    cpad = C.ops.cpad
+    # conv 3x3 with a two-segment (concat) input: logical 5+5 channels, physical 32+32
+    w = rnd(rng, 7, 10, 3, 3)
+    segs = [(5, 32), (5, 32)]
+    wf = torch.zeros(9 * 32 * 64, dtype=T, device='cuda')
+    wd = torch.zeros(9 * 64 * 32, dtype=T, device='cuda')
+    wt = dev(w)
+    wc = rnd(rng, 6, 3, 2, 2); wct = dev(wc)
+    cf = torch.zeros(4 * 32 * 32, dtype=T, device='cuda'); cd = torch.zeros(32 * 4 * 32, dtype=T, device='cuda')
+    wh = rnd(rng, 21, 40, 1, 1); wht = dev(wh)
+    hf = torch.zeros(32 * 64, dtype=T, device='cuda'); hd = torch.zeros(64 * 32, dtype=T, device='cuda')
+    b = rnd(rng, 7); bt = dev(b); bp = torch.full((32,), 9.0, device='cuda')
+    tab = C.ops.PackTable()
+    tab.conv3x3(wt, wf, wd, segs, 7)
+    tab.convT(wct, cf, cd, 6, 3)
+    tab.head(wht, hf, hd, 40, 21)
+    tab.vector(bt, bp, 7)
+    tab.finalize('cuda').run(dcode)
+    sync()
+    pm = phys_map(segs)
+    exp_f = np.zeros((9, 32, 64), np.float32); exp_d = np.zeros((9, 64, 32), np.float32)
+    for t in range(9):
+        ky, kx = divmod(t, 3)
+        for kp, kl in enumerate(pm):
+            if kl < 0:
+                continue
+            exp_f[t, :7, kp] = w[:, kl, ky, kx]
+            exp_d[t, kp, :7] = w[:, kl, 2 - ky, 2 - kx]
+    assert np.array_equal(wf.float().cpu().numpy().reshape(9, 32, 64), rb(exp_f, dcode))
+    assert np.array_equal(wd.float().cpu().numpy().reshape(9, 64, 32), rb(exp_d, dcode))
+    exp_cf = np.zeros((4, 32, 32), np.float32); exp_cd = np.zeros((32, 4, 32), np.float32)
+    for q in range(4):
+        exp_cf[q, :3, :6] = wc[:, :, q // 2, q % 2].T
+        exp_cd[:6, q, :3] = wc[:, :, q // 2, q % 2]
+    assert np.array_equal(cf.float().cpu().numpy().reshape(4, 32, 32), rb(exp_cf, dcode))
+    assert np.array_equal(cd.float().cpu().numpy().reshape(32, 4, 32), rb(exp_cd, dcode))
+    exp_hf = np.zeros((32, 64), np.float32); exp_hf[:21, :40] = wh[:, :, 0, 0]
+    assert np.array_equal(hf.float().cpu().numpy().reshape(32, 64), rb(exp_hf, dcode))
+    assert np.array_equal(hd.float().cpu().numpy().reshape(64, 32), rb(exp_hf.T, dcode))
+    exp_b = np.zeros(32, np.float32); exp_b[:7] = b
+    assert np.array_equal(bp.cpu().numpy(), exp_b)
+    assert cpad(21) == 32 and cpad(64) == 64 and cpad(65) == 128
+
+
+CONV_SHAPES = [  # B, Cin segs, Cout, H, W
+    (2, [(5, 32)], 7, 8, 12),                 # tiny ragged image, heavy channel padding
+    (1, [(64, 64)], 64, 16, 16),              # exact 16x16 tile (the centre of the full-size net)
+    (2, [(20, 32), (20, 32)], 130, 40, 64),   # concat input, 3 Cout tiles with a ragged last one, TW=32 tiles
+    (1, [(3, 32)], 64, 64, 96),               # first layer shape class
+    (3, [(128, 128)], 32, 4, 4),              # image smaller than a tile
+]
+
+
+def _conv_case(C, rng, B, segs, cout, H, W, dcode):
+    cin = sum(s[0] for s in segs)
+    x = rb(rnd(rng, B, cin, H, W), dcode)
+    w = rb(rnd(rng, cout, cin, 3, 3) * (1.0 / np.sqrt(9 * cin)), dcode)
+    b = rnd(rng, cout)
+    T = C.ops.TORCH_DT[dcode]
+    cin_p, cout_p = sum(s[1] for s in segs), C.ops.cpad(cout)
+    xt = nhwc_with_segs(C, x, segs, dcode)
+    wt, bt = dev(w), dev(b)
+    wf = torch.zeros(9 * cout_p * cin_p, dtype=T, device='cuda')
+    wd = torch.zeros(9 * cin_p * cout_p, dtype=T, device='cuda')
+    bp = torch.zeros(cout_p, device='cuda')
+    tab = C.ops.PackTable()
+    tab.conv3x3(wt, wf, wd, segs, cout)
+    tab.vector(bt, bp, cout)
+    tab.finalize('cuda').run(dcode)
+    return x, w, b, xt, wf, wd, bp, cin_p, cout_p
+
+
+@pytest.mark.parametrize('name,dcode', DT)
+@pytest.mark.parametrize('shape', CONV_SHAPES)
+@pytest.mark.parametrize('m_fastest', [0, 1])
+def test_conv3x3_fwd_relu_stats(C, name, dcode, shape, m_fastest):
+    B, segs, cout, H, W = shape
+    rng = np.random.default_rng(10)
+    x, w, b, xt, wf, wd, bp, cin_p, cout_p = _conv_case(C, rng, B, segs, cout, H, W, dcode)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    T = C.ops.TORCH_DT[dcode]
+    y = torch.full((B, H, W, cout_p), 7.0, dtype=T, device='cuda')
+    R = lib.load().clamd_stat_replicas()
+    stats = torch.zeros(R, 2, cout_p, device='cuda')
+    lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), B, H, W, cin_p, cout_p, 1,
+             m_fastest, dcode, s)
+    sync()
+    ref = O.relu_fwd(O.conv3x3_fwd(x, w, b))
+    got = C.ops.from_nhwc(y, cout, dcode).cpu().numpy()
+    assert rel_l2(got, ref) < TOL[dcode]
+    st = stats.sum(0).cpu().numpy()
+    np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=2e-3 if dcode else 1e-4, atol=1e-2 if dcode else 1e-3)
+    np.testing.assert_allclose(st[1, :cout], (ref ** 2).sum((0, 2, 3)), rtol=4e-3 if dcode else 1e-4, atol=1e-2 if dcode else 1e-3)
+    assert float(y[..., cout:].float().abs().max()) == 0.0 if cout < cout_p else True
+
+
+@pytest.mark.parametrize('name,dcode', DT)
+@pytest.mark.parametrize('shape', CONV_SHAPES)
+def test_conv3x3_dgrad_and_wgrad(C, name, dcode, shape):
+    B, segs, cout, H, W = shape
+    rng = np.random.default_rng(11)
+    x, w, b, xt, wf, wd, bp, cin_p, cout_p = _conv_case(C, rng, B, segs, cout, H, W, dcode)
+    cin = x.shape[1]
+    gz = rb(rnd(rng, B, cout, H, W), dcode)
+    gzt = C.ops.to_nhwc(dev(gz), dcode)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    T = C.ops.TORCH_DT[dcode]
+    gx = torch.zeros(B, H, W, cin_p, dtype=T, device='cuda')
+    lib.call('clamd_conv3x3', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, B, H, W, cout_p, cin_p, 0, 0, dcode, s)
+    wsb = lib.load().clamd_wgrad_workspace_bytes(0, B, H, W, cout_p, cin_p, dcode)
+    ws = torch.empty(wsb // 4 + 4, device='cuda')
+    gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
+    c_seg0, c_seg0p = (segs[0][0], segs[0][1]) if len(segs) == 2 else (cin, 0)
+    lib.call('clamd_wgrad', 0, ptr(gzt), cout_p, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, cin_p, cout, cin,
+             cout, 0, c_seg0, c_seg0p, dcode, s)
+    sync()
+    rgx, rgw, _ = O.conv3x3_bwd(x, w, gz)
+    pm = phys_map(segs)
+    got_gx = gx.float().cpu().numpy().transpose(0, 3, 1, 2)[:, [p for p, l in enumerate(pm) if l >= 0]]
+    assert rel_l2(got_gx, rgx) < TOL[dcode]
+    assert rel_l2(gw.cpu().numpy(), rgw) < (2e-5 if dcode == 0 else 2e-5)   # wgrad output is fp32 in both paths
+
+
+@pytest.mark.parametrize('name,dcode', DT)
+@pytest.mark.parametrize('shape', [(2, 6, 3, 4, 5), (1, 128, 64, 16, 16), (2, 70, 40, 8, 48)])
+def test_convT2x2_fwd_dgrad_wgrad(C, name, dcode, shape):
+    B, cin, cout, h, w_ = shape
+    rng = np.random.default_rng(12)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    T = C.ops.TORCH_DT[dcode]
+    cin_p, cout_p = C.ops.cpad(cin), C.ops.cpad(cout)
+    x = rb(rnd(rng, B, cin, h, w_), dcode)
+    w = rb(rnd(rng, cin, cout, 2, 2) * (1 / np.sqrt(cin)), dcode)
+    b = rnd(rng, cout)
+    xt, wt, bt = C.ops.to_nhwc(dev(x), dcode), dev(w), dev(b)
+    wf = torch.zeros(4 * cout_p * cin_p, dtype=T, device='cuda'); wd = torch.zeros(cin_p * 4 * cout_p, dtype=T, device='cuda')
+    bp = torch.zeros(cout_p, device='cuda')
+    tab = C.ops.PackTable(); tab.convT(wt, wf, wd, cin, cout); tab.vector(bt, bp, cout); tab.finalize('cuda').run(dcode)
+    # output goes into the SECOND half of a concat buffer (pitch 2*cout_p), the first half must stay untouched
+    cat = torch.full((B, 2 * h, 2 * w_, 2 * cout_p), 3.0, dtype=T, device='cuda')
+    ysl = cat[..., cout_p:]
+    lib.call('clamd_convT2x2_fwd', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(ysl), 2 * cout_p, B, h, w_, cin_p, cout_p, dcode, s)
+    sync()
+    ref = O.convT2x2_fwd(x, w, b)
+    got = cat[..., cout_p:cout_p + cout].float().cpu().numpy().transpose(0, 3, 1, 2)
+    assert rel_l2(got, ref) < TOL[dcode]
+    assert float((cat[..., :cout_p].float() - 3.0).abs().max()) == 0.0
+    # backward: gradient arrives in the same slice
+    gy = rb(rnd(rng, B, cout, 2 * h, 2 * w_), dcode)
+    gcat = torch.zeros(B, 2 * h, 2 * w_, 2 * cout_p, dtype=T, device='cuda')
+    gcat[..., cout_p:cout_p + cout] = dev(gy.transpose(0, 2, 3, 1)).to(T)
+    gsl = gcat[..., cout_p:]
+    gx = torch.zeros(B, h, w_, cin_p, dtype=T, device='cuda')
+    lib.call('clamd_convT2x2_dgrad', ptr(gsl), 2 * cout_p, ptr(wd), ptr(gx), cin_p, B, h, w_, cin_p, cout_p, dcode, s)
+    wsb = lib.load().clamd_wgrad_workspace_bytes(2, B, h, w_, cin_p, cout_p, dcode)
+    ws = torch.empty(wsb // 4 + 4, device='cuda')
+    gw = torch.zeros(cin, cout, 2, 2, device='cuda')
+    lib.call('clamd_wgrad', 2, ptr(xt), cin_p, ptr(gsl), 2 * cout_p, ptr(ws), wsb, ptr(gw), B, h, w_, cin_p, cout_p, cin, cout,
+             cin, 0, cout, 0, dcode, s)
+    gb = torch.zeros(cout, device='cuda')
+    lib.call('clamd_channel_sum', ptr(gsl), 2 * cout_p, ptr(gb), B * 4 * h * w_, cout_p, cout, dcode, s)
+    sync()
+    rgx, rgw, rgb = O.convT2x2_bwd(x, w, gy)
+    assert rel_l2(C.ops.from_nhwc(gx, cin, dcode).cpu().numpy(), rgx) < TOL[dcode]
+    assert rel_l2(gw.cpu().numpy(), rgw) < 2e-5
+    assert rel_l2(gb.cpu().numpy(), rgb) < 2e-5
+
+
+@pytest.mark.parametrize('name,dcode', DT)
+@pytest.mark.parametrize('shape', [(2, 6, 5, 16, 16), (1, 64, 21, 32, 64), (2, 40, 2, 16, 48)])
+def test_head_fwd_bwd(C, name, dcode, shape):
+    B, cin, K, H, W = shape
+    rng = np.random.default_rng(13)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    T = C.ops.TORCH_DT[dcode]
+    cin_p, kp = C.ops.cpad(cin), C.ops.cpad(K)
+    x = rb(rnd(rng, B, cin, H, W), dcode)
+    w = rb(rnd(rng, K, cin, 1, 1) * (1 / np.sqrt(cin)), dcode)
+    b = rnd(rng, K)
+    xt, wt, bt = C.ops.to_nhwc(dev(x), dcode), dev(w), dev(b)
+    wf = torch.zeros(kp * cin_p, dtype=T, device='cuda'); wd = torch.zeros(cin_p * kp, dtype=T, device='cuda')
+    bp = torch.zeros(kp, device='cuda')
+    tab = C.ops.PackTable(); tab.head(wt, wf, wd, cin, K); tab.vector(bt, bp, K); tab.finalize('cuda').run(dcode)
+    logits = torch.full((B, K, H, W), 9.0, device='cuda')
+    lib.call('clamd_conv1x1_logits', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(logits), B, H, W, cin_p, kp, K, dcode, s)
+    sync()
+    ref = O.conv1x1_fwd(x, w, b)
+    assert rel_l2(logits.cpu().numpy(), ref) < (2e-5 if dcode == 0 else 2e-5)   # fp32 output, fp32 accumulate
+    g = rb(rnd(rng, B, K, H, W), dcode)
+    gt = C.ops.to_nhwc(dev(g), dcode)
+    gx = torch.zeros(B, H, W, cin_p, dtype=T, device='cuda')
+    lib.call('clamd_conv1x1', ptr(gt), kp, ptr(wd), None, ptr(gx), cin_p, B, H, W, kp, cin_p, dcode, s)
+    wsb = lib.load().clamd_wgrad_workspace_bytes(1, B, H, W, kp, cin_p, dcode)
+    ws = torch.empty(wsb // 4 + 4, device='cuda')
+    gw = torch.zeros(K, cin, 1, 1, device='cuda')
+    lib.call('clamd_wgrad', 1, ptr(gt), kp, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, kp, cin_p, K, cin, K, 0, cin, 0, dcode, s)
+    sync()
+    rgx, rgw, _ = O.conv1x1_bwd(x, w, g)
+    assert rel_l2(C.ops.from_nhwc(gx, cin, dcode).cpu().numpy(), rgx) < TOL[dcode]
+    assert rel_l2(gw.cpu().numpy(), rgw) < 2e-5
+
+
+@pytest.mark.parametrize('name,dcode', DT)
+@pytest.mark.parametrize('shape', [(2, 7, 8, 12), (1, 64, 16, 16), (2, 200, 4, 6), (1, 1024, 2, 2)])
+@pytest.mark.parametrize('pool', [False, True])
+def test_bn_fwd_bwd_pool(C, name, dcode, shape, pool):
+    """BatchNorm(train) apply (+2x2 max-pool) and the fused ReLU/BN backward (+pool routing) vs the oracle;
+    gammas of both signs, values with ties inside pooling windows."""
+    B, Cc, H, W = shape
+    rng = np.random.default_rng(14)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    T = C.ops.TORCH_DT[dcode]
+    cp = C.ops.cpad(Cc)
+    R, NS = lib.load().clamd_stat_replicas(), lib.load().clamd_bn_bwd_nsums()
+    y = np.maximum(rnd(rng, B, Cc, H, W), 0)                       # a ReLU output: many exact zeros (ties)
+    y = rb(y, dcode)
+    gamma, beta = rnd(rng, Cc), rnd(rng, Cc)
+    rm0, rv0 = rnd(rng, Cc), np.abs(rnd(rng, Cc)) + 0.5
+    yt = C.ops.to_nhwc(dev(y), dcode)
+    # statistics as the conv epilogue would have produced them, spread over two replicas
+    stats = torch.zeros(R, 2, cp, device='cuda')
+    stats[0, 0, :Cc] = dev(y.sum((0, 2, 3)) * 0.25); stats[3, 0, :Cc] = dev(y.sum((0, 2, 3)) * 0.75)
+    stats[1, 1, :Cc] = dev((y.astype(np.float64) ** 2).sum((0, 2, 3)).astype(np.float32))
+    vec = torch.zeros(7, cp, device='cuda')
+    gt_, bt_, rm, rv = dev(gamma), dev(beta), dev(rm0), dev(rv0)
+    n = B * H * W
+    lib.call('clamd_bn_finalize', ptr(stats), ptr(gt_), ptr(bt_), ptr(rm), ptr(rv), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]),
+             ptr(vec[3]), cp, Cc, float(n), 0.1, 1e-5, s)
+    cat = torch.full((B, H, W, 2 * cp), 2.0, dtype=T, device='cuda')       # BN output goes to the FIRST half of a concat buffer
+    pooled = torch.zeros(B, H // 2, W // 2, cp, dtype=T, device='cuda') if pool else None
+    lib.call('clamd_bn_apply', ptr(yt), cp, ptr(vec[0]), ptr(vec[1]), ptr(cat), 2 * cp, ptr(pooled), cp, B, H, W, cp, dcode, s)
+    sync()
+    u_ref, cache, rm_ref, rv_ref = O.bn_train_fwd(y, gamma, beta, rm0, rv0)
+    got_u = cat[..., :Cc].float().cpu().numpy().transpose(0, 3, 1, 2)
+    assert rel_l2(got_u, u_ref) < (1e-5 if dcode == 0 else 4e-3)
+    assert float((cat[..., cp:].float() - 2.0).abs().max()) == 0.0
+    np.testing.assert_allclose(rm.cpu().numpy(), rm_ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), rv_ref, rtol=1e-4, atol=1e-6)
+    if pool:
+        # the kernel takes max/arg-max on the fp32 value fma(y, scale, shift) BEFORE rounding to the storage dtype;
+        # emulate that fma exactly (double product of two floats is exact) with the kernel's own scale/shift
+        sc = vec[0, :Cc].cpu().numpy().astype(np.float64).reshape(1, -1, 1, 1)
+        sh = vec[1, :Cc].cpu().numpy().astype(np.float64).reshape(1, -1, 1, 1)
+        u32 = (y.astype(np.float64) * sc + sh).astype(np.float32)
+        p_ref, idx = O.maxpool2x2_fwd(u32)
+        assert np.array_equal(pooled[..., :Cc].float().cpu().numpy().transpose(0, 3, 1, 2), rb(p_ref, dcode))
+    # ---- backward ----
+    ga = rb(rnd(rng, B, Cc, H, W), dcode)
+    gat = torch.zeros(B, H, W, 2 * cp, dtype=T, device='cuda')
+    gat[..., :Cc] = dev(ga.transpose(0, 2, 3, 1)).to(T)
+    gp = rb(rnd(rng, B, Cc, H // 2, W // 2), dcode) if pool else None
+    gpt = C.ops.to_nhwc(dev(gp), dcode) if pool else None
+    sums = torch.zeros(R, NS, cp, device='cuda')
+    lib.call('clamd_bn_bwd_reduce', ptr(gat), 2 * cp, ptr(gpt), cp, ptr(yt), cp, ptr(vec[0]), ptr(vec[1]), ptr(sums), B, H, W, cp, dcode, s)
+    dg, db, dcb = torch.zeros(Cc, device='cuda'), torch.zeros(Cc, device='cuda'), torch.zeros(Cc, device='cuda')
+    lib.call('clamd_bn_bwd_finalize', ptr(sums), ptr(gt_), ptr(vec[2]), ptr(vec[3]), ptr(vec[4]), ptr(dg), ptr(db), ptr(dcb), cp, Cc, float(n), s)
+    gz = torch.zeros(B, H, W, cp, dtype=T, device='cuda')
+    lib.call('clamd_bn_bwd_apply', ptr(gat), 2 * cp, ptr(gpt), cp, ptr(yt), cp, ptr(vec[0]), ptr(vec[1]), ptr(vec[4]), ptr(gz), cp, B, H, W, cp, dcode, s)
+    sync()
+    gu = ga.copy()
+    if pool:
+        gu = gu + O.maxpool2x2_bwd(gp, idx)          # routing by the arg-max of the kernel's own u (first max wins)
+    gy_ref, gg_ref, gb_ref = O.bn_train_bwd(gu, gamma, cache)
+    gz_ref = gy_ref * (y > 0)
+    tol = 1e-4 if dcode == 0 else 8e-3
+    assert rel_l2(C.ops.from_nhwc(gz, Cc, dcode).cpu().numpy(), gz_ref) < tol
+    scale = np.abs(gg_ref).max() + 1e-6
+    np.testing.assert_allclose(dg.cpu().numpy(), gg_ref, rtol=1e-3 if dcode == 0 else 2e-2, atol=1e-3 * scale if dcode == 0 else 2e-2 * scale)
+    np.testing.assert_allclose(db.cpu().numpy(), gb_ref, rtol=1e-3, atol=1e-3 * (np.abs(gb_ref).max() + 1e-6))
+    np.testing.assert_allclose(dcb.cpu().numpy(), gz_ref.sum((0, 2, 3)), rtol=1e-3 if dcode == 0 else 3e-2,
+                               atol=(1e-3 if dcode == 0 else 3e-2) * (np.abs(gz_ref.sum((0, 2, 3))).max() + 1e-6))
+
+
+def test_bn_eval_mode(C):
+    rng = np.random.default_rng(15)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    y = rnd(rng, 2, 9, 4, 6); gamma, beta = rnd(rng, 9), rnd(rng, 9); rm0, rv0 = rnd(rng, 9), np.abs(rnd(rng, 9)) + 0.3
+    yt = C.ops.to_nhwc(dev(y), 0)
+    vec = torch.zeros(4, 32, device='cuda'); rm, rv = dev(rm0), dev(rv0)
+    lib.call('clamd_bn_finalize', None, ptr(dev(gamma)), ptr(dev(beta)), ptr(rm), ptr(rv), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), 32, 9, 48.0, 0.1, 1e-5, s)
+    out = torch.zeros(2, 4, 6, 32, device='cuda')
+    lib.call('clamd_bn_apply', ptr(yt), 32, ptr(vec[0]), ptr(vec[1]), ptr(out), 32, None, 0, 2, 4, 6, 32, 0, s)
+    sync()
+    assert rel_l2(C.ops.from_nhwc(out, 9, 0).cpu().numpy(), O.bn_eval_fwd(y, gamma, beta, rm0, rv0)) < 1e-5
+    assert np.array_equal(rm.cpu().numpy(), rm0) and np.array_equal(rv.cpu().numpy(), rv0)   # eval updates nothing
+
+
+# ------------------------------------------------------------------------------------------------------------
+def test_cross_entropy_golden(C, golden):
+    g = golden('ops.npz')
+    crit = C.CrossEntropyLoss()
+    for tag in ('ce', 'ce_ign'):
+        lg = dev(g['ce/logits']).requires_grad_()
+        loss = crit(lg, dev(g[f'{tag}/labels'], torch.int64))
+        loss.backward()
+        sync()
+        assert abs(float(loss) - float(g[f'{tag}/loss'])) < 2e-6 * max(1.0, abs(float(g[f'{tag}/loss'])))
+        assert rel_l2(lg.grad.cpu().numpy(), g[f'{tag}/dlogits']) < 1e-5
+
+
+def test_cross_entropy_edge_cases(C):
+    """All pixels ignored -> loss 0 / zero gradient (no NaN); large logits; 2 classes; 32 classes."""
+    crit = C.CrossEntropyLoss()
+    lg = (torch.randn(1, 2, 16, 16, device='cuda') * 50).requires_grad_()
+    lb = torch.full((1, 16, 16), -100, dtype=torch.int64, device='cuda')
+    loss = crit(lg, lb); loss.backward(); sync()
+    assert float(loss) == 0.0 and float(lg.grad.abs().max()) == 0.0
+    rng = np.random.default_rng(3)
+    for K in (2, 32):
+        z = (rnd(rng, 2, K, 16, 32) * 30).astype(np.float32)
+        y = rng.integers(0, K, (2, 16, 32))
+        ref_l, ref_d = O.cross_entropy(z.astype(np.float64), y)
+        t = dev(z).requires_grad_()
+        l = crit(t, dev(y, torch.int64)); l.backward(); sync()
+        assert abs(float(l) - ref_l) < 1e-5 * max(1, abs(ref_l))
+        assert rel_l2(t.grad.cpu().numpy(), ref_d) < 1e-5
+    with pytest.raises(RuntimeError):
+        crit(torch.randn(1, 33, 16, 16, device='cuda'), torch.zeros(1, 16, 16, dtype=torch.int64, device='cuda'))
+
+
+def test_distillation_loss_vs_oracle(C):
+    """Build-defined term (parity unpinned vs the reference, which has none): checked against oracle.distill_kl."""
+    rng = np.random.default_rng(4)
+    z, zo = rnd(rng, 2, 21, 16, 16) * 3, rnd(rng, 2, 21, 16, 16) * 3
+    y = rng.integers(0, 21, (2, 16, 16))
+    crit = C.DistillationCrossEntropy(c_old=11, temperature=2.0, lam=0.7)
+    t = dev(z).requires_grad_()
+    loss = crit(t, dev(y, torch.int64), dev(zo)); loss.backward(); sync()
+    l_ce, d_ce = O.cross_entropy(z, y)
+    l_kd, d_kd = O.distill_kl(z, zo, 11, 2.0, 0.7)
+    assert abs(float(loss) - float(l_ce + l_kd)) < 1e-5
+    assert rel_l2(t.grad.cpu().numpy(), d_ce + d_kd) < 1e-5
+
+
+def test_fused_adam_golden_and_l2(C, golden):
+    g = golden('ops.npz')
+    p = torch.nn.Parameter(dev(g['adam/p0']))
+    opt = C.FusedAdam([p], lr=1e-2, betas=[0.5, 0.99])
+    for i in range(3):
+        p.grad = dev(g['adam/grads'][i])
+        opt.step()
+        sync()
+        assert rel_l2(p.detach().cpu().numpy(), g[f'adam/p{i + 1}']) < 1e-6
+    st = opt.state[p]
+    assert rel_l2(st['exp_avg'].cpu().numpy(), g['adam/m3']) < 1e-6
+    assert rel_l2(st['exp_avg_sq'].cpu().numpy(), g['adam/v3']) < 1e-6
+    assert float(st['step']) == 3.0
+    sd = opt.state_dict()
+    assert set(sd['state'][0].keys()) == {'step', 'exp_avg', 'exp_avg_sq'}      # torch.optim.Adam's checkpoint layout
+    # lr change through param_groups (what LambdaLR does) is picked up
+    opt.param_groups[0]['lr'] = 0.0
+    before = p.detach().clone(); p.grad = dev(g['adam/grads'][0]); opt.step(); sync()
+    assert torch.equal(before, p.detach())
+    # L2-to-old-weights (build-defined): grad += 2*lam*(theta - theta_old)
+    rng = np.random.default_rng(5)
+    p0, old, gr = rnd(rng, 5000), rnd(rng, 5000), rnd(rng, 5000)
+    q = torch.nn.Parameter(dev(p0)); o2 = C.FusedAdam([q], lr=1e-2, betas=[0.5, 0.99]); o2.set_l2_anchor([dev(old)], 0.3)
+    q.grad = dev(gr); o2.step(); sync()
+    ref, _, _ = O.adam_step(p0, gr + 2 * 0.3 * (p0 - old), np.zeros_like(p0), np.zeros_like(p0), 1, 1e-2)
+    assert rel_l2(q.detach().cpu().numpy(), ref) < 1e-6
+    assert abs(float(o2.l2_penalty()) - 0.3 * float(((p0 - old).astype(np.float64) ** 2).sum())) < 1e-2
+
+
+def test_metrics_golden(C, golden):
+    g = golden('metrics.npz')
+    t, p = g['target'], g['pred']
+    onehot = np.zeros((4, 21, 32, 32), np.float32)
+    np.put_along_axis(onehot, p[:, None], 1.0, 1)
+    lg = dev(onehot)
+    conf, pred = C.argmax_confusion(lg, dev(t, torch.int64), 21, want_pred=True)
+    sync()
+    assert np.array_equal(pred.cpu().numpy(), p)
+    assert np.array_equal(conf.cpu().numpy().astype(np.float32), g['conf21'])
+    for c in (21, 22):   # trainer.py:188 passes 22
+        m = C.eval_metrics(dev(t, torch.int64), lg, c)
+        np.testing.assert_allclose([float(v) for v in m], g[f'm{c}'], rtol=1e-6)
+    # first maximum wins on ties
+    tie = torch.zeros(1, 5, 16, 16, device='cuda')
+    _, pr = C.argmax_confusion(tie, torch.zeros(1, 16, 16, dtype=torch.int64, device='cuda'), 5, want_pred=True)
+    assert int(pr.max()) == 0
