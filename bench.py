@@ -1,0 +1,168 @@
+"""bench.py -- images/sec of the UNet 256x256 bs16 train step (BASELINE.json metric) on N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One step = trainer.py:172-176 on one synthetic batch that is already resident in HBM: forward -> zero_grad ->
+cross-entropy -> backward -> Adam, all on libclamd's HIP kernels.  Default workload = BASELINE.json configs[1]
+(UNet(21,3,64) 256x256 bs16 fp32, single task); ``--dtype bf16`` selects configs[2]'s arithmetic.  With N > 1 every
+rank trains its own 16 images (weak scaling) and gradients are all-reduced over RCCL/xGMI, overlapped with backward.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOP_PER_IMAGE_256 = 289_281_146_880          # train step, SURVEY.md §8d / BASELINE.md
+PEAK = {'fp32': 157.3, 'bf16': 2500.0}         # dense MFMA TFLOP/s, MI355X_MICROARCH.md:42-43
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'])
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--conv-dim', type=int, default=64)
+    ap.add_argument('--num-classes', type=int, default=21)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true', help='skip the per-launch HIP events')
+    ap.add_argument('--also', default='', help="second dtype measured after the main run and reported under 'also'")
+    return ap.parse_args()
+
+
+def run(args, dtype, rank, world, device, timing=True):
+    import continual_learning_amd as C
+    from continual_learning_amd import unet as U
+    torch.manual_seed(1234)
+    model = C.UNet(args.num_classes, 3, args.conv_dim, compute_dtype=dtype).to(device).train()
+    opt = C.FusedAdam(model.parameters(), lr=1e-4, betas=[0.5, 0.99])
+    crit = C.CrossEntropyLoss()
+    if world > 1:
+        C.ddp.broadcast_parameters(model)
+        C.ddp.GradSync(model, opt)
+    x = torch.from_numpy(C.synth.images(1234, args.batch, 3, args.size, args.size, first_image=rank * args.batch)).to(device)
+    y = torch.from_numpy(C.synth.labels(1234, args.batch, args.size, args.size, args.num_classes,
+                                        first_image=rank * args.batch)).to(device)
+
+    def step():
+        out = model(x)                  # trainer.py:172
+        opt.zero_grad()                 # :173
+        loss = crit(out, y)             # :174
+        loss.backward()                 # :175
+        opt.step()                      # :176
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    U.KERNEL_TIMING = [] if timing else None
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    events = U.KERNEL_TIMING or []
+    U.KERNEL_TIMING = None
+    kern = {}
+    for tag, flops, e0, e1 in events:
+        k = kern.setdefault(tag, [0.0, 0.0, 0])
+        k[0] += e0.elapsed_time(e1) * 1e-3
+        k[1] += flops
+        k[2] += 1
+    return dt, float(loss), kern
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('launch with torch.distributed.run for --gpus > 1')
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)       # "nccl" IS RCCL on ROCm
+
+    dt, loss, kern = run(args, args.dtype, rank, world, device, timing=not args.no_kernel_timing)
+    images = args.batch * world * args.steps
+    value = images / dt
+    scale = (args.size / 256.0) ** 2 * (args.conv_dim / 64.0) ** 2
+    flop_img = FLOP_PER_IMAGE_256 * scale
+
+    out = {
+        'metric': 'images/sec UNET 256x256 bs16 train step', 'value': round(value, 2), 'unit': 'images/sec',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else 'bf16',
+        'data': 'synthetic (splitmix64 images U(-1,1), blocky 21-class labels), random-init weights',
+        'config': {'workload': f'UNet({args.num_classes},3,{args.conv_dim}) {args.size}x{args.size} bs{args.batch}/GPU '
+                               f'{args.dtype} train step (fwd + CE + bwd + Adam), BASELINE.json configs['
+                               f'{1 if args.dtype == "fp32" else 2}]',
+                   'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'final_loss': round(loss, 5)},
+        'step_tflops': round(value * flop_img / 1e12, 2),
+        'step_frac_of_mfma_peak': round(value * flop_img / 1e12 / (PEAK[args.dtype] * world), 4),
+    }
+    if kern:
+        # dominant kernel = the 3x3 implicit-GEMM (forward + data-gradient launches share one kernel template)
+        sec, flops, n = kern.get('igemm_conv3x3', (0, 0, 0))
+        if sec > 0:
+            ach = flops / sec / 1e12
+            out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK[args.dtype], 'unit': 'TFLOP/s',
+                               'frac': round(ach / PEAK[args.dtype], 4), 'traffic': None,
+                               'kernel': 'clamd::igemm_kernel<T,CONV3,NHWC,TW> (conv3x3 fwd + dgrad)',
+                               'launches': n, 'avg_launch_ms': round(sec / n * 1e3, 4),
+                               'share_of_step': round(sec / dt, 3)}
+        sec, flops, n = kern.get('wgrad_conv3x3', (0, 0, 0))
+        if sec > 0:
+            ach = flops / sec / 1e12
+            out['roofline_wgrad'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK[args.dtype],
+                                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK[args.dtype], 4), 'launches': n,
+                                     'avg_launch_ms': round(sec / n * 1e3, 4), 'share_of_step': round(sec / dt, 3)}
+    if args.also and args.also != args.dtype:
+        dt2, loss2, _ = run(args, args.also, rank, world, device, timing=False)
+        v2 = images / dt2
+        out['also'] = {'dtype': args.also, 'value': round(v2, 2), 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
+                       'step_frac_of_mfma_peak': round(v2 * flop_img / 1e12 / (PEAK[args.also] * world), 4)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_cpu as TC                       # the checker timed as the reported CPU baseline
+        xb = x_cpu = None
+        import continual_learning_amd as C
+        xb = torch.from_numpy(C.synth.images(1234, args.batch, 3, args.size, args.size))
+        yb = torch.from_numpy(C.synth.labels(1234, args.batch, args.size, args.size, args.num_classes))
+        cb = TC.time_cpu_baseline(batch=args.batch, size=args.size, num_classes=args.num_classes,
+                                  conv_dim=args.conv_dim, steps=1, warmup=1, images=xb, labels=yb)
+        out['cpu_baseline'] = {'value': round(cb['value'], 3), 'unit': 'images/sec', 'cores': cb['cores'],
+                               'kind': 'port', 'sample': cb['sample']}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

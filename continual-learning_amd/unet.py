@@ -17,6 +17,22 @@ from .ops import PackTable, cpad
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
+# bench.py sets this to a list to get per-launch HIP-event timings of the MFMA kernels:
+# entries (tag, algorithmic_flops, start_event, end_event), recorded on the stream the kernel is launched on.
+KERNEL_TIMING = None
+
+
+def _timed(tag, flops, name, *args):
+    kt = KERNEL_TIMING
+    if kt is None:
+        call(name, *args)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call(name, *args)
+    e1.record()
+    kt.append((tag, flops, e0, e1))
+
 
 def stage_table(num_classes, in_dim=3, conv_dim=64):
     """Structure of models/unet.py:49-72: (name, wrapped_in_block, pool_first, conv/bn module indices, tail)."""
@@ -335,8 +351,9 @@ class _Engine:
     def _conv_fwd(self, u, training, s):
         B, dc = self.B, self.dcode
         v = u.vec
-        call('clamd_conv3x3', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
-             ptr(u.stats) if training else None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, u.m_fastest, dc, s)
+        _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout,
+               'clamd_conv3x3', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
+               ptr(u.stats) if training else None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, u.m_fastest, dc, s)
         call('clamd_bn_finalize', ptr(u.stats) if training else None, ptr(u.gamma), ptr(u.beta), ptr(u.rm), ptr(u.rv),
              ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), u.cout_p, u.cout, float(B * u.h * u.w_), BN_MOMENTUM, BN_EPS, s)
         call('clamd_bn_apply', ptr(u.y), u.cout_p, ptr(v[0]), ptr(v[1]), ptr(u.out), u.out_ldc,
@@ -394,8 +411,11 @@ class _Engine:
             c_seg0, c_seg0p = u.cin_segs[0]
         else:
             c_seg0, c_seg0p = u.cin, 0
-        call('clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
-             ptr(g[u.keys[0]]), B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, 0, c_seg0, c_seg0p, dc, s)
+        flops = 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout
+        _timed('wgrad_conv3x3', flops,
+               'clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
+               ptr(g[u.keys[0]]), B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, 0, c_seg0, c_seg0p, dc, s)
         if u.g_in is not None:
-            call('clamd_conv3x3', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
-                 B, u.h, u.w_, u.cout_p, u.cin_p, 0, 1 if 9 * u.cin_p > B * u.h * u.w_ else 0, dc, s)
+            _timed('igemm_conv3x3', flops,
+                   'clamd_conv3x3', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
+                   B, u.h, u.w_, u.cout_p, u.cin_p, 0, 1 if 9 * u.cin_p > B * u.h * u.w_ else 0, dc, s)

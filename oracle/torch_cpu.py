@@ -94,10 +94,23 @@ def train_step(model, optim, criterion, images, labels):
     return out, loss
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota (os.cpu_count() reports the
+    whole host on the GPU box and oversubscribing 256 threads on a 16-core share is ~10x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))      # a 1-GPU box has a 16-core share
+
+
 def time_cpu_baseline(batch=16, size=256, num_classes=21, conv_dim=64, steps=1, warmup=1, threads=None,
                       images=None, labels=None):
     """Times the stock-torch CPU train step on this host.  Returns dict(value img/s, cores, sample, s_per_step)."""
-    threads = threads or os.cpu_count() or 1
+    threads = threads or usable_cores()
     torch.set_num_threads(threads)
     m = build_unet(num_classes, 3, conv_dim)
     m.train()

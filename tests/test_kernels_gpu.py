@@ -359,7 +359,8 @@ def test_bn_eval_mode(C):
     y = rnd(rng, 2, 9, 4, 6); gamma, beta = rnd(rng, 9), rnd(rng, 9); rm0, rv0 = rnd(rng, 9), np.abs(rnd(rng, 9)) + 0.3
     yt = C.ops.to_nhwc(dev(y), 0)
     vec = torch.zeros(4, 32, device='cuda'); rm, rv = dev(rm0), dev(rv0)
-    lib.call('clamd_bn_finalize', None, ptr(dev(gamma)), ptr(dev(beta)), ptr(rm), ptr(rv), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), 32, 9, 48.0, 0.1, 1e-5, s)
+    gt_, bt_ = dev(gamma), dev(beta)          # keep the tensors alive: raw pointers are only borrowed
+    lib.call('clamd_bn_finalize', None, ptr(gt_), ptr(bt_), ptr(rm), ptr(rv), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), 32, 9, 48.0, 0.1, 1e-5, s)
     out = torch.zeros(2, 4, 6, 32, device='cuda')
     lib.call('clamd_bn_apply', ptr(yt), 32, ptr(vec[0]), ptr(vec[1]), ptr(out), 32, None, 0, 2, 4, 6, 32, 0, s)
     sync()
