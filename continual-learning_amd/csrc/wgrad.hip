@@ -196,27 +196,41 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
         }
 }
 
-// out[rl][cl][t] = scale * sum_s partial[s][t][rp(rl)][cp(cl)]     (logical -> physical channel maps: two segments)
+// out[rl][cl][t] = sum_s partial[s][t][rp][cp]: 64 consecutive (t,rp,cp) elements x 4 split-phases per block, so the
+// slab reads are coalesced 256-B rows and the split loop is spread over the 4 waves; fixed summation order
+// (deterministic).  Physical -> logical channel maps use the clamd_pack convention (two segments for concat inputs).
 struct ReduceParams {
     const float* partial; float* out;
     int nsplit, NT, Rp, Cp;
     int R, C;                 // logical sizes
-    int r_seg0, r_seg0p;      // logical rows < r_seg0 map to themselves, the rest to r_seg0p + (r - r_seg0)
+    int r_seg0, r_seg0p;      // physical p < seg0p ? (p < seg0 ? p : pad) : seg0 + (p - seg0p)
     int c_seg0, c_seg0p;
-    int flip;                 // CONV3: out tap index = t (kernel tap (dy,dx) IS (ky,kx) for wgrad)
 };
 
-__global__ void wgrad_reduce_kernel(const ReduceParams p) {
-    const long long n = (long long)p.R * p.C;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int cl = (int)(i % p.C), rl = (int)(i / p.C);
-        const int rp = rl < p.r_seg0 ? rl : p.r_seg0p + (rl - p.r_seg0);
-        const int cp = cl < p.c_seg0 ? cl : p.c_seg0p + (cl - p.c_seg0);
-        for (int t = 0; t < p.NT; ++t) {
-            float s = 0.f;
-            for (int k = 0; k < p.nsplit; ++k) s += p.partial[(((size_t)k * p.NT + t) * p.Rp + rp) * p.Cp + cp];
-            p.out[i * p.NT + t] = s;
+__device__ inline int wg_phys2log(int p, int seg0, int seg0p, int L) {
+    if (p < seg0p) return p < seg0 ? p : -1;
+    const int l = seg0 + (p - seg0p);
+    return l < L ? l : -1;
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const ReduceParams p) {
+    __shared__ float red[4][64];
+    const int le = threadIdx.x & 63, kp = threadIdx.x >> 6;
+    const long long E = (long long)p.NT * p.Rp * p.Cp;
+    for (long long base = (long long)blockIdx.x * 64; base < E; base += (long long)gridDim.x * 64) {
+        const long long e = base + le;
+        float s = 0.f;
+        if (e < E)
+            for (int k = kp; k < p.nsplit; k += 4) s += p.partial[(size_t)k * E + e];
+        red[kp][le] = s;
+        __syncthreads();
+        if (kp == 0 && e < E) {
+            s = (red[0][le] + red[1][le]) + (red[2][le] + red[3][le]);
+            const int cp = (int)(e % p.Cp), rp = (int)((e / p.Cp) % p.Rp), t = (int)(e / ((long long)p.Cp * p.Rp));
+            const int rl = wg_phys2log(rp, p.r_seg0, p.r_seg0p, p.R), cl = wg_phys2log(cp, p.c_seg0, p.c_seg0p, p.C);
+            if (rl >= 0 && cl >= 0) p.out[((long long)rl * p.C + cl) * p.NT + t] = s;
         }
+        __syncthreads();
     }
 }
 
@@ -273,10 +287,10 @@ int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, fl
           : mode == WG_PW    ? launch_wg<float, WG_PW>(p, s, grid) : launch_wg<float, WG_UP2>(p, s, grid);
     } else return clamd_fail("wgrad: bad dtype");
     if (e) return e;
-    ReduceParams rp{workspace, out, nsplit, NT, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p, 0};
-    const long long n = (long long)R * C;
-    int g = (int)((n + 255) / 256);
-    if (g > 2048) g = 2048;
+    ReduceParams rp{workspace, out, nsplit, NT, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p};
+    const long long n = (long long)NT * Rp * Cp;
+    int g = (int)((n + 63) / 64);
+    if (g > 8192) g = 8192;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, s, rp);
     return clamd_check_launch("wgrad_reduce");
 }

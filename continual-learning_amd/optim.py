@@ -46,7 +46,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._derived = torch.zeros(2, dtype=torch.float32, device=dev)
         self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         self._l2acc = torch.zeros(1, dtype=torch.float32, device=dev)
-        off = 0
+        off, steps0 = 0, set()
+        self._step_host = torch.tensor(0.0)          # ONE host-side step counter shared by every parameter's state
         for p, st in zip(params, prev):
             k = p.numel()
             m, v = self._m[off:off + k].view_as(p), self._v[off:off + k].view_as(p)
@@ -55,12 +56,13 @@ class FusedAdam(torch.optim.Optimizer):
                 m.copy_(st['exp_avg'])
                 v.copy_(st['exp_avg_sq'])
                 step0 = float(st['step'])
-            self.state[p] = {'step': torch.tensor(step0), 'exp_avg': m, 'exp_avg_sq': v}
+            self.state[p] = {'step': self._step_host, 'exp_avg': m, 'exp_avg_sq': v}
+            steps0.add(step0)
             off += k
-        steps = {float(self.state[p]['step']) for p in params}
-        if len(steps) != 1:
+        if len(steps0) != 1:
             raise ValueError('FusedAdam needs one common step count across parameters')
-        self._step_dev.fill_(int(steps.pop()))
+        self._step_host.fill_(steps0.pop())
+        self._step_dev.fill_(int(self._step_host))
 
     def _build_table(self, params):
         chunk = _lib.load().clamd_adam_chunk_elems()
@@ -76,6 +78,12 @@ class FusedAdam(torch.optim.Optimizer):
         self._chunks_dev = torch.tensor(chunks, dtype=torch.int32, device=dev)
         self._nchunks = len(chunks)
         self._table = [(p.data_ptr(), p.grad.data_ptr()) for p in params]
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._table = None            # restored exp_avg / exp_avg_sq are re-homed into the flat buffers at the next step
+        if hasattr(self, '_m'):
+            del self._m
 
     def set_l2_anchor(self, old_params, lam):
         """old_params: list of tensors aligned with this optimiser's parameters (a frozen task-1 snapshot)."""
@@ -94,15 +102,19 @@ class FusedAdam(torch.optim.Optimizer):
         for h in self.pre_step_hooks:
             h()
         group = self.param_groups[0]
-        params = [p for p in group['params'] if p.grad is not None]
-        if len(params) != len(group['params']):
-            raise RuntimeError('FusedAdam: every parameter must have a gradient (the UNet backward produces all of them)')
+        params = group['params']
+        key = []
         for p in params:
-            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
-                raise RuntimeError('FusedAdam needs contiguous fp32 GPU parameters and gradients: there is no CPU fallback')
-        if not hasattr(self, '_m') or self._m.device != params[0].device:
-            self._init_state(params)
-        if self._table is None or self._table != [(p.data_ptr(), p.grad.data_ptr()) for p in params]:
+            gr = p.grad
+            if gr is None:
+                raise RuntimeError('FusedAdam: every parameter must have a gradient (the UNet backward produces all of them)')
+            key.append((p.data_ptr(), gr.data_ptr()))
+        if self._table != key:       # first step, or parameters / gradients moved: validate and rebuild the device table
+            for p in params:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise RuntimeError('FusedAdam needs contiguous fp32 GPU parameters and gradients: there is no CPU fallback')
+            if not hasattr(self, '_m') or self._m.device != params[0].device:
+                self._init_state(params)
             self._build_table(params)
         hyper = (float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
                  float(self.grad_scale), float(self._l2_lambda), 0.0, 0.0)
@@ -114,6 +126,5 @@ class FusedAdam(torch.optim.Optimizer):
         call('clamd_adam_step', ptr(self._tensors_dev), ptr(self._chunks_dev), self._nchunks, ptr(self._hyper),
              ptr(self._step_dev), ptr(self._derived), ptr(self._l2acc) if self._anchor is not None else None,
              _lib.stream_ptr())
-        for p in params:
-            self.state[p]['step'] += 1      # host-side mirror (CPU scalar tensors, like torch's non-capturable Adam)
+        self._step_host += 1                # host-side mirror of the device counter (shared by all param states)
         return loss

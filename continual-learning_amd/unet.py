@@ -160,12 +160,14 @@ class _Engine:
         # flat gradient buffer in REVERSE registration order (= order gradients are produced): contiguous buckets
         sizes = [named[n].numel() for n in self.param_names]
         self.gflat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-        self.gview, off = {}, 0
-        self.goffset = {}
+        # NOTE: no tensor views of the gradients are kept alive here.  Fresh views are handed to autograd at the end
+        # of every backward so that AccumulateGrad can adopt them as .grad without a copy (it clones when the
+        # incoming gradient has other owners).
+        self.goffset, self.gshape, off = {}, {}, 0
         for n in reversed(self.param_names):
             k = named[n].numel()
-            self.gview[n] = self.gflat[off:off + k].view(named[n].shape)
             self.goffset[n] = (off, k)
+            self.gshape[n] = tuple(named[n].shape)
             off += k
 
         # ---- geometry: stages -> conv units ----------------------------------------------------------
@@ -364,28 +366,35 @@ class _Engine:
         m = self.model
         s = _lib.stream_ptr()
         B, H, W, dc = self.B, self.H, self.W, self.dcode
-        g = self.gview
+        p0 = next(iter(m.parameters()))
+        if p0.grad is not None:
+            lo = self.gflat.data_ptr()
+            if lo <= p0.grad.data_ptr() < lo + 4 * self.gflat.numel():
+                # the previous gradients are still installed as .grad (no zero_grad since): accumulate semantics
+                # need them intact, so this backward writes into a fresh buffer
+                self.gflat = torch.empty_like(self.gflat)
+        base = self.gflat.data_ptr()
+        g = {n: base + 4 * o for n, (o, _) in self.goffset.items()}      # raw device pointers into the flat buffer
         sync = m.grad_sync
-        for u in self.convs:
-            u.sums.zero_()
+        self._gp = g
         for st in reversed(self.stages):
             t = st.get('tail')
             if t is not None:
                 h, w = H >> t.level, W >> t.level
-                g[t.keys[1]].zero_()
+                call('clamd_fill_f32', g[t.keys[1]], t.cout, 0.0, s)
                 if t.kind == 'head':
                     call('clamd_nchw_to_nhwc', ptr(gout), ptr(self.dl), self.Kp, B, self.K, H, W, self.Kp, 1.0, dc, s)
                     call('clamd_wgrad', _lib.WGRAD_PW, ptr(self.dl), self.Kp, ptr(t.x), t.x.shape[-1], ptr(self.ws),
-                         self.ws_bytes, ptr(g[t.keys[0]]), B, h, w, t.cout_p, t.cin_p, t.cout, t.cin,
-                         t.cout, 0, t.cin, 0, dc, s)
-                    call('clamd_channel_sum', ptr(self.dl), self.Kp, ptr(g[t.keys[1]]), B * h * w, self.Kp, t.cout, dc, s)
+                         self.ws_bytes, g[t.keys[0]], B, h, w, t.cout_p, t.cin_p, t.cout, t.cin,
+                         t.cout, t.cout_p, t.cin, t.cin_p, dc, s)
+                    call('clamd_channel_sum', ptr(self.dl), self.Kp, g[t.keys[1]], B * h * w, self.Kp, t.cout, dc, s)
                     call('clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], B, h, w,
                          t.cout_p, t.cin_p, dc, s)
                 else:
                     call('clamd_wgrad', _lib.WGRAD_UP2, ptr(t.x), t.x.shape[-1], ptr(t.gy_slice), t.y_ldc, ptr(self.ws),
-                         self.ws_bytes, ptr(g[t.keys[0]]), B, h, w, t.cin_p, t.cout_p, t.cin, t.cout,
-                         t.cin, 0, t.cout, 0, dc, s)
-                    call('clamd_channel_sum', ptr(t.gy_slice), t.y_ldc, ptr(g[t.keys[1]]), B * 4 * h * w, t.cout_p,
+                         self.ws_bytes, g[t.keys[0]], B, h, w, t.cin_p, t.cout_p, t.cin, t.cout,
+                         t.cin, t.cin_p, t.cout, t.cout_p, dc, s)
+                    call('clamd_channel_sum', ptr(t.gy_slice), t.y_ldc, g[t.keys[1]], B * 4 * h * w, t.cout_p,
                          t.cout, dc, s)
                     call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1], B, h, w,
                          t.cin_p, t.cout_p, dc, s)
@@ -393,28 +402,29 @@ class _Engine:
                 self._conv_bwd(u, s)
             if sync is not None:
                 sync.stage_done(self, st)
-        return [g[n] for n in self.param_names]
+        gf = self.gflat
+        return [gf[o:o + k].view(self.gshape[n]) for n, (o, k) in ((n, self.goffset[n]) for n in self.param_names)]
 
     def _conv_bwd(self, u, s):
         B, dc = self.B, self.dcode
         v = u.vec
         ga, ga_ldc, gp = u.g_src
         count = float(B * u.h * u.w_)
-        g = self.gview
+        g = self._gp
         call('clamd_bn_bwd_reduce', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.cout_p,
              ptr(v[0]), ptr(v[1]), ptr(u.sums), B, u.h, u.w_, u.cout_p, dc, s)
-        call('clamd_bn_bwd_finalize', ptr(u.sums), ptr(u.gamma), ptr(v[2]), ptr(v[3]), ptr(v[4]), ptr(g[u.keys[2]]),
-             ptr(g[u.keys[3]]), ptr(g[u.keys[1]]), u.cout_p, u.cout, count, s)
+        call('clamd_bn_bwd_finalize', ptr(u.sums), ptr(u.gamma), ptr(v[2]), ptr(v[3]), ptr(v[4]), g[u.keys[2]],
+             g[u.keys[3]], g[u.keys[1]], u.cout_p, u.cout, count, s)
         call('clamd_bn_bwd_apply', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.cout_p,
              ptr(v[0]), ptr(v[1]), ptr(v[4]), ptr(u.gz), u.cout_p, B, u.h, u.w_, u.cout_p, dc, s)
         if len(u.cin_segs) == 2:
             c_seg0, c_seg0p = u.cin_segs[0]
         else:
-            c_seg0, c_seg0p = u.cin, 0
+            c_seg0, c_seg0p = u.cin, u.cin_p
         flops = 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout
         _timed('wgrad_conv3x3', flops,
                'clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
-               ptr(g[u.keys[0]]), B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, 0, c_seg0, c_seg0p, dc, s)
+               g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, dc, s)
         if u.g_in is not None:
             _timed('igemm_conv3x3', flops,
                    'clamd_conv3x3', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,

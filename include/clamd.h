@@ -65,8 +65,9 @@ int clamd_convT2x2_dgrad(const void* gy, int gy_ldc, const void* w_packed, void*
  *   CONV3: a = d(conv output), b = conv input  -> d weight [Cout][Cin][3][3]
  *   PW   : a = d logits,       b = head input  -> d weight [K][Cin][1][1]
  *   UP2  : a = convT input,    b = d(convT output) -> d weight [Cin][Cout][2][2]
- * R,C logical sizes; logical index l maps to physical l (l < seg0) or seg0p + (l - seg0): concat inputs keep each
- * half padded separately.  workspace: fp32 split-K slabs, size >= clamd_wgrad_workspace_bytes(). */
+ * R,C logical sizes.  Physical channel p maps to logical p (p < seg0p and p < seg0), to padding (seg0 <= p < seg0p),
+ * or to seg0 + (p - seg0p): concat inputs keep each half padded separately; a single segment is (seg0, seg0p) =
+ * (logical size, physical size).  workspace: fp32 split-K slabs, size >= clamd_wgrad_workspace_bytes(). */
 size_t clamd_wgrad_workspace_bytes(int mode, int B, int H, int W, int Rp, int Cp, int dtype);
 int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, float* workspace, size_t ws_bytes,
                 float* out, int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0,

@@ -192,9 +192,9 @@ def test_conv3x3_dgrad_and_wgrad(C, name, dcode, shape):
     wsb = lib.load().clamd_wgrad_workspace_bytes(0, B, H, W, cout_p, cin_p, dcode)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
-    c_seg0, c_seg0p = (segs[0][0], segs[0][1]) if len(segs) == 2 else (cin, 0)
+    c_seg0, c_seg0p = (segs[0][0], segs[0][1]) if len(segs) == 2 else (cin, cin_p)
     lib.call('clamd_wgrad', 0, ptr(gzt), cout_p, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, cin_p, cout, cin,
-             cout, 0, c_seg0, c_seg0p, dcode, s)
+             cout, cout_p, c_seg0, c_seg0p, dcode, s)
     sync()
     rgx, rgw, _ = O.conv3x3_bwd(x, w, gz)
     pm = phys_map(segs)
@@ -238,7 +238,7 @@ def test_convT2x2_fwd_dgrad_wgrad(C, name, dcode, shape):
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     gw = torch.zeros(cin, cout, 2, 2, device='cuda')
     lib.call('clamd_wgrad', 2, ptr(xt), cin_p, ptr(gsl), 2 * cout_p, ptr(ws), wsb, ptr(gw), B, h, w_, cin_p, cout_p, cin, cout,
-             cin, 0, cout, 0, dcode, s)
+             cin, cin_p, cout, cout_p, dcode, s)
     gb = torch.zeros(cout, device='cuda')
     lib.call('clamd_channel_sum', ptr(gsl), 2 * cout_p, ptr(gb), B * 4 * h * w_, cout_p, cout, dcode, s)
     sync()
@@ -275,7 +275,7 @@ def test_head_fwd_bwd(C, name, dcode, shape):
     wsb = lib.load().clamd_wgrad_workspace_bytes(1, B, H, W, kp, cin_p, dcode)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     gw = torch.zeros(K, cin, 1, 1, device='cuda')
-    lib.call('clamd_wgrad', 1, ptr(gt), kp, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, kp, cin_p, K, cin, K, 0, cin, 0, dcode, s)
+    lib.call('clamd_wgrad', 1, ptr(gt), kp, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, kp, cin_p, K, cin, K, kp, cin, cin_p, dcode, s)
     sync()
     rgx, rgw, _ = O.conv1x1_bwd(x, w, g)
     assert rel_l2(C.ops.from_nhwc(gx, cin, dcode).cpu().numpy(), rgx) < TOL[dcode]

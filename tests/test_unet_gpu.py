@@ -93,7 +93,8 @@ def test_train_steps_vs_reference_golden(C, golden, fixture, nc, cd, size, dtype
                 got, ref = sd[k[3:]].cpu().numpy(), g[k]
                 # Adam's sign-like first steps amplify rounding-level gradients (|update| = lr whatever |g|)
                 bad = int((np.abs(got - ref) > 0.5 * float(g['lr'])).sum())
-                assert rel_l2(got, ref) < 1e-2 and bad <= max(2, 0.02 * got.size), k
+                is_stat = k.endswith(('running_mean', 'running_var'))
+                assert rel_l2(got, ref) < 1e-2 and (is_stat or bad <= max(2, 0.02 * got.size)), k
     assert int(model.state_dict()['enc1.2.num_batches_tracked']) == 3
 
 
@@ -249,7 +250,7 @@ def test_adjoint_identities_full_size(C):
     lib.call('clamd_conv3x3', ptr(g), Cc, ptr(wd), None, ptr(gx), Cc, None, B, H, W, Cc, Cc, 0, 0, 0, s)
     wsb = lib.load().clamd_wgrad_workspace_bytes(0, B, H, W, Cc, Cc, 0)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
-    lib.call('clamd_wgrad', 0, ptr(g), Cc, ptr(x), Cc, ptr(ws), wsb, ptr(gw), B, H, W, Cc, Cc, Cc, Cc, Cc, 0, Cc, 0, 0, s)
+    lib.call('clamd_wgrad', 0, ptr(g), Cc, ptr(x), Cc, ptr(ws), wsb, ptr(gw), B, H, W, Cc, Cc, Cc, Cc, Cc, Cc, Cc, Cc, 0, s)
     torch.cuda.synchronize()
     a = float((y.double() * g.double()).sum()); b = float((x.double() * gx.double()).sum()); c = float((w.double() * gw.double()).sum())
     assert abs(a - b) < 1e-5 * abs(a) and abs(a - c) < 1e-5 * abs(a), (a, b, c)
