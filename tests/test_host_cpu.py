@@ -1,0 +1,99 @@
+"""CPU-only tests of the host side: C-ABI library loads and exports every symbol include/clamd.h declares, the
+drop-in module surface matches the reference's state_dict, synthetic data is deterministic, engine geometry and
+packing tables are consistent.  No kernel is launched here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def C():
+    import continual_learning_amd as C
+    return C
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, 'include', 'clamd.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(clamd_[a-z0-9_A-Z]+)\s*\(', src)))
+
+
+def test_abi_library_exports_every_declared_symbol(C):
+    names = header_functions()
+    assert len(names) >= 25
+    lib = ctypes.CDLL(C._lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/clamd.h but not exported by libclamd.so'
+    assert sorted(C._lib.SIGNATURES) == names, 'ctypes signature table and header disagree'
+    l = C._lib.load()
+    assert l.clamd_version() >= 100
+    assert l.clamd_sizeof_pack_job() == 120 and l.clamd_sizeof_adam_tensor() == 48
+    assert l.clamd_stat_replicas() == 16 and l.clamd_bn_bwd_nsums() == 5
+
+
+def test_module_surface_matches_reference_state_dict(C, golden):
+    g = golden('unet_cd8_c21_64.npz')
+    m = C.UNet(21, 3, 8)
+    assert [n for n, _ in m.named_parameters()] == list(g['grad_names'])
+    sd = m.state_dict()
+    assert len(sd) == 136
+    assert sd['dec1.block.6.weight'].shape == (128, 64, 2, 2)         # ConvTranspose2d [Cin, Cout, 2, 2]
+    assert sd['enc2.block.1.weight'].shape == (16, 8, 3, 3)
+    assert sd['last.6.weight'].shape == (21, 8, 1, 1)
+    assert sd['enc1.2.num_batches_tracked'].dtype == torch.int64
+    full = C.UNet(21)
+    assert sum(p.numel() for p in full.parameters()) == 31_044_821
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 32, 32))                                    # no CPU fallback
+
+
+def test_synth_is_deterministic_and_blocky(C):
+    a = C.synth.images(1234, 2, 3, 32, 32)
+    b = C.synth.images(1234, 4, 3, 32, 32)
+    assert a.dtype == np.float32 and a.min() >= -1 and a.max() < 1
+    assert np.array_equal(a, b[:2])
+    assert np.array_equal(C.synth.images(1234, 2, 3, 32, 32, first_image=2), b[2:])
+    l = C.synth.labels(1234, 2, 64, 64, 21)
+    assert l.dtype == np.int64 and l.min() >= 0 and l.max() < 21
+    assert (l[:, :16, :16] == l[:, :1, :1]).all()
+    l2 = C.synth.labels(1234, 2, 64, 64, 21, class_lo=11, class_hi=21)
+    assert set(np.unique(l2)) <= {0, *range(11, 21)}
+    w = C.synth.closed_form_tensor('enc1.0.weight', (4, 3, 3, 3))
+    assert np.abs(w).max() <= 1 / np.sqrt(27) + 1e-7
+
+
+def test_engine_geometry_and_pack_table(C):
+    from continual_learning_amd.unet import _Engine
+    m = C.UNet(21, 3, 8)
+    e = _Engine(m, 2, 64, 64, torch.device('cpu'))
+    assert len(e.convs) == 18 and len(e.stages) == 9
+    assert e.gflat.numel() == sum(p.numel() for p in m.parameters())
+    # flat gradient buffer is in reverse registration order: the head's bias first, enc1.0.weight last
+    assert e.goffset['last.6.bias'][0] == 0
+    assert e.goffset['enc1.0.weight'][0] + e.goffset['enc1.0.weight'][1] == e.gflat.numel()
+    dec2a = [u for u in e.convs if u.name == 'dec2.block.0'][0]
+    assert dec2a.cin_segs == [(64, 64), (64, 64)] and dec2a.xin is e.cat[3]
+    enc1b = [u for u in e.convs if u.name == 'enc1.3'][0]
+    assert enc1b.out is e.cat[0] and enc1b.pooled is e.pool[0] and enc1b.out_ldc == 64
+    jobs = e.pack_table.jobs
+    assert len(jobs) == 18 * 3 - 1 + 5 * 3            # wf + wd + bias per conv (no wd for enc1.0), 3 per tail
+    assert e.pack_table.nblocks == sum((j[2] * j[3] * j[4] + 255) // 256 for j in jobs)
+    assert C.cpad(3) == 32 and C.cpad(21) == 32 and C.cpad(1024) == 1024
+
+
+def test_fused_adam_state_dict_layout_without_gpu(C):
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = C.FusedAdam([p], lr=1e-4, betas=[0.5, 0.99])
+    ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros(3))], lr=1e-4, betas=[0.5, 0.99])
+    a, b = opt.state_dict()['param_groups'][0], ref.state_dict()['param_groups'][0]
+    for k in ('lr', 'betas', 'eps', 'weight_decay', 'amsgrad', 'params'):
+        assert a[k] == b[k] or list(a[k]) == list(b[k])
+    p.grad = torch.zeros(3)
+    with pytest.raises(RuntimeError):
+        opt.step()                                     # CPU parameters: fails loudly
