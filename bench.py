@@ -101,6 +101,23 @@ def run(args, dtype, rank, world, device, timing=True):
     return dt, float(loss), kern
 
 
+def pmc_traffic(dtype):
+    """HBM bytes per launch of the conv3x3 implicit-GEMM kernel from the committed rocprofv3 PMC passes
+    (profiles/*traffic_<dtype>.json, written by tools/pmc_summary.py; FETCH_SIZE x2 gfx950 correction applied).
+    A running process cannot read PMC counters of its own kernels, so this is the profile of the same command."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'*traffic_{dtype}.json')))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    tot, n = 0.0, 0
+    for k, v in d['kernels'].items():
+        if k.startswith('igemm_kernel<') and k.replace(' ', '').split(',')[1:3] == ['0', '0']:
+            tot += (v['hbm_read_bytes_per_launch'] + v['hbm_write_bytes_per_launch']) * v['launches']
+            n += v['launches']
+    return round(tot / n) if n else None
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -139,8 +156,9 @@ def main():
         sec, flops, n = kern.get('igemm_conv3x3', (0, 0, 0))
         if sec > 0:
             ach = flops / sec / 1e12
+            traffic = pmc_traffic(args.dtype)
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK[args.dtype], 'unit': 'TFLOP/s',
-                               'frac': round(ach / PEAK[args.dtype], 4), 'traffic': None,
+                               'frac': round(ach / PEAK[args.dtype], 4), 'traffic': traffic,
                                'kernel': 'clamd::igemm_kernel<T,CONV3,NHWC,TW> (conv3x3 fwd + dgrad)',
                                'launches': n, 'avg_launch_ms': round(sec / n * 1e3, 4),
                                'ms_per_step': round(sec / 2 * 1e3, 3),
