@@ -22,6 +22,7 @@ SIGNATURES = {
     'clamd_sizeof_pack_job': (_I, []),
     'clamd_sizeof_adam_tensor': (_I, []),
     'clamd_adam_chunk_elems': (_I, []),
+    'clamd_pack_tile': (_I, []),
     'clamd_stat_replicas': (_I, []),
     'clamd_bn_bwd_nsums': (_I, []),
     'clamd_conv3x3': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -45,6 +46,7 @@ SIGNATURES = {
     'clamd_adam_step': (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
     'clamd_argmax_confusion': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'clamd_fill_f32': (_I, [_P, _LL, _D, _P]),
+    'clamd_set_tuning': (_I, [c_char_p, _I]),
 }
 
 _lib = None

@@ -18,6 +18,7 @@
 // Epilogues (EPI):  NHWC  (+bias, ReLU, per-channel sum / sum-of-squares for BatchNorm, store T),
 //                   UP2   (ConvTranspose2d forward: column n = (dy,dx,co) is scattered to pixel (2y+dy,2x+dx)),
 //                   NCHW  (logits head: fp32 NCHW, only the logical classes).
+#include <string.h>
 #include "common.hip.h"
 #include "clamd_internal.h"
 
@@ -55,7 +56,7 @@ template <int MODE, int TW> struct Geo {
     static constexpr int SLOTS = IN_SLOTS + WT_SLOTS > EPI_SLOTS ? IN_SLOTS + WT_SLOTS : EPI_SLOTS;
 };
 
-template <typename T, int MODE, int EPI, int TW>
+template <typename T, int MODE, int EPI, int TW, int VAR>
 __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
     using G = Geo<MODE, TW>;
     constexpr int TH = G::TH, NT = G::NT, NIN = G::NIN, HW_ = G::HW_, NPIX = G::NPIX, NPIXP = G::NPIXP, NJ = G::NJ;
@@ -162,21 +163,54 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
         IGEMM_LDS_STORE();
         __syncthreads();
         if (ks + 1 < nk) IGEMM_GLOAD(ks + 1);   // in flight during the MFMA loop below
+        if constexpr (VAR == 0) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int in_base = MODE == MODE_CONV3 ? (t / 3) * HW_ + (t % 3) : t * 4 * NPIXP;
+            for (int t = 0; t < NT; ++t) {
+                const int in_base = MODE == MODE_CONV3 ? (t / 3) * HW_ + (t % 3) : t * 4 * NPIXP;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int g = kk * 2 + h;
-                const uint4 a0 = smem[in_base + g * NPIXP + apix[0]];
-                const uint4 a1 = smem[in_base + g * NPIXP + apix[1]];
-                const uint4 b0 = smem[G::IN_SLOTS + (t * 4 + g) * G::WG + r];
-                const uint4 b1 = smem[G::IN_SLOTS + (t * 4 + g) * G::WG + 32 + r];
-                mma16<T>(a0, b0, acc[0][0]);
-                mma16<T>(a0, b1, acc[0][1]);
-                mma16<T>(a1, b0, acc[1][0]);
-                mma16<T>(a1, b1, acc[1][1]);
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int g = kk * 2 + h;
+                    const uint4 a0 = smem[in_base + g * NPIXP + apix[0]];
+                    const uint4 a1 = smem[in_base + g * NPIXP + apix[1]];
+                    const uint4 b0 = smem[G::IN_SLOTS + (t * 4 + g) * G::WG + r];
+                    const uint4 b1 = smem[G::IN_SLOTS + (t * 4 + g) * G::WG + 32 + r];
+                    mma16<T>(a0, b0, acc[0][0]);
+                    mma16<T>(a0, b1, acc[0][1]);
+                    mma16<T>(a1, b0, acc[1][0]);
+                    mma16<T>(a1, b1, acc[1][1]);
+                }
             }
+        } else {
+            // fragments of step s+1 are read from LDS while the MFMAs of step s run (explicit double buffering)
+            constexpr int NSTEP = 2 * NT;
+            constexpr int NMF = sizeof(T) == 2 ? 4 : 16;
+            uint4 fa0, fa1, fb0, fb1, na0, na1, nb0, nb1;
+#define IGEMM_FRAG(s_, a0_, a1_, b0_, b1_)                                                                       \
+    do {                                                                                                          \
+        const int t_ = (s_) >> 1, g_ = ((s_) & 1) * 2 + h;                                                        \
+        const int ib_ = MODE == MODE_CONV3 ? (t_ / 3) * HW_ + (t_ % 3) : t_ * 4 * NPIXP;                          \
+        a0_ = smem[ib_ + g_ * NPIXP + apix[0]];                                                                   \
+        a1_ = smem[ib_ + g_ * NPIXP + apix[1]];                                                                   \
+        b0_ = smem[G::IN_SLOTS + (t_ * 4 + g_) * G::WG + r];                                                      \
+        b1_ = smem[G::IN_SLOTS + (t_ * 4 + g_) * G::WG + 32 + r];                                                 \
+    } while (0)
+            IGEMM_FRAG(0, fa0, fa1, fb0, fb1);
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                if (st + 1 < NSTEP) IGEMM_FRAG(st + 1, na0, na1, nb0, nb1);
+                if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(1);
+                mma16<T>(fa0, fb0, acc[0][0]);
+                mma16<T>(fa0, fb1, acc[0][1]);
+                mma16<T>(fa1, fb0, acc[1][0]);
+                mma16<T>(fa1, fb1, acc[1][1]);
+                if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(0);
+                if constexpr (VAR >= 1) {
+                    if (st + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+                }
+                fa0 = na0; fa1 = na1; fb0 = nb0; fb1 = nb1;
+            }
+#undef IGEMM_FRAG
         }
     }
 
@@ -317,6 +351,8 @@ static_assert(Geo<MODE_CONV3, 16>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4,
 static_assert(Geo<MODE_PW, 32>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4, "LDS too small for epilogue");
 static_assert(Geo<MODE_PW, 16>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4, "LDS too small for epilogue");
 
+static int g_igemm_variant = 0;   // tuning knob (clamd_set_tuning): 0 = compiler-scheduled, 1/2 = explicit fragment double-buffering
+
 template <typename T, int MODE, int EPI>
 static int launch_tw(const IgemmParams& p, hipStream_t s) {
     const bool wide = p.W >= 32;
@@ -324,8 +360,16 @@ static int launch_tw(const IgemmParams& p, hipStream_t s) {
     const long long tiles = (long long)((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.B;
     const long long nblk = tiles * ((p.Np + 63) / 64);
     if (nblk <= 0 || nblk > 0x7fffffff) return clamd_fail("igemm: grid out of range");
-    if (wide) hipLaunchKernelGGL((igemm_kernel<T, MODE, EPI, 32>), dim3((unsigned)nblk), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((igemm_kernel<T, MODE, EPI, 16>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+    const int var = (MODE == MODE_CONV3 && EPI == EPI_NHWC) ? g_igemm_variant : 0;
+#define IGEMM_LAUNCH(TW_, V_) hipLaunchKernelGGL((igemm_kernel<T, MODE, EPI, TW_, V_>), dim3((unsigned)nblk), dim3(256), 0, s, p)
+    if constexpr (MODE == MODE_CONV3 && EPI == EPI_NHWC) {
+        if (wide) { if (var == 1) IGEMM_LAUNCH(32, 1); else if (var == 2) IGEMM_LAUNCH(32, 2); else IGEMM_LAUNCH(32, 0); }
+        else { if (var == 1) IGEMM_LAUNCH(16, 1); else if (var == 2) IGEMM_LAUNCH(16, 2); else IGEMM_LAUNCH(16, 0); }
+    } else {
+        if (wide) IGEMM_LAUNCH(32, 0); else IGEMM_LAUNCH(16, 0);
+    }
+#undef IGEMM_LAUNCH
+    (void)var;
     return clamd_check_launch("igemm");
 }
 
@@ -350,6 +394,11 @@ static int check_common(const IgemmParams& p, const char* who) {
 using namespace clamd;
 
 extern "C" {
+
+int clamd_set_tuning(const char* key, int value) {
+    if (!strcmp(key, "igemm_variant")) { g_igemm_variant = value; return 0; }
+    return clamd_fail("set_tuning: unknown key");
+}
 
 int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
                   float* stats, int B, int H, int W, int Cin_p, int Cout_p, int relu, int m_fastest, int dtype,

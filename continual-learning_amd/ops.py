@@ -67,13 +67,16 @@ class PackTable:
         self.add(v, dst, 1, 1, cpad(c), 1, c, 0, 0, 1, 0, 0, 1, f32=1)
 
     def finalize(self, device):
-        assert _lib.load().clamd_sizeof_pack_job() == _PACK_DT.itemsize
+        lib = _lib.load()
+        assert lib.clamd_sizeof_pack_job() == _PACK_DT.itemsize
+        tile = lib.clamd_pack_tile()
         arr = np.zeros(len(self.jobs), dtype=_PACK_DT)
         blk = 0
         for i, j in enumerate(self.jobs):
+            assert j[2] <= 9, 'pack: at most 9 taps'
             arr[i] = j
             arr[i]['block0'] = blk
-            blk += (j[2] * j[3] * j[4] + 255) // 256
+            blk += ((j[3] + tile - 1) // tile) * ((j[4] + tile - 1) // tile)
         self.dev_table = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
         self.nblocks = blk
         return self

@@ -34,6 +34,7 @@ int clamd_version(void);
 int clamd_sizeof_pack_job(void);
 int clamd_sizeof_adam_tensor(void);
 int clamd_adam_chunk_elems(void);
+int clamd_pack_tile(void);            /* clamd_pack: blocks per job = ceil(Np/tile) * ceil(Kp/tile) */
 int clamd_stat_replicas(void);
 int clamd_bn_bwd_nsums(void);
 
@@ -119,6 +120,8 @@ int clamd_adam_step(const void* tensors_dev, const void* chunks_dev, int nchunks
 int clamd_argmax_confusion(const float* logits, const long long* labels, long long* pred, unsigned long long* conf,
                            int B, int K, int Kc, int H, int W, void* stream);
 int clamd_fill_f32(float* p, long long n, double v, void* stream);
+/* performance experiments only (never changes results): e.g. ("igemm_variant", 0|1|2). */
+int clamd_set_tuning(const char* key, int value);
 
 #ifdef __cplusplus
 }

@@ -83,7 +83,7 @@ def test_engine_geometry_and_pack_table(C):
     assert enc1b.out is e.cat[0] and enc1b.pooled is e.pool[0] and enc1b.out_ldc == 64
     jobs = e.pack_table.jobs
     assert len(jobs) == 18 * 3 - 1 + 5 * 3            # wf + wd + bias per conv (no wd for enc1.0), 3 per tail
-    assert e.pack_table.nblocks == sum((j[2] * j[3] * j[4] + 255) // 256 for j in jobs)
+    assert e.pack_table.nblocks == sum(((j[3] + 31) // 32) * ((j[4] + 31) // 32) for j in jobs)
     assert C.cpad(3) == 32 and C.cpad(21) == 32 and C.cpad(1024) == 1024
 
 

@@ -254,3 +254,40 @@ def test_adjoint_identities_full_size(C):
     torch.cuda.synchronize()
     a = float((y.double() * g.double()).sum()); b = float((x.double() * gx.double()).sum()); c = float((w.double() * gw.double()).sum())
     assert abs(a - b) < 1e-5 * abs(a) and abs(a - c) < 1e-5 * abs(a), (a, b, c)
+
+
+def test_gradsync_rccl_world1_on_gpu(C):
+    """The RCCL code path of ddp.GradSync (side stream, per-stage buckets, optimiser hook) with a 1-rank "nccl"
+    process group on the one GPU of the test box: results must equal the plain single-GPU step."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        created = True
+    try:
+        x = torch.from_numpy(C.synth.images(3, 2, 3, 64, 64)).cuda()
+        y = torch.from_numpy(C.synth.labels(3, 2, 64, 64, 6)).cuda()
+        outs = []
+        for use_ddp in (False, True):
+            torch.manual_seed(0)
+            m = C.UNet(6, 3, 8).cuda().train()
+            opt = C.FusedAdam(m.parameters(), lr=1e-3, betas=[0.5, 0.99])
+            if use_ddp:
+                C.ddp.broadcast_parameters(m)
+                gs = C.ddp.GradSync(m, opt, min_bucket_bytes=16 << 10)
+                assert opt.grad_scale == 1.0
+            crit = C.CrossEntropyLoss()
+            for _ in range(2):
+                out = m(x); opt.zero_grad(); loss = crit(out, y); loss.backward(); opt.step()
+            torch.cuda.synchronize()
+            outs.append((float(loss), m.state_dict()['dec2.block.0.weight'].clone()))
+        # BN statistics are accumulated with float atomics (order varies run to run) and Adam's first steps are
+        # sign-like, so two runs agree to ~1e-5 absolute, not bitwise
+        assert abs(outs[0][0] - outs[1][0]) < 1e-5
+        assert torch.allclose(outs[0][1], outs[1][1], rtol=0, atol=1e-4)
+    finally:
+        if created:
+            dist.destroy_process_group()
