@@ -23,7 +23,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FLOP_PER_IMAGE_256 = 289_281_146_880          # train step, SURVEY.md §8d / BASELINE.md
-PEAK = {'fp32': 157.3, 'bf16': 2500.0}         # dense MFMA TFLOP/s, MI355X_MICROARCH.md:42-43
+PEAK = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0 / 3}   # dense MFMA TFLOP/s (MI355X_MICROARCH.md:42-43); bf16x3
+#                                                              # issues 3 bf16 MFMAs per algorithmic multiply-add
+DTYPE_NAME = {'fp32': 'f32', 'bf16': 'bf16', 'bf16x3': 'bf16x3 (f32 storage, hi/lo-split bf16 MFMA, f32 accumulate)'}
 
 
 def parse():
@@ -31,7 +33,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'])
+    ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16', 'bf16x3'])
     ap.add_argument('--batch', type=int, default=16, help='images per GPU')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--conv-dim', type=int, default=64)
@@ -142,11 +144,11 @@ def main():
     out = {
         'metric': 'images/sec UNET 256x256 bs16 train step', 'value': round(value, 2), 'unit': 'images/sec',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.dtype == 'fp32' else 'bf16',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_NAME[args.dtype],
         'data': 'synthetic (splitmix64 images U(-1,1), blocky 21-class labels), random-init weights',
         'config': {'workload': f'UNet({args.num_classes},3,{args.conv_dim}) {args.size}x{args.size} bs{args.batch}/GPU '
                                f'{args.dtype} train step (fwd + CE + bwd + Adam), BASELINE.json configs['
-                               f'{1 if args.dtype == "fp32" else 2}]',
+                               f'{2 if args.dtype == "bf16" else 1}]',
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'final_loss': round(loss, 5)},
         'step_tflops': round(value * flop_img / 1e12, 2),
         'step_frac_of_mfma_peak': round(value * flop_img / 1e12 / (PEAK[args.dtype] * world), 4),

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_double, c_int, c_longlong, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libclamd.so')
 
-F32, BF16 = 0, 1
+F32, BF16, SPLIT = 0, 1, 2      # SPLIT = 'bf16x3': fp32 storage, 3-term split-bf16 MFMA
 WGRAD_CONV3, WGRAD_PW, WGRAD_UP2 = 0, 1, 2
 
 _P, _I, _D, _LL, _SZ = c_void_p, c_int, c_double, c_longlong, c_size_t

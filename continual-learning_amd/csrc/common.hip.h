@@ -11,6 +11,10 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 struct bf16_t { uint16_t v; };   // storage type tag for bf16 tensors
+// "split" compute type: tensors are STORED as fp32; the MFMA kernels split every operand x into bf16 hi = rne(x) and
+// lo = rne(x - hi) at LDS-staging time and accumulate hi*hi + hi*lo + lo*hi in fp32 with three bf16 MFMAs
+// (relative product error ~2^-17 instead of bf16's 2^-9, at 3/16 of the fp32-MFMA cost).
+struct split_t { float v; };
 
 // ---- dtype traits -------------------------------------------------------------------------------
 template <typename T> struct DT;
@@ -24,6 +28,11 @@ template <> struct DT<bf16_t> {
     static constexpr int BYTES = 2;
     static constexpr int VEC = 8;
     static constexpr int KC = 32;
+};
+template <> struct DT<split_t> {
+    static constexpr int BYTES = 4;
+    static constexpr int VEC = 4;
+    static constexpr int KC = 16;
 };
 
 __device__ inline float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
@@ -63,6 +72,24 @@ template <> struct Vec8<bf16_t> {
         *reinterpret_cast<uint4*>(p) = u;
     }
 };
+
+template <> struct Vec8<split_t> {
+    __device__ static inline void load(const split_t* p, float (&v)[8]) { Vec8<float>::load(reinterpret_cast<const float*>(p), v); }
+    __device__ static inline void store(split_t* p, const float (&v)[8]) { Vec8<float>::store(reinterpret_cast<float*>(p), v); }
+};
+
+// fp32 x4 -> bf16 hi x4 and bf16 lo x4 (lo = rne(x - float(hi)))
+__device__ inline void split4(const uint4& x, uint2& hi, uint2& lo) {
+    const float f0 = __uint_as_float(x.x), f1 = __uint_as_float(x.y), f2 = __uint_as_float(x.z), f3 = __uint_as_float(x.w);
+    const uint16_t h0 = f2bf(f0), h1 = f2bf(f1), h2 = f2bf(f2), h3 = f2bf(f3);
+    hi.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
+    hi.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+    lo.x = pack2bf(f0 - bf2f(h0), f1 - bf2f(h1));
+    lo.y = pack2bf(f2 - bf2f(h2), f3 - bf2f(h3));
+}
+__device__ inline void mma_bf16(const uint4& a, const uint4& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
 
 template <typename T> __device__ inline float ld1(const T* p);
 template <> __device__ inline float ld1<float>(const float* p) { return *p; }

@@ -362,7 +362,7 @@ int clamd_bn_apply(const void* y, int y_ldc, const float* scale, const float* sh
 #define LAUNCH(T, P) hipLaunchKernelGGL((bn_apply_kernel<T, P>), g, b, 0, s, (const T*)y, y_ldc, scale, shift, \
                                         (T*)out, out_ldc, (T*)pooled, p_ldc, B, H, W, Cp)
     if (dtype == CLAMD_BF16) { if (pooled) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
-    else if (dtype == CLAMD_F32) { if (pooled) LAUNCH(float, true); else LAUNCH(float, false); }
+    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT) { if (pooled) LAUNCH(float, true); else LAUNCH(float, false); }
     else return clamd_fail("bn_apply: bad dtype");
 #undef LAUNCH
     return clamd_check_launch("bn_apply");
@@ -381,7 +381,7 @@ int clamd_bn_bwd_reduce(const void* ga, int ga_ldc, const void* gp, int gp_ldc, 
 #define LAUNCH(T, P) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, P>), g, b, 0, s, (const T*)ga, ga_ldc, \
                                         (const T*)gp, gp_ldc, (const T*)y, y_ldc, scale, shift, sums, B, H, W, Cp)
     if (dtype == CLAMD_BF16) { if (gp) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
-    else if (dtype == CLAMD_F32) { if (gp) LAUNCH(float, true); else LAUNCH(float, false); }
+    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT) { if (gp) LAUNCH(float, true); else LAUNCH(float, false); }
     else return clamd_fail("bn_bwd_reduce: bad dtype");
 #undef LAUNCH
     return clamd_check_launch("bn_bwd_reduce");
@@ -405,7 +405,7 @@ int clamd_bn_bwd_apply(const void* ga, int ga_ldc, const void* gp, int gp_ldc, c
 #define LAUNCH(T, P) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, P>), g, b, 0, s, (const T*)ga, ga_ldc, \
                                         (const T*)gp, gp_ldc, (const T*)y, y_ldc, scale, shift, k012, (T*)gz, gz_ldc, B, H, W, Cp)
     if (dtype == CLAMD_BF16) { if (gp) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
-    else if (dtype == CLAMD_F32) { if (gp) LAUNCH(float, true); else LAUNCH(float, false); }
+    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT) { if (gp) LAUNCH(float, true); else LAUNCH(float, false); }
     else return clamd_fail("bn_bwd_apply: bad dtype");
 #undef LAUNCH
     return clamd_check_launch("bn_bwd_apply");
@@ -418,7 +418,7 @@ int clamd_channel_sum(const void* g, int ldc, float* out, long long npix, int Cp
     dim3 gr((unsigned)(gb > 1024 ? 1024 : gb)), b(256);
     if (dtype == CLAMD_BF16)
         hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, gr, b, 0, (hipStream_t)stream, (const bf16_t*)g, ldc, out, npix, Cp, C);
-    else if (dtype == CLAMD_F32)
+    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT)
         hipLaunchKernelGGL(channel_sum_kernel<float>, gr, b, 0, (hipStream_t)stream, (const float*)g, ldc, out, npix, Cp, C);
     else return clamd_fail("channel_sum: bad dtype");
     return clamd_check_launch("channel_sum");
@@ -431,7 +431,7 @@ int clamd_nchw_to_nhwc(const float* src, void* dst, int ldc, int B, int C, int H
     dim3 g(ew_grid(nitem, 8192)), b(256);
     if (dtype == CLAMD_BF16)
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, src, (bf16_t*)dst, ldc, B, C, H, W, Cp, (float)mul);
-    else if (dtype == CLAMD_F32)
+    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT)
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, g, b, 0, (hipStream_t)stream, src, (float*)dst, ldc, B, C, H, W, Cp, (float)mul);
     else return clamd_fail("nchw_to_nhwc: bad dtype");
     return clamd_check_launch("nchw_to_nhwc");
@@ -442,7 +442,7 @@ int clamd_nhwc_to_nchw(const void* src, int ldc, float* dst, int B, int C, int H
     dim3 g(ew_grid(n, 8192)), b(256);
     if (dtype == CLAMD_BF16)
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, (const bf16_t*)src, ldc, dst, B, C, H, W);
-    else if (dtype == CLAMD_F32)
+    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT)
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, g, b, 0, (hipStream_t)stream, (const float*)src, ldc, dst, B, C, H, W);
     else return clamd_fail("nhwc_to_nchw: bad dtype");
     return clamd_check_launch("nhwc_to_nchw");

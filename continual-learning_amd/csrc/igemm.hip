@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
     using G = Geo<MODE, TW>;
     constexpr int TH = G::TH, NT = G::NT, NIN = G::NIN, HW_ = G::HW_, NPIX = G::NPIX, NPIXP = G::NPIXP, NJ = G::NJ;
     constexpr int KC = DT<T>::KC, VEC = DT<T>::VEC;
+    constexpr bool SPLIT = sizeof(T) == 4 && DT<T>::KC == 16 && !__is_same(T, float);
     __shared__ uint4 smem[G::SLOTS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,7 +136,16 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
         _Pragma("unroll") for (int t = 0; t < NIN; ++t)                                                           \
             _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                      \
                 const int pix_ = (tid >> 2) + 64 * j;                                                             \
-                if (pix_ < NPIX) smem[t * 4 * NPIXP + g4 * NPIXP + pix_] = rin[t][j];                             \
+                if constexpr (!SPLIT) {                                                                           \
+                    if (pix_ < NPIX) smem[t * 4 * NPIXP + g4 * NPIXP + pix_] = rin[t][j];                         \
+                } else if (pix_ < NPIX) {                                                                         \
+                    /* groups 0,1 = hi channels 0-7 / 8-15, groups 2,3 = lo; this thread owns 4 channels */       \
+                    uint2 hi_, lo_;                                                                               \
+                    split4(rin[t][j], hi_, lo_);                                                                  \
+                    char* b_ = reinterpret_cast<char*>(smem) + ((t * 4 + (g4 >> 1)) * NPIXP + pix_) * 16 + 8 * (g4 & 1); \
+                    *reinterpret_cast<uint2*>(b_) = hi_;                                                          \
+                    *reinterpret_cast<uint2*>(b_ + 2 * NPIXP * 16) = lo_;                                         \
+                }                                                                                                 \
             }                                                                                                     \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) smem[G::IN_SLOTS + (t * 4 + g4) * G::WG + wco] = rw[t];    \
     } while (0)
@@ -163,7 +173,21 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
         IGEMM_LDS_STORE();
         __syncthreads();
         if (ks + 1 < nk) IGEMM_GLOAD(ks + 1);   // in flight during the MFMA loop below
-        if constexpr (VAR == 0) {
+        if constexpr (SPLIT) {
+            // one 16-channel k-step per tap: groups h / 2+h hold the hi / lo halves; 3 MFMAs per tile
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int in_base = MODE == MODE_CONV3 ? (t / 3) * HW_ + (t % 3) : t * 4 * NPIXP;
+                const uint4 ah0 = smem[in_base + h * NPIXP + apix[0]], al0 = smem[in_base + (2 + h) * NPIXP + apix[0]];
+                const uint4 ah1 = smem[in_base + h * NPIXP + apix[1]], al1 = smem[in_base + (2 + h) * NPIXP + apix[1]];
+                const uint4 bh0 = smem[G::IN_SLOTS + (t * 4 + h) * G::WG + r], bl0 = smem[G::IN_SLOTS + (t * 4 + 2 + h) * G::WG + r];
+                const uint4 bh1 = smem[G::IN_SLOTS + (t * 4 + h) * G::WG + 32 + r], bl1 = smem[G::IN_SLOTS + (t * 4 + 2 + h) * G::WG + 32 + r];
+                mma_bf16(al0, bh0, acc[0][0]); mma_bf16(ah0, bl0, acc[0][0]); mma_bf16(ah0, bh0, acc[0][0]);
+                mma_bf16(al0, bh1, acc[0][1]); mma_bf16(ah0, bl1, acc[0][1]); mma_bf16(ah0, bh1, acc[0][1]);
+                mma_bf16(al1, bh0, acc[1][0]); mma_bf16(ah1, bl0, acc[1][0]); mma_bf16(ah1, bh0, acc[1][0]);
+                mma_bf16(al1, bh1, acc[1][1]); mma_bf16(ah1, bl1, acc[1][1]); mma_bf16(ah1, bh1, acc[1][1]);
+            }
+        } else if constexpr (VAR == 0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int in_base = MODE == MODE_CONV3 ? (t / 3) * HW_ + (t % 3) : t * 4 * NPIXP;
@@ -360,9 +384,9 @@ static int launch_tw(const IgemmParams& p, hipStream_t s) {
     const long long tiles = (long long)((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.B;
     const long long nblk = tiles * ((p.Np + 63) / 64);
     if (nblk <= 0 || nblk > 0x7fffffff) return clamd_fail("igemm: grid out of range");
-    const int var = (MODE == MODE_CONV3 && EPI == EPI_NHWC) ? g_igemm_variant : 0;
+    const int var = (MODE == MODE_CONV3 && EPI == EPI_NHWC && !__is_same(T, split_t)) ? g_igemm_variant : 0;
 #define IGEMM_LAUNCH(TW_, V_) hipLaunchKernelGGL((igemm_kernel<T, MODE, EPI, TW_, V_>), dim3((unsigned)nblk), dim3(256), 0, s, p)
-    if constexpr (MODE == MODE_CONV3 && EPI == EPI_NHWC) {
+    if constexpr (MODE == MODE_CONV3 && EPI == EPI_NHWC && !__is_same(T, split_t)) {
         if (wide) { if (var == 1) IGEMM_LAUNCH(32, 1); else if (var == 2) IGEMM_LAUNCH(32, 2); else IGEMM_LAUNCH(32, 0); }
         else { if (var == 1) IGEMM_LAUNCH(16, 1); else if (var == 2) IGEMM_LAUNCH(16, 2); else IGEMM_LAUNCH(16, 0); }
     } else {
@@ -377,6 +401,7 @@ template <int MODE, int EPI>
 static int launch(const IgemmParams& p, int dtype, hipStream_t s) {
     if (dtype == CLAMD_BF16) return launch_tw<bf16_t, MODE, EPI>(p, s);
     if (dtype == CLAMD_F32) return launch_tw<float, MODE, EPI>(p, s);
+    if (dtype == CLAMD_SPLIT) return launch_tw<split_t, MODE, EPI>(p, s);
     return clamd_fail("igemm: bad dtype");
 }
 

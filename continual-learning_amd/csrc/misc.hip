@@ -86,7 +86,14 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackJob* __restrict__ j
             for (int t = 0; t < j.T; ++t) {
                 const long long d = t * j.dt + n * j.dn + k * j.dk;
                 if (j.dst_f32) ((float*)j.dst)[d] = tile[t][nn][kk];
-                else st1<T>((T*)j.dst + d, tile[t][nn][kk]);
+                else if constexpr (__is_same(T, split_t)) {
+                    // 4 bytes per element: every 16-channel chunk is stored as [16 x bf16 hi][16 x bf16 lo]
+                    const float x = tile[t][nn][kk];
+                    const uint16_t hi = f2bf(x);
+                    uint16_t* row = (uint16_t*)j.dst + 2 * (d - k);
+                    row[(k >> 4) * 32 + (k & 15)] = hi;
+                    row[(k >> 4) * 32 + 16 + (k & 15)] = f2bf(x - bf2f(hi));
+                } else st1<T>((T*)j.dst + d, tile[t][nn][kk]);
             }
         }
     }
@@ -311,6 +318,8 @@ int clamd_pack(const void* jobs_dev, int njobs, int total_blocks, int dtype, voi
         hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs_dev, njobs);
     else if (dtype == CLAMD_F32)
         hipLaunchKernelGGL(pack_kernel<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs_dev, njobs);
+    else if (dtype == CLAMD_SPLIT)
+        hipLaunchKernelGGL(pack_kernel<split_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs_dev, njobs);
     else return clamd_fail("pack: bad dtype");
     return clamd_check_launch("pack");
 }

@@ -33,15 +33,16 @@ struct WgradParams {
 };
 
 template <typename T, int MODE, int TW> struct WGeo {
+    static constexpr bool SPLIT = __is_same(T, split_t);   // fp32 storage, bf16 hi/lo LDS images, 3 MFMAs per product
     static constexpr int TH = (sizeof(T) == 2 ? 128 : 64) / (MODE == 2 ? 2 : 1) / TW;   // pixel tile rows (UP2: B tile is 4x)
     static constexpr int NT = MODE == WG_CONV3 ? 9 : (MODE == WG_UP2 ? 4 : 1);
     static constexpr int BW = MODE == WG_CONV3 ? TW + 2 : (MODE == WG_UP2 ? 2 * TW : TW);
     static constexpr int BH = MODE == WG_CONV3 ? TH + 2 : (MODE == WG_UP2 ? 2 * TH : TH);
-    static constexpr int STRIDE = sizeof(T) == 2 ? 192 : 256;                   // bytes per pixel row (64 channels + pad)
+    static constexpr int STRIDE = (sizeof(T) == 2 || SPLIT) ? 192 : 256;        // bytes per pixel row (64 channels + pad)
     static constexpr int APIX = TH * TW, BPIX = BH * BW;
     static constexpr int GPP = 64 * sizeof(T) / 16;                             // 16-B groups per pixel (8 or 16)
     static constexpr int NJA = (APIX * GPP + 255) / 256, NJB = (BPIX * GPP + 255) / 256;
-    static constexpr int BYTES = (APIX + BPIX) * STRIDE;
+    static constexpr int BYTES = (APIX + BPIX) * STRIDE * (SPLIT ? 2 : 1);
 };
 
 __device__ inline uint2 ds_tr16(const char* lds_addr) {
@@ -54,9 +55,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
     using G = WGeo<T, MODE, TW>;
     constexpr int TH = G::TH, NT = G::NT, BW = G::BW, STRIDE = G::STRIDE, GPP = G::GPP, NJA = G::NJA, NJB = G::NJB;
     constexpr int VEC = DT<T>::VEC;
+    constexpr bool SPLIT = G::SPLIT;
     __shared__ __attribute__((aligned(16))) char smem[G::BYTES];
     char* const sa = smem;
     char* const sb = smem + G::APIX * STRIDE;
+    constexpr int LO = (G::APIX + G::BPIX) * STRIDE;      // split: byte offset of the lo images (same layout as hi)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -118,12 +121,26 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int j = 0; j < NJA; ++j) {
             const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;
-            if (pix < G::APIX) *reinterpret_cast<uint4*>(sa + pix * STRIDE + g * 16) = ra[j];
+            if constexpr (!SPLIT) {
+                if (pix < G::APIX) *reinterpret_cast<uint4*>(sa + pix * STRIDE + g * 16) = ra[j];
+            } else if (pix < G::APIX) {
+                uint2 hi, lo;
+                split4(ra[j], hi, lo);
+                *reinterpret_cast<uint2*>(sa + pix * STRIDE + g * 8) = hi;
+                *reinterpret_cast<uint2*>(sa + LO + pix * STRIDE + g * 8) = lo;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NJB; ++j) {
             const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;
-            if (pix < G::BPIX) *reinterpret_cast<uint4*>(sb + pix * STRIDE + g * 16) = rb[j];
+            if constexpr (!SPLIT) {
+                if (pix < G::BPIX) *reinterpret_cast<uint4*>(sb + pix * STRIDE + g * 16) = rb[j];
+            } else if (pix < G::BPIX) {
+                uint2 hi, lo;
+                split4(rb[j], hi, lo);
+                *reinterpret_cast<uint2*>(sb + pix * STRIDE + g * 8) = hi;
+                *reinterpret_cast<uint2*>(sb + LO + pix * STRIDE + g * 8) = lo;
+            }
         }
     };
 
@@ -141,8 +158,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
         __syncthreads();
         if (tile + 1 < t_end) gload(tile + 1);
 
-        if constexpr (sizeof(T) == 2) {
-            // bf16: k-group = 16 consecutive pixels of one tile row.  Transposed reads: lane -> (gq = lane>>4,
+        if constexpr (sizeof(T) == 2 || SPLIT) {
+            // bf16 / split: k-group = 16 consecutive pixels of one tile row.  Transposed reads: lane -> (gq = lane>>4,
             // q = (lane>>2)&3, pp = lane&3); it supplies the address of pixel (8*(gq>>1) + q) [+4 for the second
             // read], channels 16*(gq&1) + 4*pp .. +3, and receives 4 pixels of channel 16*(gq&1) + (lane&15).
             const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
@@ -155,15 +172,25 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
                 for (int xs = 0; xs < TW; xs += 16) {
                     const char* ap = sa + (ty * TW + xs + kq) * STRIDE + a_ch;
                     const uint2 alo = ds_tr16(ap), ahi = ds_tr16(ap + 4 * STRIDE);
-                    const uint4 af = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
+                    const uint4 af = make_uint4(alo.x, alo.y, ahi.x, ahi.y);       // pixels 0-3 | 4-7 of this lane half
+                    uint4 af_lo = af;
+                    if constexpr (SPLIT) {
+                        const uint2 l0 = ds_tr16(ap + LO), l1 = ds_tr16(ap + LO + 4 * STRIDE);
+                        af_lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                    }
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const int step = MODE == WG_UP2 ? 2 : 1;
                         const char* bp = sb + (bpix(ty, xs, t) + step * kq) * STRIDE + b_ch;
                         const uint2 blo = ds_tr16(bp), bhi = ds_tr16(bp + 4 * step * STRIDE);
                         const uint4 bf = make_uint4(blo.x, blo.y, bhi.x, bhi.y);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af),
-                                                                         __builtin_bit_cast(bf16x8, bf), acc[t], 0, 0, 0);
+                        if constexpr (SPLIT) {
+                            const uint2 m0 = ds_tr16(bp + LO), m1 = ds_tr16(bp + LO + 4 * step * STRIDE);
+                            const uint4 bf_lo = make_uint4(m0.x, m0.y, m1.x, m1.y);
+                            mma_bf16(af_lo, bf, acc[t]);
+                            mma_bf16(af, bf_lo, acc[t]);
+                        }
+                        mma_bf16(af, bf, acc[t]);
                     }
                 }
         } else {
@@ -265,7 +292,7 @@ int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, fl
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("wgrad: empty problem");
     const int NT = mode == WG_CONV3 ? 9 : (mode == WG_UP2 ? 4 : 1);
     const int TW = W >= 32 ? 32 : 16;
-    const int TH = (dtype == CLAMD_BF16 ? 128 : 64) / (mode == WG_UP2 ? 2 : 1) / TW;
+    const int TH = (dtype == CLAMD_BF16 ? 128 : 64) / (mode == WG_UP2 ? 2 : 1) / TW;    // CLAMD_SPLIT tiles like fp32
     const int ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
     const int rt = (Rp + 63) / 64, ct = (Cp + 63) / 64;
     int nsplit = 512 / (rt * ct);
@@ -285,6 +312,9 @@ int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, fl
     } else if (dtype == CLAMD_F32) {
         e = mode == WG_CONV3 ? launch_wg<float, WG_CONV3>(p, s, grid)
           : mode == WG_PW    ? launch_wg<float, WG_PW>(p, s, grid) : launch_wg<float, WG_UP2>(p, s, grid);
+    } else if (dtype == CLAMD_SPLIT) {
+        e = mode == WG_CONV3 ? launch_wg<split_t, WG_CONV3>(p, s, grid)
+          : mode == WG_PW    ? launch_wg<split_t, WG_PW>(p, s, grid) : launch_wg<split_t, WG_UP2>(p, s, grid);
     } else return clamd_fail("wgrad: bad dtype");
     if (e) return e;
     ReduceParams rp{workspace, out, nsplit, NT, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p};

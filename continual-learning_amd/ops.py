@@ -8,7 +8,7 @@ import torch
 from . import _lib
 from ._lib import call, ptr
 
-TORCH_DT = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16}
+TORCH_DT = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.SPLIT: torch.float32}
 
 _PACK_DT = np.dtype({'names': ['src', 'dst', 'T', 'Np', 'Kp', 'N', 'K', 'st', 'sn', 'sk', 'dt', 'dn', 'dk',
                                'n_seg0', 'n_seg0p', 'k_seg0', 'k_seg0p', 'flip', 'dst_f32', 'block0', 'pad_'],

@@ -70,12 +70,14 @@ def _stage_modules(st):
 
 
 _DTYPES = {'fp32': (_lib.F32, torch.float32), 'float32': (_lib.F32, torch.float32),
-           'bf16': (_lib.BF16, torch.bfloat16), 'bfloat16': (_lib.BF16, torch.bfloat16)}
+           'bf16': (_lib.BF16, torch.bfloat16), 'bfloat16': (_lib.BF16, torch.bfloat16),
+           'bf16x3': (_lib.SPLIT, torch.float32)}
 
 
 class UNet(nn.Module):
-    """models/unet.py:40-92.  ``compute_dtype``: 'fp32' (exact-fp32 MFMA, the reference's arithmetic) or 'bf16'
-    (bf16 activations/packed weights, fp32 accumulation, fp32 master weights and BatchNorm statistics)."""
+    """models/unet.py:40-92.  ``compute_dtype``: 'fp32' (exact-fp32 MFMA, the reference's arithmetic), 'bf16'
+    (bf16 activations/packed weights, fp32 accumulation, fp32 master weights and BatchNorm statistics) or 'bf16x3'
+    (fp32 activations; every MFMA operand split into bf16 hi+lo, three bf16 MFMAs per product, fp32 accumulation)."""
 
     def __init__(self, num_classes, in_dim=3, conv_dim=64, compute_dtype='fp32'):
         super().__init__()

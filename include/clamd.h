@@ -15,7 +15,9 @@
  *     tensor may be a channel slice of a concat buffer (replaces torch.cat, models/unet.py:83-87).
  *     Physical channel counts (`*_p`) are padded to a power of two >= 32; padded channels hold zeros.
  *   - dtype: CLAMD_F32 computes with v_mfma_f32_32x32x2_f32 (exact fp32), CLAMD_BF16 stores activations and
- *     packed weights as bf16 and accumulates in fp32 (v_mfma_f32_32x32x16_bf16).
+ *     packed weights as bf16 and accumulates in fp32 (v_mfma_f32_32x32x16_bf16).  CLAMD_SPLIT ("bf16x3") stores
+ *     activations as fp32 and splits every MFMA operand into bf16 hi+lo on the fly: hi*hi + hi*lo + lo*hi with fp32
+ *     accumulation (~2^-17 relative product error); packed weights hold the hi/lo halves (4 bytes per element).
  */
 #ifndef CLAMD_H
 #define CLAMD_H
@@ -25,7 +27,7 @@
 extern "C" {
 #endif
 
-enum { CLAMD_F32 = 0, CLAMD_BF16 = 1 };
+enum { CLAMD_F32 = 0, CLAMD_BF16 = 1, CLAMD_SPLIT = 2 };
 enum { CLAMD_WGRAD_CONV3 = 0, CLAMD_WGRAD_PW = 1, CLAMD_WGRAD_UP2 = 2 };
 
 const char* clamd_last_error(void);
