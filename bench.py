@@ -40,7 +40,8 @@ def parse():
     ap.add_argument('--num-classes', type=int, default=21)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true', help='skip the per-launch HIP events')
-    ap.add_argument('--also', default='', help="second dtype measured after the main run and reported under 'also'")
+    ap.add_argument('--also', default='bf16x3,bf16',
+                    help="comma list of further dtypes measured after the main run and reported under 'also' ('' = none)")
     return ap.parse_args()
 
 
@@ -172,11 +173,20 @@ def main():
                                      'unit': 'TFLOP/s', 'frac': round(ach / PEAK[args.dtype], 4), 'launches': n,
                                      'avg_launch_ms': round(sec / n * 1e3, 4), 'ms_per_step': round(sec / 2 * 1e3, 3),
                                      'note': 'wgrad kernel + its split-K reduce kernel'}
-    if args.also and args.also != args.dtype:
-        dt2, loss2, _ = run(args, args.also, rank, world, device, timing=False)
+    for other in [d for d in args.also.split(',') if d and d != args.dtype]:
+        dt2, loss2, k2 = run(args, other, rank, world, device, timing=not args.no_kernel_timing)
         v2 = images / dt2
-        out['also'] = {'dtype': args.also, 'value': round(v2, 2), 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
-                       'step_frac_of_mfma_peak': round(v2 * flop_img / 1e12 / (PEAK[args.also] * world), 4)}
+        o = {'dtype': DTYPE_NAME[other], 'value': round(v2, 2), 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
+             'step_frac_of_mfma_peak': round(v2 * flop_img / 1e12 / (PEAK[other] * world), 4),
+             'final_loss': round(loss2, 5)}
+        sec, flops, n = k2.get('igemm_conv3x3', (0, 0, 0))
+        if sec > 0:
+            o['conv3x3_igemm_tflops'] = round(flops / sec / 1e12, 1)
+            o['conv3x3_igemm_frac_of_peak'] = round(flops / sec / 1e12 / PEAK[other], 4)
+        sec, flops, n = k2.get('wgrad_conv3x3', (0, 0, 0))
+        if sec > 0:
+            o['conv3x3_wgrad_tflops'] = round(flops / sec / 1e12, 1)
+        out.setdefault('also', []).append(o)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_cpu as TC                       # the checker timed as the reported CPU baseline
         xb = x_cpu = None

@@ -26,7 +26,7 @@ SIGNATURES = {
     'clamd_stat_replicas': (_I, []),
     'clamd_bn_bwd_nsums': (_I, []),
     'clamd_conv3x3': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    'clamd_conv1x1': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_conv1x1': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_conv1x1_logits': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_convT2x2_fwd': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_convT2x2_dgrad': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -40,6 +40,7 @@ SIGNATURES = {
     'clamd_channel_sum': (_I, [_P, _I, _P, _LL, _I, _I, _I, _P]),
     'clamd_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _D, _I, _P]),
     'clamd_nhwc_to_nchw': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'clamd_nchw_im2col3': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_pack': (_I, [_P, _I, _I, _I, _P]),
     'clamd_ce_workspace_bytes': (_SZ, []),
     'clamd_ce_fwd_bwd': (_I, [_P, _P, _P, _I, _I, _D, _D, _P, _P, _P, _SZ, _I, _I, _I, _I, _LL, _D, _P]),

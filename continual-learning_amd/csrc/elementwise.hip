@@ -318,6 +318,31 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* dst, int l
     }
 }
 
+// First-layer special case (enc1.0, models/unet.py:50: Cin = 3): the 3x3 neighbourhood is gathered ONCE into the
+// channel dimension, k = c*9 + (ky*3+kx) < 9*C <= Cp (zero outside the image and for k >= 9*C), so the conv becomes a
+// K=32 pointwise GEMM instead of a 9-tap conv over 3 channels padded to 32 (10x wasted MFMA work), and its weight
+// gradient a plain [Cout] x [27] pixel contraction whose output IS the [Cout][Cin][3][3] layout.
+template <typename T>
+__global__ void nchw_im2col3_kernel(const float* __restrict__ src, T* dst, int ldc, int B, int C, int H, int W, int Cp) {
+    const int G = Cp >> 3;
+    const long long hw = (long long)H * W, nitem = (long long)B * hw * G;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < nitem;
+         it += (long long)gridDim.x * blockDim.x) {
+        const long long pixb = it % (B * hw);
+        const int cg = (int)(it / (B * hw));
+        const long long b = pixb / hw, p = pixb % hw;
+        const int y = (int)(p / W), x = (int)(p % W);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = cg * 8 + j, c = k / 9, t = k - c * 9;
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            v[j] = (c < C && yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[(b * C + c) * hw + (long long)yy * W + xx] : 0.f;
+        }
+        Vec8<T>::store(dst + pixb * ldc + cg * 8, v);
+    }
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int ldc, float* dst, int B, int C, int H, int W) {
     const long long hw = (long long)H * W, n = (long long)B * C * hw;
@@ -435,6 +460,18 @@ int clamd_nchw_to_nhwc(const float* src, void* dst, int ldc, int B, int C, int H
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, g, b, 0, (hipStream_t)stream, src, (float*)dst, ldc, B, C, H, W, Cp, (float)mul);
     else return clamd_fail("nchw_to_nhwc: bad dtype");
     return clamd_check_launch("nchw_to_nhwc");
+}
+
+int clamd_nchw_im2col3(const float* src, void* dst, int ldc, int B, int C, int H, int W, int Cp, int dtype, void* stream) {
+    if (Cp % 8 || 9 * C > Cp) return clamd_fail("nchw_im2col3: needs 9*C <= Cp, Cp % 8 == 0");
+    const long long nitem = (long long)B * H * W * (Cp / 8);
+    dim3 g(ew_grid(nitem, 8192)), b(256);
+    if (dtype == CLAMD_BF16)
+        hipLaunchKernelGGL(nchw_im2col3_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, src, (bf16_t*)dst, ldc, B, C, H, W, Cp);
+    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT)
+        hipLaunchKernelGGL(nchw_im2col3_kernel<float>, g, b, 0, (hipStream_t)stream, src, (float*)dst, ldc, B, C, H, W, Cp);
+    else return clamd_fail("nchw_im2col3: bad dtype");
+    return clamd_check_launch("nchw_im2col3");
 }
 
 int clamd_nhwc_to_nchw(const void* src, int ldc, float* dst, int B, int C, int H, int W, int dtype, void* stream) {

@@ -433,9 +433,9 @@ int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* b
     return launch<MODE_CONV3, EPI_NHWC>(p, dtype, (hipStream_t)stream);
 }
 
-int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc, int B,
-                  int H, int W, int Cin_p, int Cout_p, int dtype, void* stream) {
-    IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, nullptr, B, H, W, Cin_p, Cout_p, 0, 0, 0};
+int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
+                  float* stats, int B, int H, int W, int Cin_p, int Cout_p, int relu, int dtype, void* stream) {
+    IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, 0};
     if (int e = check_common(p, "conv1x1")) return e;
     return launch<MODE_PW, EPI_NHWC>(p, dtype, (hipStream_t)stream);
 }

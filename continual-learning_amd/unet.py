@@ -197,9 +197,11 @@ class _Engine:
             u.cout, u.cout_p = cout, cpad(cout)
             u.xin, u.xin_ldc = xin, xin_ldc
             u.first = first_of_net
+            # first conv (Cin = 3): 3x3 neighbourhood folded into 27 (->32) channels, conv runs as a pointwise GEMM
+            u.im2col = first_of_net and 9 * u.cin <= cpad(9 * u.cin) == u.cin_p
             u.y = act(level, u.cout_p)
             u.gz = act(level, u.cout_p)
-            u.wf = torch.zeros(9 * u.cout_p * u.cin_p, dtype=T, device=dev)
+            u.wf = torch.zeros((1 if u.im2col else 9) * u.cout_p * u.cin_p, dtype=T, device=dev)
             u.wd = None if first_of_net else torch.zeros(9 * u.cin_p * u.cout_p, dtype=T, device=dev)
             u.bias_p = torch.zeros(u.cout_p, dtype=torch.float32, device=dev)
             u.vec = torch.zeros(7, u.cout_p, dtype=torch.float32, device=dev)   # scale, shift, mean, istd, k0, k1, k2
@@ -294,7 +296,10 @@ class _Engine:
     def _build_pack_table(self):
         tab = PackTable()
         for u in self.convs:
-            tab.conv3x3(u.w, u.wf, u.wd, u.cin_segs, u.cout)
+            if u.im2col:
+                tab.head(u.w, u.wf, None, 9 * u.cin, u.cout)     # [Cout][Cin*9] is already the (c*9 + tap) K order
+            else:
+                tab.conv3x3(u.w, u.wf, u.wd, u.cin_segs, u.cout)
             tab.vector(u.b, u.bias_p, u.cout)
         for s in self.stages:
             t = s.get('tail')
@@ -332,8 +337,12 @@ class _Engine:
         if training:
             self.stat_arena.zero_()
         self.pack_table.run(dc, s)
-        call('clamd_nchw_to_nhwc', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
-             self.x_in.shape[-1], 1.0, dc, s)
+        if self.convs[0].im2col:
+            call('clamd_nchw_im2col3', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
+                 self.x_in.shape[-1], dc, s)
+        else:
+            call('clamd_nchw_to_nhwc', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
+                 self.x_in.shape[-1], 1.0, dc, s)
         for st in self.stages:
             for u in st['convs']:
                 self._conv_fwd(u, training, s)
@@ -355,9 +364,13 @@ class _Engine:
     def _conv_fwd(self, u, training, s):
         B, dc = self.B, self.dcode
         v = u.vec
-        _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout,
-               'clamd_conv3x3', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
-               ptr(u.stats) if training else None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, u.m_fastest, dc, s)
+        if u.im2col:
+            call('clamd_conv1x1', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
+                 ptr(u.stats) if training else None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
+        else:
+            _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout,
+                   'clamd_conv3x3', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
+                   ptr(u.stats) if training else None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, u.m_fastest, dc, s)
         call('clamd_bn_finalize', ptr(u.stats) if training else None, ptr(u.gamma), ptr(u.beta), ptr(u.rm), ptr(u.rv),
              ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), u.cout_p, u.cout, float(B * u.h * u.w_), BN_MOMENTUM, BN_EPS, s)
         call('clamd_bn_apply', ptr(u.y), u.cout_p, ptr(v[0]), ptr(v[1]), ptr(u.out), u.out_ldc,
@@ -390,8 +403,8 @@ class _Engine:
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cout_p, t.cin_p, t.cout, t.cin,
                          t.cout, t.cout_p, t.cin, t.cin_p, dc, s)
                     call('clamd_channel_sum', ptr(self.dl), self.Kp, g[t.keys[1]], B * h * w, self.Kp, t.cout, dc, s)
-                    call('clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], B, h, w,
-                         t.cout_p, t.cin_p, dc, s)
+                    call('clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], None,
+                         B, h, w, t.cout_p, t.cin_p, 0, dc, s)
                 else:
                     call('clamd_wgrad', _lib.WGRAD_UP2, ptr(t.x), t.x.shape[-1], ptr(t.gy_slice), t.y_ldc, ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cin_p, t.cout_p, t.cin, t.cout,
@@ -424,6 +437,10 @@ class _Engine:
         else:
             c_seg0, c_seg0p = u.cin, u.cin_p
         flops = 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout
+        if u.im2col:
+            call('clamd_wgrad', _lib.WGRAD_PW, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
+                 g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, 9 * u.cin, u.cout, u.cout_p, 9 * u.cin, u.cin_p, dc, s)
+            return
         _timed('wgrad_conv3x3', flops,
                'clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
                g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, dc, s)

@@ -49,9 +49,11 @@ int clamd_bn_bwd_nsums(void);
 int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
                   float* stats, int B, int H, int W, int Cin_p, int Cout_p, int relu, int m_fastest, int dtype,
                   void* stream);
-/* 1x1 convolution, NHWC output (data gradient of the head, unet.py:72). w_packed [1][Cout_p][Cin_p]. */
-int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc, int B,
-                  int H, int W, int Cin_p, int Cout_p, int dtype, void* stream);
+/* 1x1 convolution, NHWC output, same epilogue options as clamd_conv3x3 (bias, ReLU, BN statistics).  Used for the
+ * data gradient of the head (unet.py:72) and, on an im2col'ed input (clamd_nchw_im2col3), for the first conv
+ * enc1.0 (unet.py:50, Cin = 3).  w_packed [1][Cout_p][Cin_p]. */
+int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
+                  float* stats, int B, int H, int W, int Cin_p, int Cout_p, int relu, int dtype, void* stream);
 /* the head nn.Conv2d(conv_dim, num_classes, k1) (unet.py:72): logits written as fp32 NCHW [B,num_classes,H,W]. */
 int clamd_conv1x1_logits(const void* x, int x_ldc, const void* w_packed, const float* bias, float* logits_nchw,
                          int B, int H, int W, int Cin_p, int Cout_p, int num_classes, int dtype, void* stream);
@@ -103,6 +105,8 @@ int clamd_channel_sum(const void* g, int ldc, float* out, long long npix, int Cp
 int clamd_nchw_to_nhwc(const float* src, void* dst, int ldc, int B, int C, int H, int W, int Cp, double mul,
                        int dtype, void* stream);
 int clamd_nhwc_to_nchw(const void* src, int ldc, float* dst, int B, int C, int H, int W, int dtype, void* stream);
+/* NCHW fp32 image -> NHWC with the 3x3 neighbourhood folded into channels: dst[p, c*9 + ky*3 + kx] (9*C <= Cp). */
+int clamd_nchw_im2col3(const float* src, void* dst, int ldc, int B, int C, int H, int W, int Cp, int dtype, void* stream);
 
 /* ---- parameters, loss, optimiser, metrics (misc.hip) ---------------------------------------------------------
  * clamd_pack: one fused launch re-packing every fp32 master parameter into the layouts above (job table built by

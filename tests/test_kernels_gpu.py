@@ -290,7 +290,7 @@ def test_head_fwd_bwd(C, name, dcode, shape):
     g = rb(rnd(rng, B, K, H, W), dcode)
     gt = C.ops.to_nhwc(dev(g), dcode)
     gx = torch.zeros(B, H, W, cin_p, dtype=T, device='cuda')
-    lib.call('clamd_conv1x1', ptr(gt), kp, ptr(wd), None, ptr(gx), cin_p, B, H, W, kp, cin_p, dcode, s)
+    lib.call('clamd_conv1x1', ptr(gt), kp, ptr(wd), None, ptr(gx), cin_p, None, B, H, W, kp, cin_p, 0, dcode, s)
     wsb = lib.load().clamd_wgrad_workspace_bytes(1, B, H, W, kp, cin_p, dcode)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     gw = torch.zeros(K, cin, 1, 1, device='cuda')
@@ -298,6 +298,44 @@ def test_head_fwd_bwd(C, name, dcode, shape):
     sync()
     rgx, rgw, _ = O.conv1x1_bwd(x, w, g)
     assert rel_l2(C.ops.from_nhwc(gx, cin, dcode).cpu().numpy(), rgx) < TOL[dcode]
+    assert rel_l2(gw.cpu().numpy(), rgw) < (6e-5 if dcode == 2 else 2e-5)
+
+
+@pytest.mark.parametrize('name,dcode', DT)
+@pytest.mark.parametrize('shape', [(2, 3, 64, 16, 48), (1, 1, 5, 32, 32), (2, 3, 7, 8, 12)])
+def test_first_layer_im2col_path(C, name, dcode, shape):
+    """enc1.0 (Cin = 3, models/unet.py:50) as im2col + pointwise GEMM: forward (+ReLU, BN stats) and weight gradient
+    against the oracle's 3x3 conv."""
+    B, cin, cout, H, W = shape
+    rng = np.random.default_rng(21)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    T = C.ops.TORCH_DT[dcode]
+    x = rnd(rng, B, cin, H, W)
+    w = rb(rnd(rng, cout, cin, 3, 3) * (1.0 / np.sqrt(9 * cin)), dcode)
+    b = rnd(rng, cout)
+    kp, cout_p = C.ops.cpad(9 * cin), C.ops.cpad(cout)
+    xt_ = dev(x)
+    xcol = torch.empty(B, H, W, kp, dtype=T, device='cuda')
+    lib.call('clamd_nchw_im2col3', ptr(xt_), ptr(xcol), kp, B, cin, H, W, kp, dcode, s)
+    wt, bt = dev(w), dev(b)
+    wf = torch.zeros(cout_p * kp, dtype=T, device='cuda'); bp = torch.zeros(cout_p, device='cuda')
+    tab = C.ops.PackTable(); tab.head(wt, wf, None, 9 * cin, cout); tab.vector(bt, bp, cout); tab.finalize('cuda').run(dcode)
+    y = torch.zeros(B, H, W, cout_p, dtype=T, device='cuda')
+    stats = torch.zeros(lib.load().clamd_stat_replicas(), 2, cout_p, device='cuda')
+    lib.call('clamd_conv1x1', ptr(xcol), kp, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), B, H, W, kp, cout_p, 1, dcode, s)
+    sync()
+    xr = rb(x, dcode)                                    # the gather rounds the image to the compute dtype
+    ref = O.relu_fwd(O.conv3x3_fwd(xr, w, b))
+    assert rel_l2(C.ops.from_nhwc(y, cout, dcode).cpu().numpy(), ref) < TOL[dcode]
+    np.testing.assert_allclose(stats.sum(0).cpu().numpy()[0, :cout], ref.sum((0, 2, 3)), rtol=3e-3, atol=1e-2)
+    gz = rb(rnd(rng, B, cout, H, W), dcode)
+    gzt = C.ops.to_nhwc(dev(gz), dcode)
+    wsb = lib.load().clamd_wgrad_workspace_bytes(1, B, H, W, cout_p, kp, dcode)
+    ws = torch.empty(wsb // 4 + 4, device='cuda'); gw = torch.zeros(cout, cin, 3, 3, device='cuda')
+    lib.call('clamd_wgrad', 1, ptr(gzt), cout_p, ptr(xcol), kp, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, kp, cout, 9 * cin,
+             cout, cout_p, 9 * cin, kp, dcode, s)
+    sync()
+    _, rgw, _ = O.conv3x3_bwd(xr, w, gz, need_gx=False)
     assert rel_l2(gw.cpu().numpy(), rgw) < (6e-5 if dcode == 2 else 2e-5)
 
 
