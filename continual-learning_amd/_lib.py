@@ -25,11 +25,11 @@ SIGNATURES = {
     'clamd_pack_tile': (_I, []),
     'clamd_stat_replicas': (_I, []),
     'clamd_bn_bwd_nsums': (_I, []),
-    'clamd_conv3x3': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    'clamd_conv1x1': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_conv3x3': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_conv1x1': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_conv1x1_logits': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_convT2x2_fwd': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    'clamd_convT2x2_dgrad': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_convT2x2_dgrad': (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_wgrad_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
     'clamd_wgrad': (_I, [_I, _P, _I, _P, _I, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_bn_finalize': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _P]),

@@ -38,6 +38,11 @@ struct IgemmParams {
     int relu;
     int aux;                // EPI_UP2: convT Cout_p ; EPI_NCHW: logical classes ; MODE_UP2: channels per (dy,dx)
     int m_fastest;
+    // EPI_NHWC only: when this launch produces the gradient g w.r.t. a BatchNorm output, accumulate the five
+    // per-channel sums of the fused ReLU/BN backward (see bn_bwd_reduce_kernel) right here in the epilogue:
+    // bn_y = that unit's saved post-ReLU activation [B,H,W,Np] (dense pitch Np), bn_sums = [STAT_REPLICAS][5][Np].
+    const void* bn_y;
+    float* bn_sums;
 };
 
 template <int MODE, int TW> struct Geo {
@@ -335,6 +340,12 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
         }
         T* out = (T*)p.y;
         float* wbuf = ebuf + wave * 32 * 68;
+        float bs[5][8];
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bs[k][j] = 0.f;
+        const bool do_bn = EPI == EPI_NHWC && p.bn_y != nullptr;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             __syncthreads();
@@ -363,6 +374,46 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
                         off = (((long long)b * 2 * p.H + 2 * yy + (q >> 1)) * 2 * p.W + 2 * xx + (q & 1)) * p.y_ldc + co;
                     }
                     Vec8<T>::store(out + off, v);
+                    if constexpr (EPI == EPI_NHWC) {
+                        if (do_bn) {
+                            float yv[8];
+                            Vec8<T>::load((const T*)p.bn_y + (((long long)b * p.H + yy) * p.W + xx) * p.Np + n, yv);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float pos = yv[j] > 0.f ? 1.f : 0.f;
+                                bs[0][j] += v[j]; bs[1][j] += v[j] * yv[j]; bs[2][j] += v[j] * pos;
+                                bs[3][j] += pos; bs[4][j] += yv[j];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (EPI == EPI_NHWC) {
+            if (do_bn) {
+                // lanes sharing (lane & 7) own the same 8 channels: fold the 8 row-lanes, then the 4 waves through LDS
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float t = bs[k][j];
+                        t += __shfl_xor(t, 8); t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+                        bs[k][j] = t;
+                    }
+                __syncthreads();                       // transposition buffer is free again
+                if (lane < 8) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ebuf[(wave * 5 + k) * 64 + lane * 8 + j] = bs[k][j];
+                }
+                __syncthreads();
+                for (int i = tid; i < 5 * 64; i += 256) {
+                    const int k = i >> 6, c = i & 63;
+                    const float t = ebuf[(0 * 5 + k) * 64 + c] + ebuf[(1 * 5 + k) * 64 + c] + ebuf[(2 * 5 + k) * 64 + c] +
+                                    ebuf[(3 * 5 + k) * 64 + c];
+                    if (n0 + c < p.Np)
+                        atomicAdd(p.bn_sums + ((size_t)(blockIdx.x % STAT_REPLICAS) * 5 + k) * p.Np + n0 + c, t);
                 }
             }
         }
@@ -426,23 +477,24 @@ int clamd_set_tuning(const char* key, int value) {
 }
 
 int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
-                  float* stats, int B, int H, int W, int Cin_p, int Cout_p, int relu, int m_fastest, int dtype,
-                  void* stream) {
-    IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, m_fastest};
+                  float* stats, const void* bn_y, float* bn_sums, int B, int H, int W, int Cin_p, int Cout_p, int relu,
+                  int m_fastest, int dtype, void* stream) {
+    IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, m_fastest, bn_y, bn_sums};
     if (int e = check_common(p, "conv3x3")) return e;
     return launch<MODE_CONV3, EPI_NHWC>(p, dtype, (hipStream_t)stream);
 }
 
 int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
-                  float* stats, int B, int H, int W, int Cin_p, int Cout_p, int relu, int dtype, void* stream) {
-    IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, 0};
+                  float* stats, const void* bn_y, float* bn_sums, int B, int H, int W, int Cin_p, int Cout_p, int relu,
+                  int dtype, void* stream) {
+    IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, 0, bn_y, bn_sums};
     if (int e = check_common(p, "conv1x1")) return e;
     return launch<MODE_PW, EPI_NHWC>(p, dtype, (hipStream_t)stream);
 }
 
 int clamd_conv1x1_logits(const void* x, int x_ldc, const void* w_packed, const float* bias, float* logits_nchw,
                          int B, int H, int W, int Cin_p, int Cout_p, int num_classes, int dtype, void* stream) {
-    IgemmParams p{x, x_ldc, w_packed, bias, logits_nchw, 8, nullptr, B, H, W, Cin_p, Cout_p, 0, num_classes, 0};
+    IgemmParams p{x, x_ldc, w_packed, bias, logits_nchw, 8, nullptr, B, H, W, Cin_p, Cout_p, 0, num_classes, 0, nullptr, nullptr};
     if (int e = check_common(p, "conv1x1_logits")) return e;
     if (num_classes > Cout_p) return clamd_fail("conv1x1_logits: num_classes > padded Cout");
     return launch<MODE_PW, EPI_NCHW>(p, dtype, (hipStream_t)stream);
@@ -450,14 +502,14 @@ int clamd_conv1x1_logits(const void* x, int x_ldc, const void* w_packed, const f
 
 int clamd_convT2x2_fwd(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc, int B,
                        int h, int w, int Cin_p, int Cout_p, int dtype, void* stream) {
-    IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, nullptr, B, h, w, Cin_p, 4 * Cout_p, 0, Cout_p, 0};
+    IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, nullptr, B, h, w, Cin_p, 4 * Cout_p, 0, Cout_p, 0, nullptr, nullptr};
     if (int e = check_common(p, "convT_fwd")) return e;
     return launch<MODE_PW, EPI_UP2>(p, dtype, (hipStream_t)stream);
 }
 
-int clamd_convT2x2_dgrad(const void* gy, int gy_ldc, const void* w_packed, void* gx, int gx_ldc, int B, int h, int w,
-                         int Cin_p, int Cout_p, int dtype, void* stream) {
-    IgemmParams p{gy, gy_ldc, w_packed, nullptr, gx, gx_ldc, nullptr, B, h, w, 4 * Cout_p, Cin_p, 0, Cout_p, 0};
+int clamd_convT2x2_dgrad(const void* gy, int gy_ldc, const void* w_packed, void* gx, int gx_ldc, const void* bn_y,
+                         float* bn_sums, int B, int h, int w, int Cin_p, int Cout_p, int dtype, void* stream) {
+    IgemmParams p{gy, gy_ldc, w_packed, nullptr, gx, gx_ldc, nullptr, B, h, w, 4 * Cout_p, Cin_p, 0, Cout_p, 0, bn_y, bn_sums};
     if (int e = check_common(p, "up2_dgrad")) return e;
     return launch<MODE_UP2, EPI_NHWC>(p, dtype, (hipStream_t)stream);
 }

@@ -226,6 +226,9 @@ class _Engine:
             b.g_in = act(k, cpad(cout))                             # grad w.r.t. ua
             a.g_src = (b.g_in, b.g_in.shape[-1], None)               # where conv a's BN-output gradient comes from
             b.g_src = (self.gcat[k], self.gcat[k].shape[-1], self.gpool[k])
+            # b's data-gradient kernel writes the gradient w.r.t. a's BatchNorm output: it also accumulates a's BN-bwd sums
+            b.consumer, a.fused_reduce = a, True
+            a.consumer, b.fused_reduce = None, False                # a's dgrad feeds a pooled / concat gradient: separate reduce
             self.stages.append(dict(kind='enc', convs=(a, b)))
             prev = (self.pool[k], self.pool[k].shape[-1], [(cout, cpad(cout))])
         spec = [(8 * d, 16 * d, 8 * d), (16 * d, 8 * d, 4 * d), (8 * d, 4 * d, 2 * d), (4 * d, 2 * d, d), (2 * d, d, None)]
@@ -248,6 +251,8 @@ class _Engine:
             g_ub = act(level, cpad(mid))
             a.g_src = (b.g_in, b.g_in.shape[-1], None)
             b.g_src = (g_ub, g_ub.shape[-1], None)
+            b.consumer, a.fused_reduce = a, True
+            a.consumer, b.fused_reduce = None, True                 # b's gradient comes from the tail's data-gradient kernel
             kind, ti, tcin, tcout = st['tail']
             tail = _Conv()
             tail.kind = kind
@@ -255,6 +260,7 @@ class _Engine:
             tail.keys = (f'{pre}.{ti}.weight', f'{pre}.{ti}.bias')
             tail.cin, tail.cin_p, tail.cout = tcin, cpad(tcin), tcout
             tail.x, tail.g_x, tail.level = ub, g_ub, level
+            tail.consumer = b
             if kind == 'convT':
                 tail.cout_p = cpad(tcout)
                 tail.wf = torch.zeros(4 * tail.cout_p * tail.cin_p, dtype=T, device=dev)
@@ -330,6 +336,7 @@ class _Engine:
     def forward(self, x, params):
         m = self.model
         training = m.training
+        self.fwd_training = training
         self.generation += 1
         self._check_ptrs(params)
         s = _lib.stream_ptr()
@@ -366,11 +373,11 @@ class _Engine:
         v = u.vec
         if u.im2col:
             call('clamd_conv1x1', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
-                 ptr(u.stats) if training else None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
+                 ptr(u.stats) if training else None, None, None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
         else:
             _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout,
                    'clamd_conv3x3', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
-                   ptr(u.stats) if training else None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, u.m_fastest, dc, s)
+                   ptr(u.stats) if training else None, None, None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, u.m_fastest, dc, s)
         call('clamd_bn_finalize', ptr(u.stats) if training else None, ptr(u.gamma), ptr(u.beta), ptr(u.rm), ptr(u.rv),
              ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), u.cout_p, u.cout, float(B * u.h * u.w_), BN_MOMENTUM, BN_EPS, s)
         call('clamd_bn_apply', ptr(u.y), u.cout_p, ptr(v[0]), ptr(v[1]), ptr(u.out), u.out_ldc,
@@ -381,6 +388,8 @@ class _Engine:
         m = self.model
         s = _lib.stream_ptr()
         B, H, W, dc = self.B, self.H, self.W, self.dcode
+        if not self.fwd_training:
+            raise RuntimeError('UNet.backward after an eval-mode forward is not supported (BatchNorm backward uses batch statistics)')
         p0 = next(iter(m.parameters()))
         if p0.grad is not None:
             lo = self.gflat.data_ptr()
@@ -404,15 +413,15 @@ class _Engine:
                          t.cout, t.cout_p, t.cin, t.cin_p, dc, s)
                     call('clamd_channel_sum', ptr(self.dl), self.Kp, g[t.keys[1]], B * h * w, self.Kp, t.cout, dc, s)
                     call('clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], None,
-                         B, h, w, t.cout_p, t.cin_p, 0, dc, s)
+                         ptr(t.consumer.y), ptr(t.consumer.sums), B, h, w, t.cout_p, t.cin_p, 0, dc, s)
                 else:
                     call('clamd_wgrad', _lib.WGRAD_UP2, ptr(t.x), t.x.shape[-1], ptr(t.gy_slice), t.y_ldc, ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cin_p, t.cout_p, t.cin, t.cout,
                          t.cin, t.cin_p, t.cout, t.cout_p, dc, s)
                     call('clamd_channel_sum', ptr(t.gy_slice), t.y_ldc, g[t.keys[1]], B * 4 * h * w, t.cout_p,
                          t.cout, dc, s)
-                    call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1], B, h, w,
-                         t.cin_p, t.cout_p, dc, s)
+                    call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
+                         ptr(t.consumer.y), ptr(t.consumer.sums), B, h, w, t.cin_p, t.cout_p, dc, s)
             for u in reversed(st['convs']):
                 self._conv_bwd(u, s)
             if sync is not None:
@@ -426,8 +435,9 @@ class _Engine:
         ga, ga_ldc, gp = u.g_src
         count = float(B * u.h * u.w_)
         g = self._gp
-        call('clamd_bn_bwd_reduce', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.cout_p,
-             ptr(v[0]), ptr(v[1]), ptr(u.sums), B, u.h, u.w_, u.cout_p, dc, s)
+        if not u.fused_reduce:     # otherwise the five sums were accumulated by the epilogue of the kernel that wrote `ga`
+            call('clamd_bn_bwd_reduce', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.cout_p,
+                 ptr(v[0]), ptr(v[1]), ptr(u.sums), B, u.h, u.w_, u.cout_p, dc, s)
         call('clamd_bn_bwd_finalize', ptr(u.sums), ptr(u.gamma), ptr(v[2]), ptr(v[3]), ptr(v[4]), g[u.keys[2]],
              g[u.keys[3]], g[u.keys[1]], u.cout_p, u.cout, count, s)
         call('clamd_bn_bwd_apply', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.cout_p,
@@ -447,4 +457,6 @@ class _Engine:
         if u.g_in is not None:
             _timed('igemm_conv3x3', flops,
                    'clamd_conv3x3', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
+                   ptr(u.consumer.y) if u.consumer is not None else None,
+                   ptr(u.consumer.sums) if u.consumer is not None else None,
                    B, u.h, u.w_, u.cout_p, u.cin_p, 0, 1 if 9 * u.cin_p > B * u.h * u.w_ else 0, dc, s)

@@ -45,15 +45,19 @@ int clamd_bn_bwd_nsums(void);
  *   y = relu?(conv3x3(x, w) + bias), and (if stats != NULL) per-channel sum / sum-of-squares of y accumulated
  *   into stats[replica][2][Cout_p] for the following nn.BatchNorm2d (unet.py:15,...).  The same entry point run
  *   on the flipped/transposed packing computes the data gradient of that conv (loss.backward(), trainer.py:175).
- *   w_packed: [9][Cout_p][Cin_p] compute dtype, Cin innermost (see clamd_pack).  m_fastest: block order hint. */
+ *   w_packed: [9][Cout_p][Cin_p] compute dtype, Cin innermost (see clamd_pack).  m_fastest: block order hint.
+ *   bn_y/bn_sums (optional, data-gradient launches): when y of THIS launch is the gradient w.r.t. a BatchNorm output,
+ *   also accumulate the five per-channel sums of clamd_bn_bwd_reduce (bn_y = that unit's saved activation
+ *   [B,H,W,Cout_p], bn_sums = [replica][5][Cout_p]) in the epilogue, so the separate reduce pass is not needed. */
 int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
-                  float* stats, int B, int H, int W, int Cin_p, int Cout_p, int relu, int m_fastest, int dtype,
-                  void* stream);
+                  float* stats, const void* bn_y, float* bn_sums, int B, int H, int W, int Cin_p, int Cout_p, int relu,
+                  int m_fastest, int dtype, void* stream);
 /* 1x1 convolution, NHWC output, same epilogue options as clamd_conv3x3 (bias, ReLU, BN statistics).  Used for the
  * data gradient of the head (unet.py:72) and, on an im2col'ed input (clamd_nchw_im2col3), for the first conv
  * enc1.0 (unet.py:50, Cin = 3).  w_packed [1][Cout_p][Cin_p]. */
 int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
-                  float* stats, int B, int H, int W, int Cin_p, int Cout_p, int relu, int dtype, void* stream);
+                  float* stats, const void* bn_y, float* bn_sums, int B, int H, int W, int Cin_p, int Cout_p, int relu,
+                  int dtype, void* stream);
 /* the head nn.Conv2d(conv_dim, num_classes, k1) (unet.py:72): logits written as fp32 NCHW [B,num_classes,H,W]. */
 int clamd_conv1x1_logits(const void* x, int x_ldc, const void* w_packed, const float* bias, float* logits_nchw,
                          int B, int H, int W, int Cin_p, int Cout_p, int num_classes, int dtype, void* stream);
@@ -62,8 +66,8 @@ int clamd_conv1x1_logits(const void* x, int x_ldc, const void* w_packed, const f
 int clamd_convT2x2_fwd(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc, int B,
                        int h, int w, int Cin_p, int Cout_p, int dtype, void* stream);
 /* data gradient of the above: gy [B,2h,2w,...] -> gx [B,h,w,Cin_p].  w_packed [Cin_p][4][Cout_p]. */
-int clamd_convT2x2_dgrad(const void* gy, int gy_ldc, const void* w_packed, void* gx, int gx_ldc, int B, int h, int w,
-                         int Cin_p, int Cout_p, int dtype, void* stream);
+int clamd_convT2x2_dgrad(const void* gy, int gy_ldc, const void* w_packed, void* gx, int gx_ldc, const void* bn_y,
+                         float* bn_sums, int B, int h, int w, int Cin_p, int Cout_p, int dtype, void* stream);
 
 /* ---- weight gradients (wgrad.hip) --------------------------------------------------------------------------
  * out[r][c][t] = sum_pixels a[p, r] * b[nbr_t(p), c]  written in the parameter's own fp32 layout:

@@ -183,7 +183,7 @@ def test_conv3x3_fwd_relu_stats(C, name, dcode, shape, m_fastest):
     y = torch.full((B, H, W, cout_p), 7.0, dtype=T, device='cuda')
     R = lib.load().clamd_stat_replicas()
     stats = torch.zeros(R, 2, cout_p, device='cuda')
-    lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), B, H, W, cin_p, cout_p, 1,
+    lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, B, H, W, cin_p, cout_p, 1,
              m_fastest, dcode, s)
     sync()
     ref = O.relu_fwd(O.conv3x3_fwd(x, w, b))
@@ -207,7 +207,12 @@ def test_conv3x3_dgrad_and_wgrad(C, name, dcode, shape):
     lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
     T = C.ops.TORCH_DT[dcode]
     gx = torch.zeros(B, H, W, cin_p, dtype=T, device='cuda')
-    lib.call('clamd_conv3x3', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, B, H, W, cout_p, cin_p, 0, 0, dcode, s)
+    # the data-gradient launch also accumulates the 5 per-channel sums of the downstream ReLU/BN backward (fused epilogue)
+    pm_ = phys_map(segs)
+    yb = np.maximum(rnd(rng, B, cin, H, W), 0)
+    ybt = nhwc_with_segs(C, rb(yb, dcode), segs, dcode)
+    bsums = torch.zeros(lib.load().clamd_stat_replicas(), 5, cin_p, device='cuda')
+    lib.call('clamd_conv3x3', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, ptr(ybt), ptr(bsums), B, H, W, cout_p, cin_p, 0, 0, dcode, s)
     wsb = lib.load().clamd_wgrad_workspace_bytes(0, B, H, W, cout_p, cin_p, dcode)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
@@ -220,6 +225,13 @@ def test_conv3x3_dgrad_and_wgrad(C, name, dcode, shape):
     got_gx = gx.float().cpu().numpy().transpose(0, 3, 1, 2)[:, [p for p, l in enumerate(pm) if l >= 0]]
     assert rel_l2(got_gx, rgx) < TOL[dcode]
     assert rel_l2(gw.cpu().numpy(), rgw) < (6e-5 if dcode == 2 else 2e-5)   # wgrad output is fp32 in every path
+    ybr = rb(yb, dcode)
+    pos = (ybr > 0).astype(np.float32)
+    want = np.stack([rgx.sum((0, 2, 3)), (rgx * ybr).sum((0, 2, 3)), (rgx * pos).sum((0, 2, 3)), pos.sum((0, 2, 3)), ybr.sum((0, 2, 3))])
+    got = bsums.sum(0).cpu().numpy()[:, [p for p, l in enumerate(pm_) if l >= 0]]
+    scale = np.abs(want).max(1, keepdims=True) + 1e-6
+    assert np.abs(got - want).max() <= (2e-2 if dcode == 1 else 1e-3) * scale.max(), np.abs(got - want).max()
+    np.testing.assert_allclose(got[3:], want[3:], rtol=1e-5, atol=1e-3)
 
 
 @pytest.mark.parametrize('name,dcode', DT)
@@ -252,7 +264,7 @@ def test_convT2x2_fwd_dgrad_wgrad(C, name, dcode, shape):
     gcat[..., cout_p:cout_p + cout] = dev(gy.transpose(0, 2, 3, 1)).to(T)
     gsl = gcat[..., cout_p:]
     gx = torch.zeros(B, h, w_, cin_p, dtype=T, device='cuda')
-    lib.call('clamd_convT2x2_dgrad', ptr(gsl), 2 * cout_p, ptr(wd), ptr(gx), cin_p, B, h, w_, cin_p, cout_p, dcode, s)
+    lib.call('clamd_convT2x2_dgrad', ptr(gsl), 2 * cout_p, ptr(wd), ptr(gx), cin_p, None, None, B, h, w_, cin_p, cout_p, dcode, s)
     wsb = lib.load().clamd_wgrad_workspace_bytes(2, B, h, w_, cin_p, cout_p, dcode)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     gw = torch.zeros(cin, cout, 2, 2, device='cuda')
@@ -290,7 +302,7 @@ def test_head_fwd_bwd(C, name, dcode, shape):
     g = rb(rnd(rng, B, K, H, W), dcode)
     gt = C.ops.to_nhwc(dev(g), dcode)
     gx = torch.zeros(B, H, W, cin_p, dtype=T, device='cuda')
-    lib.call('clamd_conv1x1', ptr(gt), kp, ptr(wd), None, ptr(gx), cin_p, None, B, H, W, kp, cin_p, 0, dcode, s)
+    lib.call('clamd_conv1x1', ptr(gt), kp, ptr(wd), None, ptr(gx), cin_p, None, None, None, B, H, W, kp, cin_p, 0, dcode, s)
     wsb = lib.load().clamd_wgrad_workspace_bytes(1, B, H, W, kp, cin_p, dcode)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     gw = torch.zeros(K, cin, 1, 1, device='cuda')
@@ -322,7 +334,7 @@ def test_first_layer_im2col_path(C, name, dcode, shape):
     tab = C.ops.PackTable(); tab.head(wt, wf, None, 9 * cin, cout); tab.vector(bt, bp, cout); tab.finalize('cuda').run(dcode)
     y = torch.zeros(B, H, W, cout_p, dtype=T, device='cuda')
     stats = torch.zeros(lib.load().clamd_stat_replicas(), 2, cout_p, device='cuda')
-    lib.call('clamd_conv1x1', ptr(xcol), kp, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), B, H, W, kp, cout_p, 1, dcode, s)
+    lib.call('clamd_conv1x1', ptr(xcol), kp, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, B, H, W, kp, cout_p, 1, dcode, s)
     sync()
     xr = rb(x, dcode)                                    # the gather rounds the image to the compute dtype
     ref = O.relu_fwd(O.conv3x3_fwd(xr, w, b))

@@ -248,8 +248,8 @@ def test_adjoint_identities_full_size(C):
     tab = C.ops.PackTable(); tab.conv3x3(w, wf, wd, [(Cc, Cc)], Cc); tab.finalize('cuda').run(0)
     s = lib.stream_ptr()
     y = torch.empty_like(x); gx = torch.empty_like(x); gw = torch.empty_like(w)
-    lib.call('clamd_conv3x3', ptr(x), Cc, ptr(wf), None, ptr(y), Cc, None, B, H, W, Cc, Cc, 0, 0, 0, s)
-    lib.call('clamd_conv3x3', ptr(g), Cc, ptr(wd), None, ptr(gx), Cc, None, B, H, W, Cc, Cc, 0, 0, 0, s)
+    lib.call('clamd_conv3x3', ptr(x), Cc, ptr(wf), None, ptr(y), Cc, None, None, None, B, H, W, Cc, Cc, 0, 0, 0, s)
+    lib.call('clamd_conv3x3', ptr(g), Cc, ptr(wd), None, ptr(gx), Cc, None, None, None, B, H, W, Cc, Cc, 0, 0, 0, s)
     wsb = lib.load().clamd_wgrad_workspace_bytes(0, B, H, W, Cc, Cc, 0)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     lib.call('clamd_wgrad', 0, ptr(g), Cc, ptr(x), Cc, ptr(ws), wsb, ptr(gw), B, H, W, Cc, Cc, Cc, Cc, Cc, Cc, Cc, Cc, 0, s)

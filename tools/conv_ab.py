@@ -26,11 +26,11 @@ for cin, cout, hw in layers:
     for rd in range(rounds):
         for v in variants:
             lib.clamd_set_tuning(key, v)
-            call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), B, hw, hw, cin, cout, 1, mf, dc, s)
+            call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, B, hw, hw, cin, cout, 1, mf, dc, s)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
-                call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), B, hw, hw, cin, cout, 1, mf, dc, s)
+                call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, B, hw, hw, cin, cout, 1, mf, dc, s)
             e1.record(); torch.cuda.synchronize()
             best[v] = min(best[v], e0.elapsed_time(e1) / iters * 1e-3)
             if rd == 0:

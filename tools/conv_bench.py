@@ -27,7 +27,7 @@ for cin, cout, hw in layers:
     stats = torch.zeros(16, 2, cout, device='cuda')
     mf = 1 if 9 * cout > B * hw * hw else 0
     def fwd():
-        call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), B, hw, hw, cin, cout, 1, mf, dc, s)
+        call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, B, hw, hw, cin, cout, 1, mf, dc, s)
     wsb = lib.clamd_wgrad_workspace_bytes(0, B, hw, hw, cout, cin, dc)
     ws = torch.empty(wsb // 4 + 4, device='cuda'); gw = torch.empty_like(w)
     g = torch.randn(B, hw, hw, cout, device='cuda').to(T)
