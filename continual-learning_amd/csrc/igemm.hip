@@ -20,46 +20,10 @@
 //                   NCHW  (logits head: fp32 NCHW, only the logical classes).
 #include <string.h>
 #include "common.hip.h"
+#include "igemm_common.hip.h"
 #include "clamd_internal.h"
 
 namespace clamd {
-
-enum { MODE_CONV3 = 0, MODE_PW = 1, MODE_UP2 = 2 };
-enum { EPI_NHWC = 0, EPI_UP2 = 1, EPI_NCHW = 2 };
-
-struct IgemmParams {
-    const void* x; int x_ldc;
-    const void* w;          // packed [taps][Np][Kp], K innermost
-    const float* bias;      // indexed by n (NHWC/NCHW) or by n % aux (UP2 epilogue); may be null
-    void* y; int y_ldc;
-    float* stats;           // [STAT_REPLICAS][2][Np] or null
-    int B, H, W;            // pixel grid of the GEMM rows
-    int Kp, Np;
-    int relu;
-    int aux;                // EPI_UP2: convT Cout_p ; EPI_NCHW: logical classes ; MODE_UP2: channels per (dy,dx)
-    int m_fastest;
-    // EPI_NHWC only: when this launch produces the gradient g w.r.t. a BatchNorm output, accumulate the five
-    // per-channel sums of the fused ReLU/BN backward (see bn_bwd_reduce_kernel) right here in the epilogue:
-    // bn_y = that unit's saved post-ReLU activation [B,H,W,Np] (dense pitch Np), bn_sums = [STAT_REPLICAS][5][Np].
-    const void* bn_y;
-    float* bn_sums;
-};
-
-template <int MODE, int TW> struct Geo {
-    static constexpr int TH = 256 / TW;
-    static constexpr int NT = MODE == MODE_CONV3 ? 9 : 2;          // filter slabs per staged K-step
-    static constexpr int NIN = MODE == MODE_CONV3 ? 1 : NT;        // input slabs per staged K-step
-    static constexpr int HW_ = MODE == MODE_CONV3 ? TW + 2 : TW;
-    static constexpr int HH_ = MODE == MODE_CONV3 ? TH + 2 : TH;
-    static constexpr int NPIX = HW_ * HH_;
-    static constexpr int NPIXP = NPIX + ((10 - NPIX % 8) % 8);     // == 2 (mod 8)
-    static constexpr int NJ = (NPIX * 4 + 255) / 256;              // 16-B input loads per thread per slab
-    static constexpr int IN_SLOTS = NIN * 4 * NPIXP;
-    static constexpr int WG = 66;                                  // padded channel rows per group, == 2 (mod 8)
-    static constexpr int WT_SLOTS = NT * 4 * WG;
-    static constexpr int EPI_SLOTS = 4 * 32 * 68 / 4;              // fp32 transposition buffer, 4 waves x [32][68]
-    static constexpr int SLOTS = IN_SLOTS + WT_SLOTS > EPI_SLOTS ? IN_SLOTS + WT_SLOTS : EPI_SLOTS;
-};
 
 template <typename T, int MODE, int EPI, int TW, int VAR>
 __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
@@ -117,9 +81,10 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
         if constexpr (MODE == MODE_CONV3) {                                                                       \
             const int k0_ = (ks_) * KC;                                                                           \
             _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                        \
-                rin[0][j] = ldg16(xg + in_off[j] + k0_, in_off[j] >= 0);                                          \
+                rin[0][j] = ldg16(xg + in_off[j] + k0_, in_off[j] >= 0 && VAR != 4);                              \
             _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
-                rw[t] = ldg16(wg + (long long)t * p.Np * p.Kp + w_row + k0_, w_ok);                               \
+                rw[t] = ldg16(wg + ((long long)((ks_) * NT + t) * p.Np + n0 + wco) * KC + g4 * VEC,              \
+                              w_ok && VAR != 3 && VAR != 4);   /* K-chunk-major filter layout */                   \
         } else {                                                                                                  \
             _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                      \
                 const int k0_ = ((ks_) * NT + t) * KC;                                                            \
@@ -192,7 +157,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
                 mma_bf16(al1, bh0, acc[1][0]); mma_bf16(ah1, bl0, acc[1][0]); mma_bf16(ah1, bh0, acc[1][0]);
                 mma_bf16(al1, bh1, acc[1][1]); mma_bf16(ah1, bl1, acc[1][1]); mma_bf16(ah1, bh1, acc[1][1]);
             }
-        } else if constexpr (VAR == 0) {
+        } else if constexpr (VAR == 0 || VAR >= 3) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int in_base = MODE == MODE_CONV3 ? (t / 3) * HW_ + (t % 3) : t * 4 * NPIXP;
@@ -203,10 +168,14 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
                     const uint4 a1 = smem[in_base + g * NPIXP + apix[1]];
                     const uint4 b0 = smem[G::IN_SLOTS + (t * 4 + g) * G::WG + r];
                     const uint4 b1 = smem[G::IN_SLOTS + (t * 4 + g) * G::WG + 32 + r];
-                    mma16<T>(a0, b0, acc[0][0]);
-                    mma16<T>(a0, b1, acc[0][1]);
-                    mma16<T>(a1, b0, acc[1][0]);
-                    mma16<T>(a1, b1, acc[1][1]);
+                    if constexpr (VAR == 5) {      // ablation: LDS reads kept alive, no MFMA
+                        asm volatile("" :: "v"(a0.x), "v"(a1.x), "v"(b0.x), "v"(b1.x));
+                    } else {
+                        mma16<T>(a0, b0, acc[0][0]);
+                        mma16<T>(a0, b1, acc[0][1]);
+                        mma16<T>(a1, b0, acc[1][0]);
+                        mma16<T>(a1, b1, acc[1][1]);
+                    }
                 }
             }
         } else {
@@ -224,6 +193,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
         b1_ = smem[G::IN_SLOTS + (t_ * 4 + g_) * G::WG + 32 + r];                                                 \
     } while (0)
             IGEMM_FRAG(0, fa0, fa1, fb0, fb1);
+            if constexpr (VAR >= 1) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // R(0) leads: R(s+1) precedes M(s)
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
                 if (st + 1 < NSTEP) IGEMM_FRAG(st + 1, na0, na1, nb0, nb1);
@@ -426,7 +396,11 @@ static_assert(Geo<MODE_CONV3, 16>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4,
 static_assert(Geo<MODE_PW, 32>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4, "LDS too small for epilogue");
 static_assert(Geo<MODE_PW, 16>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4, "LDS too small for epilogue");
 
-static int g_igemm_variant = 0;   // tuning knob (clamd_set_tuning): 0 = compiler-scheduled, 1/2 = explicit fragment double-buffering
+extern int g_wgrad_target_blocks;
+static int g_igemm_variant = 0;
+static int g_igemm_ws = 2;         // 0: never, 1: always, 2: where it measured faster (A/B in tools/conv_ab.py): images narrower
+                                   // than 32 px (the 16x16 bottleneck of the 256x256 net: +14..19 %); elsewhere the baseline
+                                   // two-workgroups-per-CU kernel wins by 0..30 % (short K loops cannot fill the 2-stage pipeline)   // tuning knob (clamd_set_tuning): 0 = compiler-scheduled, 1/2 = explicit fragment double-buffering
 
 template <typename T, int MODE, int EPI>
 static int launch_tw(const IgemmParams& p, hipStream_t s) {
@@ -438,7 +412,8 @@ static int launch_tw(const IgemmParams& p, hipStream_t s) {
     const int var = (MODE == MODE_CONV3 && EPI == EPI_NHWC && !__is_same(T, split_t)) ? g_igemm_variant : 0;
 #define IGEMM_LAUNCH(TW_, V_) hipLaunchKernelGGL((igemm_kernel<T, MODE, EPI, TW_, V_>), dim3((unsigned)nblk), dim3(256), 0, s, p)
     if constexpr (MODE == MODE_CONV3 && EPI == EPI_NHWC && !__is_same(T, split_t)) {
-        if (wide) { if (var == 1) IGEMM_LAUNCH(32, 1); else if (var == 2) IGEMM_LAUNCH(32, 2); else IGEMM_LAUNCH(32, 0); }
+        if (wide) { if (var == 1) IGEMM_LAUNCH(32, 1); else if (var == 2) IGEMM_LAUNCH(32, 2); else if (var == 3) IGEMM_LAUNCH(32, 3);
+                    else if (var == 4) IGEMM_LAUNCH(32, 4); else if (var == 5) IGEMM_LAUNCH(32, 5); else IGEMM_LAUNCH(32, 0); }
         else { if (var == 1) IGEMM_LAUNCH(16, 1); else if (var == 2) IGEMM_LAUNCH(16, 2); else IGEMM_LAUNCH(16, 0); }
     } else {
         if (wide) IGEMM_LAUNCH(32, 0); else IGEMM_LAUNCH(16, 0);
@@ -473,6 +448,8 @@ extern "C" {
 
 int clamd_set_tuning(const char* key, int value) {
     if (!strcmp(key, "igemm_variant")) { g_igemm_variant = value; return 0; }
+    if (!strcmp(key, "igemm_ws")) { g_igemm_ws = value; return 0; }
+    if (!strcmp(key, "wgrad_blocks")) { if (value < 1 || value > 512) return clamd_fail("wgrad_blocks: 1..512"); g_wgrad_target_blocks = value; return 0; }
     return clamd_fail("set_tuning: unknown key");
 }
 
@@ -481,6 +458,7 @@ int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* b
                   int m_fastest, int dtype, void* stream) {
     IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, m_fastest, bn_y, bn_sums};
     if (int e = check_common(p, "conv3x3")) return e;
+    if (g_igemm_ws == 1 || (g_igemm_ws == 2 && W < 32 && Cin_p >= 256)) return launch_igemm_ws(p, dtype, (hipStream_t)stream);
     return launch<MODE_CONV3, EPI_NHWC>(p, dtype, (hipStream_t)stream);
 }
 

@@ -35,7 +35,8 @@ struct PackJob {
     int flip;                    // read source tap T-1-t (spatially flipped filter for the data gradient)
     int dst_f32;                 // destination element type: 1 = float, 0 = compute dtype of the launch
     int block0;                  // first block of this job in the fused launch
-    int pad_;
+    int kc;                      // 0: dst = t*dt + n*dn + k*dk;  >0: K-chunk-major  ((k/kc)*T + t)*Np*kc + n*kc + k%kc
+                                 // (the 3x3 kernels read whole [tap][n] slabs of one K-chunk: contiguous 128-B lines)
 };
 
 __device__ inline int phys2log(int p, int seg0, int seg0p, int L) {
@@ -84,15 +85,17 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackJob* __restrict__ j
         const int n = n0 + nn, k = k0 + kk;
         if (n < j.Np && k < j.Kp) {
             for (int t = 0; t < j.T; ++t) {
-                const long long d = t * j.dt + n * j.dn + k * j.dk;
+                // element offset of (t, n, k) with k rounded down to its 16-channel group `kg` (+ k%16 added below)
+                const long long d = j.kc > 0 ? (((long long)(k / j.kc) * j.T + t) * j.Np + n) * j.kc + (k % j.kc)
+                                             : t * j.dt + n * j.dn + k * j.dk;
                 if (j.dst_f32) ((float*)j.dst)[d] = tile[t][nn][kk];
                 else if constexpr (__is_same(T, split_t)) {
-                    // 4 bytes per element: every 16-channel chunk is stored as [16 x bf16 hi][16 x bf16 lo]
+                    // 4 bytes per element: every 16-channel group is stored as [16 x bf16 hi][16 x bf16 lo]
                     const float x = tile[t][nn][kk];
                     const uint16_t hi = f2bf(x);
-                    uint16_t* row = (uint16_t*)j.dst + 2 * (d - k);
-                    row[(k >> 4) * 32 + (k & 15)] = hi;
-                    row[(k >> 4) * 32 + 16 + (k & 15)] = f2bf(x - bf2f(hi));
+                    uint16_t* grp = (uint16_t*)j.dst + 2 * (d - (k & 15));
+                    grp[k & 15] = hi;
+                    grp[16 + (k & 15)] = f2bf(x - bf2f(hi));
                 } else st1<T>((T*)j.dst + d, tile[t][nn][kk]);
             }
         }

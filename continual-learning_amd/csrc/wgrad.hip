@@ -261,6 +261,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const ReduceParams p)
     }
 }
 
+int g_wgrad_target_blocks = 512;   // tuning knob (clamd_set_tuning "wgrad_blocks"): split-K until about this many workgroups
+
 template <typename T, int MODE>
 static int launch_wg(const WgradParams& p, hipStream_t s, int grid) {
     if (p.W >= 32) hipLaunchKernelGGL((wgrad_kernel<T, MODE, 32>), dim3(grid), dim3(256), 0, s, p);
@@ -278,7 +280,7 @@ size_t clamd_wgrad_workspace_bytes(int mode, int B, int H, int W, int Rp, int Cp
     // upper bound used by callers to size the slab buffer: nsplit is capped at 512 blocks total (see below)
     const int NT = mode == WG_CONV3 ? 9 : (mode == WG_UP2 ? 4 : 1);
     const int rt = (Rp + 63) / 64, ct = (Cp + 63) / 64;
-    int nsplit = 512 / (rt * ct);
+    int nsplit = 512 / (rt * ct);      // upper bound over every value the tuning knob may take
     if (nsplit < 1) nsplit = 1;
     (void)B; (void)H; (void)W; (void)dtype;
     return (size_t)nsplit * NT * Rp * Cp * sizeof(float);
@@ -295,7 +297,7 @@ int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, fl
     const int TH = (dtype == CLAMD_BF16 ? 128 : 64) / (mode == WG_UP2 ? 2 : 1) / TW;    // CLAMD_SPLIT tiles like fp32
     const int ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
     const int rt = (Rp + 63) / 64, ct = (Cp + 63) / 64;
-    int nsplit = 512 / (rt * ct);
+    int nsplit = g_wgrad_target_blocks / (rt * ct);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > ntiles) nsplit = ntiles;
     int per = (ntiles + nsplit - 1) / nsplit;

@@ -11,7 +11,7 @@ from ._lib import call, ptr
 TORCH_DT = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.SPLIT: torch.float32}
 
 _PACK_DT = np.dtype({'names': ['src', 'dst', 'T', 'Np', 'Kp', 'N', 'K', 'st', 'sn', 'sk', 'dt', 'dn', 'dk',
-                               'n_seg0', 'n_seg0p', 'k_seg0', 'k_seg0p', 'flip', 'dst_f32', 'block0', 'pad_'],
+                               'n_seg0', 'n_seg0p', 'k_seg0', 'k_seg0p', 'flip', 'dst_f32', 'block0', 'kc'],
                      'formats': ['u8', 'u8', 'i4', 'i4', 'i4', 'i4', 'i4', 'i8', 'i8', 'i8', 'i8', 'i8', 'i8',
                                  'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4'],
                      'offsets': [0, 8, 16, 20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 88, 92, 96, 100, 104, 108, 112, 116],
@@ -26,27 +26,33 @@ def cpad(c):
 class PackTable:
     """Job table for clamd_pack: one fused launch re-packs every fp32 master parameter (see include/clamd.h)."""
 
-    def __init__(self):
+    KC = {_lib.F32: 16, _lib.BF16: 32, _lib.SPLIT: 16}     # channels per 64-byte K-chunk of the 3x3 kernels
+
+    def __init__(self, dcode):
         self.jobs = []
         self.dev_table = None
+        self.dcode = dcode
+        self.kc = self.KC[dcode]
 
-    def add(self, src, dst, T, Np, Kp, N, K, st, sn, sk, dt, dn, dk, nseg=None, kseg=None, flip=0, f32=0):
+    def add(self, src, dst, T, Np, Kp, N, K, st, sn, sk, dt, dn, dk, nseg=None, kseg=None, flip=0, f32=0, kc=0):
         nseg = nseg or (N, Np)
         kseg = kseg or (K, Kp)
         self.jobs.append((src.data_ptr(), dst.data_ptr(), T, Np, Kp, N, K, st, sn, sk, dt, dn, dk,
-                          nseg[0], nseg[1], kseg[0], kseg[1], flip, f32, 0, 0))
+                          nseg[0], nseg[1], kseg[0], kseg[1], flip, f32, 0, kc))
 
     # ---- the layouts of include/clamd.h ----
     def conv3x3(self, w, wf, wd, cin_segs, cout):
-        """w [Cout][Cin][3][3] fp32 -> wf [9][Cout_p][Cin_p] (forward) and wd [9][Cin_p][Cout_p] (data gradient,
-        taps flipped).  cin_segs: [(logical, physical), ...] one or two channel segments (concat inputs)."""
+        """w [Cout][Cin][3][3] fp32 -> wf [Cin_p/kc][9][Cout_p][kc] (forward) and wd [Cout_p/kc][9][Cin_p][kc] (data
+        gradient, taps flipped): K-chunk-major, so the [tap][n] slab of one 64-byte K-chunk is contiguous.
+        cin_segs: [(logical, physical), ...] one or two channel segments (concat inputs)."""
         cin = sum(s[0] for s in cin_segs)
         cin_p = sum(s[1] for s in cin_segs)
         cout_p = cpad(cout)
         seg = (cin_segs[0][0], cin_segs[0][1]) if len(cin_segs) == 2 else None
-        self.add(w, wf, 9, cout_p, cin_p, cout, cin, 1, cin * 9, 9, cout_p * cin_p, cin_p, 1, kseg=seg)
+        self.add(w, wf, 9, cout_p, cin_p, cout, cin, 1, cin * 9, 9, cout_p * cin_p, cin_p, 1, kseg=seg, kc=self.kc)
         if wd is not None:
-            self.add(w, wd, 9, cin_p, cout_p, cin, cout, 1, 9, cin * 9, cin_p * cout_p, cout_p, 1, nseg=seg, flip=1)
+            self.add(w, wd, 9, cin_p, cout_p, cin, cout, 1, 9, cin * 9, cin_p * cout_p, cout_p, 1, nseg=seg, flip=1,
+                     kc=self.kc)
 
     def convT(self, w, wf, wd, cin, cout):
         """w [Cin][Cout][2][2] -> wf [4][Cout_p][Cin_p] and wd [Cin_p][4][Cout_p]."""
@@ -81,8 +87,9 @@ class PackTable:
         self.nblocks = blk
         return self
 
-    def run(self, dcode, stream=None):
-        call('clamd_pack', ptr(self.dev_table), len(self.jobs), self.nblocks, dcode, stream or _lib.stream_ptr())
+    def run(self, dcode=None, stream=None):
+        assert dcode is None or dcode == self.dcode
+        call('clamd_pack', ptr(self.dev_table), len(self.jobs), self.nblocks, self.dcode, stream or _lib.stream_ptr())
 
 
 # ---- single-kernel wrappers (tests, small tools) ----------------------------------------------------------------

@@ -300,7 +300,7 @@ class _Engine:
 
     # ------------------------------------------------------------------------------------------ pack table
     def _build_pack_table(self):
-        tab = PackTable()
+        tab = PackTable(self.dcode)
         for u in self.convs:
             if u.im2col:
                 tab.head(u.w, u.wf, None, 9 * u.cin, u.cout)     # [Cout][Cin*9] is already the (c*9 + tap) K order

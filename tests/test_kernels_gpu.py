@@ -92,7 +92,7 @@ def test_pack_layouts(C, name, dcode):
     wh = rnd(rng, 21, 40, 1, 1); wht = dev(wh)
     hf = torch.zeros(32 * 64, dtype=T, device='cuda'); hd = torch.zeros(64 * 32, dtype=T, device='cuda')
     b = rnd(rng, 7); bt = dev(b); bp = torch.full((32,), 9.0, device='cuda')
-    tab = C.ops.PackTable()
+    tab = C.ops.PackTable(dcode)
     tab.conv3x3(wt, wf, wd, segs, 7)
     tab.convT(wct, cf, cd, 6, 3)
     tab.head(wht, hf, hd, 40, 21)
@@ -106,7 +106,8 @@ def test_pack_layouts(C, name, dcode):
             raw = buf.view(torch.int16).cpu().numpy().view(np.uint16).reshape(*shape[:-1], shape[-1] // 16, 2, 16)
             f = (raw.astype(np.uint32) << 16).view(np.float32)
             return f[..., 0, :].reshape(shape), (f[..., 0, :] + f[..., 1, :]).reshape(shape)
-        hi, full = unsplit(wf, 9, 32, 64)
+        hi, full = unsplit(wf, 4, 9, 32, 16)                 # [K-chunk][tap][n][16]
+        hi, full = [a.transpose(1, 2, 0, 3).reshape(9, 32, 64) for a in (hi, full)]
         pm = phys_map(segs)
         exp_f = np.zeros((9, 32, 64), np.float32)
         for t in range(9):
@@ -127,8 +128,11 @@ def test_pack_layouts(C, name, dcode):
                 continue
             exp_f[t, :7, kp] = w[:, kl, ky, kx]
             exp_d[t, kp, :7] = w[:, kl, 2 - ky, 2 - kx]
-    assert np.array_equal(wf.float().cpu().numpy().reshape(9, 32, 64), rb(exp_f, dcode))
-    assert np.array_equal(wd.float().cpu().numpy().reshape(9, 64, 32), rb(exp_d, dcode))
+    kc = tab.kc                                           # K-chunk-major: [K/kc][tap][n][kc]
+    got_f = wf.float().cpu().numpy().reshape(64 // kc, 9, 32, kc).transpose(1, 2, 0, 3).reshape(9, 32, 64)
+    got_d = wd.float().cpu().numpy().reshape(32 // kc, 9, 64, kc).transpose(1, 2, 0, 3).reshape(9, 64, 32)
+    assert np.array_equal(got_f, rb(exp_f, dcode))
+    assert np.array_equal(got_d, rb(exp_d, dcode))
     exp_cf = np.zeros((4, 32, 32), np.float32); exp_cd = np.zeros((32, 4, 32), np.float32)
     for q in range(4):
         exp_cf[q, :3, :6] = wc[:, :, q // 2, q % 2].T
@@ -164,7 +168,7 @@ def _conv_case(C, rng, B, segs, cout, H, W, dcode):
     wf = torch.zeros(9 * cout_p * cin_p, dtype=T, device='cuda')
     wd = torch.zeros(9 * cin_p * cout_p, dtype=T, device='cuda')
     bp = torch.zeros(cout_p, device='cuda')
-    tab = C.ops.PackTable()
+    tab = C.ops.PackTable(dcode)
     tab.conv3x3(wt, wf, wd, segs, cout)
     tab.vector(bt, bp, cout)
     tab.finalize('cuda').run(dcode)
@@ -248,7 +252,7 @@ def test_convT2x2_fwd_dgrad_wgrad(C, name, dcode, shape):
     xt, wt, bt = C.ops.to_nhwc(dev(x), dcode), dev(w), dev(b)
     wf = torch.zeros(4 * cout_p * cin_p, dtype=T, device='cuda'); wd = torch.zeros(cin_p * 4 * cout_p, dtype=T, device='cuda')
     bp = torch.zeros(cout_p, device='cuda')
-    tab = C.ops.PackTable(); tab.convT(wt, wf, wd, cin, cout); tab.vector(bt, bp, cout); tab.finalize('cuda').run(dcode)
+    tab = C.ops.PackTable(dcode); tab.convT(wt, wf, wd, cin, cout); tab.vector(bt, bp, cout); tab.finalize('cuda').run(dcode)
     # output goes into the SECOND half of a concat buffer (pitch 2*cout_p), the first half must stay untouched
     cat = torch.full((B, 2 * h, 2 * w_, 2 * cout_p), 3.0, dtype=T, device='cuda')
     ysl = cat[..., cout_p:]
@@ -293,7 +297,7 @@ def test_head_fwd_bwd(C, name, dcode, shape):
     xt, wt, bt = C.ops.to_nhwc(dev(x), dcode), dev(w), dev(b)
     wf = torch.zeros(kp * cin_p, dtype=T, device='cuda'); wd = torch.zeros(cin_p * kp, dtype=T, device='cuda')
     bp = torch.zeros(kp, device='cuda')
-    tab = C.ops.PackTable(); tab.head(wt, wf, wd, cin, K); tab.vector(bt, bp, K); tab.finalize('cuda').run(dcode)
+    tab = C.ops.PackTable(dcode); tab.head(wt, wf, wd, cin, K); tab.vector(bt, bp, K); tab.finalize('cuda').run(dcode)
     logits = torch.full((B, K, H, W), 9.0, device='cuda')
     lib.call('clamd_conv1x1_logits', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(logits), B, H, W, cin_p, kp, K, dcode, s)
     sync()
@@ -331,7 +335,7 @@ def test_first_layer_im2col_path(C, name, dcode, shape):
     lib.call('clamd_nchw_im2col3', ptr(xt_), ptr(xcol), kp, B, cin, H, W, kp, dcode, s)
     wt, bt = dev(w), dev(b)
     wf = torch.zeros(cout_p * kp, dtype=T, device='cuda'); bp = torch.zeros(cout_p, device='cuda')
-    tab = C.ops.PackTable(); tab.head(wt, wf, None, 9 * cin, cout); tab.vector(bt, bp, cout); tab.finalize('cuda').run(dcode)
+    tab = C.ops.PackTable(dcode); tab.head(wt, wf, None, 9 * cin, cout); tab.vector(bt, bp, cout); tab.finalize('cuda').run(dcode)
     y = torch.zeros(B, H, W, cout_p, dtype=T, device='cuda')
     stats = torch.zeros(lib.load().clamd_stat_replicas(), 2, cout_p, device='cuda')
     lib.call('clamd_conv1x1', ptr(xcol), kp, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, B, H, W, kp, cout_p, 1, dcode, s)

@@ -126,7 +126,7 @@ def test_full_size_config2_vs_reference_golden(C, golden, dtype):
             assert maxrel(sub, g['logits']) < tol * (1 if fp32 else 2)
             gn = np.array([float(p.grad.double().norm()) for p in model.parameters()])
             big = g['grad_norms'] > 1e-4 * g['grad_norms'].max()
-            np.testing.assert_allclose(gn[big], g['grad_norms'][big], rtol=5e-3 if fp32 else 0.3)
+            np.testing.assert_allclose(gn[big], g['grad_norms'][big], rtol={'fp32': 5e-3, 'bf16x3': 2e-2, 'bf16': 0.3}[dtype])
             m = C.eval_metrics(y, out.detach(), 21)
             # mIoU "identical" (fp32) / within +-0.1 (bf16)
             assert abs(float(m[2]) - float(g['metrics'][2])) < (1e-5 if fp32 else 0.1)
@@ -244,8 +244,7 @@ def test_adjoint_identities_full_size(C):
     g = torch.randn(B, H, W, Cc, device='cuda', generator=gen)
     w = torch.randn(Cc, Cc, 3, 3, device='cuda', generator=gen) / 24.0
     wf = torch.zeros(9 * Cc * Cc, device='cuda'); wd = torch.zeros(9 * Cc * Cc, device='cuda')
-    C.ops.PackTable().conv3x3 if False else None
-    tab = C.ops.PackTable(); tab.conv3x3(w, wf, wd, [(Cc, Cc)], Cc); tab.finalize('cuda').run(0)
+    tab = C.ops.PackTable(0); tab.conv3x3(w, wf, wd, [(Cc, Cc)], Cc); tab.finalize('cuda').run(0)
     s = lib.stream_ptr()
     y = torch.empty_like(x); gx = torch.empty_like(x); gw = torch.empty_like(w)
     lib.call('clamd_conv3x3', ptr(x), Cc, ptr(wf), None, ptr(y), Cc, None, None, None, B, H, W, Cc, Cc, 0, 0, 0, s)

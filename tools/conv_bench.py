@@ -9,7 +9,7 @@ from continual_learning_amd._lib import call, ptr
 
 dt = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-dc = {'fp32': 0, 'bf16': 1}[dt]
+dc = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[dt]
 T = C.ops.TORCH_DT[dc]
 B = 16
 layers = [(64, 64, 256), (128, 64, 256), (128, 128, 128), (256, 128, 128), (256, 256, 64), (512, 256, 64),
@@ -22,7 +22,7 @@ for cin, cout, hw in layers:
     w = torch.randn(cout, cin, 3, 3, device='cuda') / (3 * cin ** 0.5)
     wf = torch.zeros(9 * cout * cin, dtype=T, device='cuda'); wd = torch.zeros(9 * cin * cout, dtype=T, device='cuda')
     bias = torch.zeros(cout, device='cuda')
-    tab = C.ops.PackTable(); tab.conv3x3(w, wf, wd, [(cin, cin)], cout); tab.finalize('cuda').run(dc)
+    tab = C.ops.PackTable(dc); tab.conv3x3(w, wf, wd, [(cin, cin)], cout); tab.finalize('cuda').run(dc)
     y = torch.empty(B, hw, hw, cout, dtype=T, device='cuda')
     stats = torch.zeros(16, 2, cout, device='cuda')
     mf = 1 if 9 * cout > B * hw * hw else 0
