@@ -29,7 +29,10 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, diag=False):
+    global FLAGS
+    if diag:
+        FLAGS = FLAGS + ['-DCLAMD_DIAG']      # diagnostic build: in-kernel cycle stamps (never for measurements)
     stamp = os.path.join(HERE, 'csrc', '.build_stamp')
     dig = _digest()
     if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == dig:
@@ -59,4 +62,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    print(build(force='--force' in sys.argv or '--diag' in sys.argv, diag='--diag' in sys.argv))

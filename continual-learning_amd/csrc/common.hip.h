@@ -124,6 +124,21 @@ __device__ inline uint4 ldg16(const void* p, bool ok) {
     return v;
 }
 
+// 16-byte buffer load with hardware range checking: one VMEM instruction, per-lane 32-bit byte offset computed ONCE,
+// wave-uniform (SGPR) chunk offset, zero returned for lanes whose offset is >= num_records.  Halo / padding lanes use
+// BUF_OOB.  Measured with in-kernel stamps (tools/ws_diag.py): the predicated 64-bit global loads used before cost
+// ~100 issue cycles each (exec-mask branches + 64-bit address VALU) and made the staging code, not the MFMAs or
+// the memory system, the critical path of the convolution kernels.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr unsigned BUF_OOB = 0x80000000u;
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ inline uint4 buf_ld16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // Row of accumulator register `reg` (0..15) for lane half h in a 32x32 MFMA tile; column = lane & 31.
 __device__ inline int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 

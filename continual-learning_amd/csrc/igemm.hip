@@ -35,9 +35,6 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const T* __restrict__ xg = (const T*)p.x;
-    const T* __restrict__ wg = (const T*)p.w;
-
     // ---- which tile -------------------------------------------------------------------------------
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     const int ntm = tiles_x * tiles_y * p.B, ntn = (p.Np + 63) >> 6;
@@ -48,67 +45,77 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
     const int n0 = tn * 64;
 
     // ---- per-thread staging descriptors (constant over the K loop) ---------------------------------
+    // Buffer descriptors: input = this image only (per-image byte offsets always fit 31 bits), filters = whole pack.
+    constexpr int ESZ = sizeof(T);
     const int g4 = tid & 3;
-    int in_off[NJ];   // element offset of this thread's 16-B group at channel 0, or -1
+    const unsigned img_elems = (MODE == MODE_UP2 ? 4u : 1u) * (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc;
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x + (size_t)b * img_elems * ESZ, img_elems * ESZ);
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.w, (unsigned)((MODE == MODE_CONV3 ? 9u : 1u) * p.Np * p.Kp * ESZ));
+    unsigned in_vo[NJ];   // byte offset of this thread's 16-B group at channel 0 inside the image, or BUF_OOB (-> zeros)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int pix = (tid >> 2) + 64 * j;
         const int hy = pix / HW_, hx = pix - hy * HW_;
-        int off = -1;
+        unsigned off = BUF_OOB;
         if (pix < NPIX) {
             if constexpr (MODE == MODE_CONV3) {
                 const int yy = y0 + hy - 1, xx = x0 + hx - 1;
-                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) off = ((b * p.H + yy) * p.W + xx) * p.x_ldc + g4 * VEC;
+                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) off = ((yy * p.W + xx) * p.x_ldc + g4 * VEC) * ESZ;
             } else if constexpr (MODE == MODE_PW) {
                 const int yy = y0 + hy, xx = x0 + hx;
-                if (yy < p.H && xx < p.W) off = ((b * p.H + yy) * p.W + xx) * p.x_ldc + g4 * VEC;
+                if (yy < p.H && xx < p.W) off = ((yy * p.W + xx) * p.x_ldc + g4 * VEC) * ESZ;
             } else {
                 const int yy = y0 + hy, xx = x0 + hx;
-                if (yy < p.H && xx < p.W) off = ((b * 2 * p.H + 2 * yy) * 2 * p.W + 2 * xx) * p.x_ldc + g4 * VEC;
+                if (yy < p.H && xx < p.W) off = ((2 * yy * 2 * p.W + 2 * xx) * p.x_ldc + g4 * VEC) * ESZ;
             }
         }
-        in_off[j] = off;
+        in_vo[j] = off;
     }
     const int wco = tid >> 2;
-    const bool w_ok = n0 + wco < p.Np;
-    const long long w_row = (long long)(n0 + wco) * p.Kp + g4 * VEC;   // + tap*Np*Kp + k0
+    // filters: CONV3 packs are K-chunk-major [chunk][tap][n][KC]; PW/UP2 packs are [n][Kp]
+    const unsigned w_vo = n0 + wco < p.Np
+        ? (unsigned)(((n0 + wco) * (MODE == MODE_CONV3 ? KC : p.Kp) + g4 * VEC) * ESZ) : BUF_OOB;
+    const unsigned w_slab = (unsigned)(p.Np * KC * ESZ);     // CONV3: bytes of one [tap] slab of one K-chunk
 
     uint4 rin[NIN][NJ], rw[NT];
+    const uint4 zero4_ = make_uint4(0u, 0u, 0u, 0u);
 
 // Global -> register staging of K-step `ks` (macro, not a lambda: the register arrays must stay in VGPRs).
+// One buffer_load_dwordx4 per 16 bytes; the only per-K-step address work is scalar (soffset).
 #define IGEMM_GLOAD(ks_)                                                                                          \
     do {                                                                                                          \
         if constexpr (MODE == MODE_CONV3) {                                                                       \
-            const int k0_ = (ks_) * KC;                                                                           \
+            const unsigned so_ = (unsigned)((ks_) * KC * ESZ);                                                    \
             _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                        \
-                rin[0][j] = ldg16(xg + in_off[j] + k0_, in_off[j] >= 0 && VAR != 4);                              \
+                rin[0][j] = VAR == 4 ? zero4_ : buf_ld16(xrs, in_vo[j], so_);                                     \
             _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                        \
-                rw[t] = ldg16(wg + ((long long)((ks_) * NT + t) * p.Np + n0 + wco) * KC + g4 * VEC,              \
-                              w_ok && VAR != 3 && VAR != 4);   /* K-chunk-major filter layout */                   \
+                rw[t] = (VAR == 3 || VAR == 4) ? zero4_ : buf_ld16(wrs, w_vo, (unsigned)((ks_) * NT + t) * w_slab); \
         } else {                                                                                                  \
             _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                      \
                 const int k0_ = ((ks_) * NT + t) * KC;                                                            \
-                const bool kok_ = k0_ < p.Kp;                                                                     \
+                const bool kok_ = k0_ < p.Kp;                      /* wave-uniform */                             \
                 int koff_ = k0_;                                                                                  \
                 if constexpr (MODE == MODE_UP2) {                                                                 \
                     const int q_ = k0_ / p.aux, c0_ = k0_ - q_ * p.aux;                                           \
                     koff_ = ((q_ >> 1) * 2 * p.W + (q_ & 1)) * p.x_ldc + c0_;                                     \
                 }                                                                                                 \
                 _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                    \
-                    rin[t][j] = ldg16(xg + in_off[j] + koff_, kok_ && in_off[j] >= 0);                            \
-                rw[t] = ldg16(wg + w_row + k0_, kok_ && w_ok);                                                    \
+                    rin[t][j] = kok_ ? buf_ld16(xrs, in_vo[j], (unsigned)(koff_ * ESZ)) : zero4_;                 \
+                rw[t] = kok_ ? buf_ld16(wrs, w_vo, (unsigned)(k0_ * ESZ)) : zero4_;                               \
             }                                                                                                     \
         }                                                                                                         \
     } while (0)
 
+// Registers -> LDS.  Only the last j can fall outside the tile (pix >= NPIX): every other store is unconditional.
 #define IGEMM_LDS_STORE()                                                                                         \
     do {                                                                                                          \
         _Pragma("unroll") for (int t = 0; t < NIN; ++t)                                                           \
             _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                      \
                 const int pix_ = (tid >> 2) + 64 * j;                                                             \
+                const bool in_ = 64 * (j + 1) <= NPIX || pix_ < NPIX;                                             \
                 if constexpr (!SPLIT) {                                                                           \
-                    if (pix_ < NPIX) smem[t * 4 * NPIXP + g4 * NPIXP + pix_] = rin[t][j];                         \
-                } else if (pix_ < NPIX) {                                                                         \
+                    if (in_) smem[t * 4 * NPIXP + g4 * NPIXP + pix_] = rin[t][j];                                 \
+                } else if (in_) {                                                                                 \
                     /* groups 0,1 = hi channels 0-7 / 8-15, groups 2,3 = lo; this thread owns 4 channels */       \
                     uint2 hi_, lo_;                                                                               \
                     split4(rin[t][j], hi_, lo_);                                                                  \
@@ -157,7 +164,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
                 mma_bf16(al1, bh0, acc[1][0]); mma_bf16(ah1, bl0, acc[1][0]); mma_bf16(ah1, bh0, acc[1][0]);
                 mma_bf16(al1, bh1, acc[1][1]); mma_bf16(ah1, bl1, acc[1][1]); mma_bf16(ah1, bh1, acc[1][1]);
             }
-        } else if constexpr (VAR == 0 || VAR >= 3) {
+        } else if constexpr (VAR == 0 || VAR >= 3) {   // 3..6 are timing ablations (tools/conv_ab.py)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int in_base = MODE == MODE_CONV3 ? (t / 3) * HW_ + (t % 3) : t * 4 * NPIXP;
@@ -214,6 +221,13 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------
+    if constexpr (VAR == 6) {      // ablation: no epilogue (accumulators kept alive, nothing stored)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
+        return;
+    }
     // accumulator (mt, nt, reg): pixel m = 64*wave + 32*mt + acc_row(reg,h), channel n = n0 + 32*nt + r
     float bcol[2];
 #pragma unroll
@@ -398,9 +412,11 @@ static_assert(Geo<MODE_PW, 16>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4, "L
 
 extern int g_wgrad_target_blocks;
 static int g_igemm_variant = 0;
-static int g_igemm_ws = 2;         // 0: never, 1: always, 2: where it measured faster (A/B in tools/conv_ab.py): images narrower
-                                   // than 32 px (the 16x16 bottleneck of the 256x256 net: +14..19 %); elsewhere the baseline
-                                   // two-workgroups-per-CU kernel wins by 0..30 % (short K loops cannot fill the 2-stage pipeline)   // tuning knob (clamd_set_tuning): 0 = compiler-scheduled, 1/2 = explicit fragment double-buffering
+static int g_igemm_ws = 2;         // 0: never, 1: always (128x2-pixel tiles), 3: always (128x4), 2: where it measured faster
+                                   // (interleaved A/B, tools/conv_ab.py): long K loops (>= 256 input channels), where the
+                                   // two-stage pipeline fills and the 512-pixel tile halves the filter traffic per MFMA
+                                   // (+10..25 % bf16/bf16x3, +2..8 % fp32); short K loops stay on the two-workgroups-per-CU
+                                   // kernel below, whose second workgroup hides prologue and epilogue.
 
 template <typename T, int MODE, int EPI>
 static int launch_tw(const IgemmParams& p, hipStream_t s) {
@@ -413,7 +429,8 @@ static int launch_tw(const IgemmParams& p, hipStream_t s) {
 #define IGEMM_LAUNCH(TW_, V_) hipLaunchKernelGGL((igemm_kernel<T, MODE, EPI, TW_, V_>), dim3((unsigned)nblk), dim3(256), 0, s, p)
     if constexpr (MODE == MODE_CONV3 && EPI == EPI_NHWC && !__is_same(T, split_t)) {
         if (wide) { if (var == 1) IGEMM_LAUNCH(32, 1); else if (var == 2) IGEMM_LAUNCH(32, 2); else if (var == 3) IGEMM_LAUNCH(32, 3);
-                    else if (var == 4) IGEMM_LAUNCH(32, 4); else if (var == 5) IGEMM_LAUNCH(32, 5); else IGEMM_LAUNCH(32, 0); }
+                    else if (var == 4) IGEMM_LAUNCH(32, 4); else if (var == 5) IGEMM_LAUNCH(32, 5); else if (var == 6) IGEMM_LAUNCH(32, 6);
+                    else IGEMM_LAUNCH(32, 0); }
         else { if (var == 1) IGEMM_LAUNCH(16, 1); else if (var == 2) IGEMM_LAUNCH(16, 2); else IGEMM_LAUNCH(16, 0); }
     } else {
         if (wide) IGEMM_LAUNCH(32, 0); else IGEMM_LAUNCH(16, 0);
@@ -435,8 +452,10 @@ static int check_common(const IgemmParams& p, const char* who) {
     if (p.B <= 0 || p.H <= 0 || p.W <= 0) return clamd_fail("igemm: empty problem");
     if (p.Kp % 32 || p.Np % 32 || p.x_ldc % 8 || p.y_ldc % 8) return clamd_fail("igemm: channel counts/pitches must be padded (K,N %32, ldc %8)");
     // 32-bit element offsets inside the kernel
-    const long long in_elems = (long long)p.B * p.H * p.W * p.x_ldc * (who[0] == 'u' ? 4 : 1);
-    if (in_elems >= (1ll << 31)) return clamd_fail("igemm: input tensor exceeds 2^31 elements");
+    // buffer descriptors address ONE image with 32-bit byte offsets (OOB marker = 2^31)
+    const long long img_bytes = (long long)p.H * p.W * p.x_ldc * (who[0] == 'u' ? 4 : 1) * 4;
+    if (img_bytes >= (1ll << 31)) return clamd_fail("igemm: one image exceeds 2^31 bytes");
+    if ((long long)9 * p.Np * p.Kp * 4 >= (1ll << 31)) return clamd_fail("igemm: packed filter exceeds 2^31 bytes");
     return 0;
 }
 
@@ -458,7 +477,13 @@ int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* b
                   int m_fastest, int dtype, void* stream) {
     IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, m_fastest, bn_y, bn_sums};
     if (int e = check_common(p, "conv3x3")) return e;
-    if (g_igemm_ws == 1 || (g_igemm_ws == 2 && W < 32 && Cin_p >= 256)) return launch_igemm_ws(p, dtype, (hipStream_t)stream);
+    if (g_igemm_ws == 1 || g_igemm_ws == 3) return launch_igemm_ws(p, dtype, (hipStream_t)stream, g_igemm_ws == 1 ? 2 : 4);
+    if (g_igemm_ws == 2 && Cin_p >= 256) {
+        // one workgroup per CU: take the 512-pixel tile only if it still gives every CU a workgroup
+        const long long ntn = (Cout_p + 63) / 64;
+        const long long blocks4 = (long long)B * ((H + 15) / 16) * ((W + 31) / 32) * ntn;
+        return launch_igemm_ws(p, dtype, (hipStream_t)stream, (W >= 32 && blocks4 >= 224) ? 4 : 2);
+    }
     return launch<MODE_CONV3, EPI_NHWC>(p, dtype, (hipStream_t)stream);
 }
 

@@ -44,6 +44,6 @@ template <int MODE, int TW> struct Geo {
 
 
 // igemm_ws.hip: producer/consumer variant of the CONV3/NHWC kernel (same results)
-int launch_igemm_ws(const IgemmParams& p, int dtype, hipStream_t s);
+int launch_igemm_ws(const IgemmParams& p, int dtype, hipStream_t s, int mt);   // mt: 32-pixel row tiles per consumer wave (2 or 4)
 
 }  // namespace clamd

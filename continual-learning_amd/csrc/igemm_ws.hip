@@ -17,14 +17,37 @@
 
 namespace clamd {
 
-template <typename T, int TW>
+#ifdef CLAMD_DIAG
+// diagnostic build only (python build.py --diag): per-role cycle shares of the K loop, summed over workgroups
+__device__ unsigned long long g_ws_diag[8];
+#define DIAG_T() __builtin_amdgcn_s_memtime()
+#define DIAG_ADD(i_, v_) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_ws_diag[i_], (unsigned long long)(v_)); } while (0)
+#else
+#define DIAG_T() 0ull
+#define DIAG_ADD(i_, v_) do { } while (0)
+#endif
+
+// Geometry of one LDS stage for a (128*MT)-pixel x 64-channel tile (MT = 32-pixel MFMA row tiles per consumer wave).
+template <int TW, int MT> struct WsGeo {
+    static constexpr int TH = 128 * MT / TW;
+    static constexpr int NT = 9;
+    static constexpr int HW_ = TW + 2, HH_ = TH + 2;
+    static constexpr int NPIX = HW_ * HH_;
+    static constexpr int NPIXP = NPIX + ((10 - NPIX % 8) % 8);     // == 2 (mod 8)
+    static constexpr int NJ = (NPIX * 4 + 255) / 256;
+    static constexpr int IN_SLOTS = 4 * NPIXP;
+    static constexpr int WG = 66;
+    static constexpr int WT_SLOTS = NT * 4 * WG;
+};
+
+template <typename T, int TW, int MT>
 __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
-    using G = Geo<MODE_CONV3, TW>;
+    using G = WsGeo<TW, MT>;
     constexpr int TH = G::TH, NT = G::NT, HW_ = G::HW_, NPIX = G::NPIX, NPIXP = G::NPIXP, NJ = G::NJ;
     constexpr int KC = DT<T>::KC, VEC = DT<T>::VEC;
     constexpr bool SPLIT = __is_same(T, split_t);
     constexpr int STAGE = G::IN_SLOTS + G::WT_SLOTS;
-    static_assert(2 * STAGE * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4, "LDS too small for the epilogue");
+    static_assert(2 * STAGE * 16 <= 160 * 1024, "two LDS stages must fit one CU");
     __shared__ uint4 smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -32,8 +55,6 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
     const int ltid = tid & 255;                    // index inside the role (4 waves each)
     const int cw = wave & 3;                       // consumer wave index (M quarter of the tile)
     const int r = lane & 31, h = lane >> 5;
-    const T* __restrict__ xg = (const T*)p.x;
-    const T* __restrict__ wg = (const T*)p.w;
 
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     const int ntm = tiles_x * tiles_y * p.B, ntn = (p.Np + 63) >> 6;
@@ -44,9 +65,9 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
     const int n0 = tn * 64;
     const int nk = p.Kp / KC;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -54,37 +75,53 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
 
     if (producer) {
         // ------------------------------------------------------------------ producers: global -> registers -> LDS
+        constexpr int ESZ = sizeof(T);
         const int g4 = ltid & 3;
-        int in_off[NJ];
+        const unsigned img_elems = (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc;
+        const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x + (size_t)b * img_elems * ESZ, img_elems * ESZ);
+        const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.w, (unsigned)(9u * p.Np * p.Kp * ESZ));
+        unsigned in_vo[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int pix = (ltid >> 2) + 64 * j;
             const int hy = pix / HW_, hx = pix - hy * HW_;
             const int yy = y0 + hy - 1, xx = x0 + hx - 1;
-            in_off[j] = (pix < NPIX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
-                            ? ((b * p.H + yy) * p.W + xx) * p.x_ldc + g4 * VEC : -1;
+            in_vo[j] = (pix < NPIX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
+                           ? (unsigned)(((yy * p.W + xx) * p.x_ldc + g4 * VEC) * ESZ) : BUF_OOB;
         }
         const int wco = ltid >> 2;
-        const bool w_ok = n0 + wco < p.Np;
-        uint4 rin[NJ], rw[NT];
+        const unsigned w_vo = n0 + wco < p.Np ? (unsigned)(((n0 + wco) * KC + g4 * VEC) * ESZ) : BUF_OOB;
+        const unsigned w_slab = (unsigned)(p.Np * KC * ESZ);
+        // Input chunks are fetched in PAIRS (two back-to-back 64-byte pieces = one full 128-byte line per pixel while the
+        // line is still in L1): fetching one 64-byte piece per K-step, a whole period apart, made every line cross the
+        // L2->CU path twice and capped the producers at ~11.5 B/clk/CU (tools/ws_diag.py, diagnostic build).
+        uint4 rinA[NJ], rinB[NJ], rw[NT];
 
-#define WS_GLOAD(ks_)                                                                                             \
+#define WS_GLOAD_IN2(kp_)                                                                                         \
     do {                                                                                                          \
-        const int k0_ = (ks_) * KC;                                                                               \
-        _Pragma("unroll") for (int j = 0; j < NJ; ++j) rin[j] = ldg16(xg + in_off[j] + k0_, in_off[j] >= 0);      \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                            \
-            rw[t] = ldg16(wg + ((long long)((ks_) * NT + t) * p.Np + n0 + wco) * KC + g4 * VEC, w_ok);            \
+        const unsigned so_ = (unsigned)(2 * (kp_) * KC * ESZ);                                                    \
+        const bool two_ = 2 * (kp_) + 1 < nk;                      /* wave-uniform */                             \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                          \
+            rinA[j] = buf_ld16(xrs, in_vo[j], so_);                                                               \
+            if (two_) rinB[j] = buf_ld16(xrs, in_vo[j], so_ + KC * ESZ);                                          \
+        }                                                                                                         \
     } while (0)
-#define WS_STORE(st_)                                                                                             \
+#define WS_GLOAD_W(ks_)                                                                                           \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                            \
+            rw[t] = buf_ld16(wrs, w_vo, (unsigned)((ks_) * NT + t) * w_slab);                                     \
+    } while (0)
+#define WS_STORE(st_, RIN)                                                                                        \
     do {                                                                                                          \
         uint4* sm_ = smem + (st_) * STAGE;                                                                        \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                          \
             const int pix_ = (ltid >> 2) + 64 * j;                                                                \
+            const bool in_ = 64 * (j + 1) <= NPIX || pix_ < NPIX;                                                 \
             if constexpr (!SPLIT) {                                                                               \
-                if (pix_ < NPIX) sm_[g4 * NPIXP + pix_] = rin[j];                                                 \
-            } else if (pix_ < NPIX) {                                                                             \
+                if (in_) sm_[g4 * NPIXP + pix_] = RIN[j];                                                         \
+            } else if (in_) {                                                                                     \
                 uint2 hi_, lo_;                                                                                   \
-                split4(rin[j], hi_, lo_);                                                                         \
+                split4(RIN[j], hi_, lo_);                                                                         \
                 char* b_ = reinterpret_cast<char*>(sm_) + ((g4 >> 1) * NPIXP + pix_) * 16 + 8 * (g4 & 1);         \
                 *reinterpret_cast<uint2*>(b_) = hi_;                                                              \
                 *reinterpret_cast<uint2*>(b_ + 2 * NPIXP * 16) = lo_;                                             \
@@ -93,87 +130,121 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
         _Pragma("unroll") for (int t = 0; t < NT; ++t) sm_[G::IN_SLOTS + (t * 4 + g4) * G::WG + wco] = rw[t];     \
     } while (0)
 
-        WS_GLOAD(0);
-        WS_STORE(0);
-        if (nk > 1) WS_GLOAD(1);
+        unsigned long long t0 = DIAG_T(), t1, d_store = 0, d_bar = 0, d_wait = 0, d_st = 0;
+        (void)d_wait; (void)d_st;
+        WS_GLOAD_IN2(0);
+        WS_GLOAD_W(0);
+        WS_STORE(0, rinA);
+        if (nk > 1) WS_GLOAD_W(1);
         __syncthreads();                                   // stage 0 is ready
+        DIAG_ADD(0, DIAG_T() - t0);                        // [0] producer prologue
         for (int ks = 0; ks < nk; ++ks) {
-            if (ks + 1 < nk) {
-                WS_STORE((ks + 1) & 1);                    // consumers are reading stage ks&1
-                if (ks + 2 < nk) WS_GLOAD(ks + 2);         // lands during the next period
+            t0 = DIAG_T();
+#ifdef CLAMD_DIAG
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            d_wait += DIAG_T() - t0;
+#endif
+            if (ks + 1 < nk) {                             // consumers are reading stage ks&1
+                if ((ks + 1) & 1) WS_STORE((ks + 1) & 1, rinB); else WS_STORE((ks + 1) & 1, rinA);
+#ifdef CLAMD_DIAG
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                d_st += DIAG_T() - t0;
+#endif
+                if (ks + 2 < nk) {
+                    WS_GLOAD_W(ks + 2);                    // lands during the next period
+                    if ((ks + 1) & 1) WS_GLOAD_IN2((ks + 2) >> 1);   // both input buffers are free again
+                }
             }
+            t1 = DIAG_T();
             __syncthreads();
+            d_store += t1 - t0; d_bar += DIAG_T() - t1;
         }
-#undef WS_GLOAD
+        DIAG_ADD(1, d_store); DIAG_ADD(2, d_bar);          // [1] producer wait-loads+store+issue, [2] producer at barrier
+        DIAG_ADD(3, d_wait); DIAG_ADD(6, d_st);            // diag build: [3] += vmcnt wait, [6] += wait+store (cumulative)
+#undef WS_GLOAD_IN2
+#undef WS_GLOAD_W
 #undef WS_STORE
     } else {
         // ------------------------------------------------------------------ consumers: LDS fragments -> MFMA
-        int apix[2];
+        int apix[MT];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int m = 64 * cw + 32 * mt + r;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = 32 * MT * cw + 32 * mt + r;
             apix[mt] = (m / TW) * HW_ + (m % TW);
         }
+        unsigned long long c0, c1, d_cmp = 0, d_cbar = 0;
+        c0 = DIAG_T();
         __syncthreads();                                   // stage 0 is ready
+        DIAG_ADD(3, DIAG_T() - c0);                        // [3] consumer waits for the first stage
         for (int ks = 0; ks < nk; ++ks) {
+            c0 = DIAG_T();
             const uint4* sm = smem + (ks & 1) * STAGE;
             if constexpr (SPLIT) {
-                uint4 f[2][8];      // [buffer][ah0, al0, ah1, al1, bh0, bl0, bh1, bl1]
+                uint4 f[2][2 * MT + 4];      // [buffer][a_hi[mt], a_lo[mt] ..., bh0, bl0, bh1, bl1]
 #define WS_FRAG_S(t_, d_)                                                                                         \
     do {                                                                                                          \
         const int ib_ = ((t_) / 3) * HW_ + ((t_) % 3);                                                            \
-        d_[0] = sm[ib_ + h * NPIXP + apix[0]];       d_[1] = sm[ib_ + (2 + h) * NPIXP + apix[0]];                 \
-        d_[2] = sm[ib_ + h * NPIXP + apix[1]];       d_[3] = sm[ib_ + (2 + h) * NPIXP + apix[1]];                 \
-        d_[4] = sm[G::IN_SLOTS + ((t_) * 4 + h) * G::WG + r];                                                     \
-        d_[5] = sm[G::IN_SLOTS + ((t_) * 4 + 2 + h) * G::WG + r];                                                 \
-        d_[6] = sm[G::IN_SLOTS + ((t_) * 4 + h) * G::WG + 32 + r];                                                \
-        d_[7] = sm[G::IN_SLOTS + ((t_) * 4 + 2 + h) * G::WG + 32 + r];                                            \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) {                                                    \
+            d_[2 * mt_] = sm[ib_ + h * NPIXP + apix[mt_]];                                                        \
+            d_[2 * mt_ + 1] = sm[ib_ + (2 + h) * NPIXP + apix[mt_]];                                              \
+        }                                                                                                         \
+        d_[2 * MT + 0] = sm[G::IN_SLOTS + ((t_) * 4 + h) * G::WG + r];                                            \
+        d_[2 * MT + 1] = sm[G::IN_SLOTS + ((t_) * 4 + 2 + h) * G::WG + r];                                        \
+        d_[2 * MT + 2] = sm[G::IN_SLOTS + ((t_) * 4 + h) * G::WG + 32 + r];                                       \
+        d_[2 * MT + 3] = sm[G::IN_SLOTS + ((t_) * 4 + 2 + h) * G::WG + 32 + r];                                   \
     } while (0)
                 WS_FRAG_S(0, f[0]);
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);     // reads of step 0 lead; then R(s+1), M(s), ...
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 4, 0);     // reads of step 0 lead; then R(s+1), M(s), ...
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     if (t + 1 < NT) WS_FRAG_S(t + 1, f[(t + 1) & 1]);
                     const uint4* c = f[t & 1];
-                    mma_bf16(c[1], c[4], acc[0][0]); mma_bf16(c[0], c[5], acc[0][0]); mma_bf16(c[0], c[4], acc[0][0]);
-                    mma_bf16(c[1], c[6], acc[0][1]); mma_bf16(c[0], c[7], acc[0][1]); mma_bf16(c[0], c[6], acc[0][1]);
-                    mma_bf16(c[3], c[4], acc[1][0]); mma_bf16(c[2], c[5], acc[1][0]); mma_bf16(c[2], c[4], acc[1][0]);
-                    mma_bf16(c[3], c[6], acc[1][1]); mma_bf16(c[2], c[7], acc[1][1]); mma_bf16(c[2], c[6], acc[1][1]);
-                    if (t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        mma_bf16(c[2 * mt + 1], c[2 * MT + 0], acc[mt][0]); mma_bf16(c[2 * mt], c[2 * MT + 1], acc[mt][0]);
+                        mma_bf16(c[2 * mt], c[2 * MT + 0], acc[mt][0]);
+                        mma_bf16(c[2 * mt + 1], c[2 * MT + 2], acc[mt][1]); mma_bf16(c[2 * mt], c[2 * MT + 3], acc[mt][1]);
+                        mma_bf16(c[2 * mt], c[2 * MT + 2], acc[mt][1]);
+                    }
+                    if (t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT, 0);
                 }
 #undef WS_FRAG_S
             } else {
                 constexpr int NSTEP = 2 * NT;
                 constexpr int NMF = sizeof(T) == 2 ? 4 : 16;
-                uint4 f[2][4];      // [buffer][a0, a1, b0, b1]
+                uint4 f[2][MT + 2];      // [buffer][a[mt] ..., b0, b1]
 #define WS_FRAG(s_, d_)                                                                                           \
     do {                                                                                                          \
         const int t_ = (s_) >> 1, g_ = ((s_) & 1) * 2 + h;                                                        \
         const int ib_ = (t_ / 3) * HW_ + (t_ % 3);                                                                \
-        d_[0] = sm[ib_ + g_ * NPIXP + apix[0]];                                                                   \
-        d_[1] = sm[ib_ + g_ * NPIXP + apix[1]];                                                                   \
-        d_[2] = sm[G::IN_SLOTS + (t_ * 4 + g_) * G::WG + r];                                                      \
-        d_[3] = sm[G::IN_SLOTS + (t_ * 4 + g_) * G::WG + 32 + r];                                                 \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) d_[mt_] = sm[ib_ + g_ * NPIXP + apix[mt_]];          \
+        d_[MT] = sm[G::IN_SLOTS + (t_ * 4 + g_) * G::WG + r];                                                     \
+        d_[MT + 1] = sm[G::IN_SLOTS + (t_ * 4 + g_) * G::WG + 32 + r];                                            \
     } while (0)
                 WS_FRAG(0, f[0]);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // reads of step 0 lead; then R(s+1), M(s), ...
+                __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);     // reads of step 0 lead; then R(s+1), M(s), ...
 #pragma unroll
                 for (int st = 0; st < NSTEP; ++st) {
                     if (st + 1 < NSTEP) WS_FRAG(st + 1, f[(st + 1) & 1]);
                     const uint4* c = f[st & 1];
-                    mma16<T>(c[0], c[2], acc[0][0]);
-                    mma16<T>(c[0], c[3], acc[0][1]);
-                    mma16<T>(c[1], c[2], acc[1][0]);
-                    mma16<T>(c[1], c[3], acc[1][1]);
-                    if (st + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        mma16<T>(c[mt], c[MT], acc[mt][0]);
+                        mma16<T>(c[mt], c[MT + 1], acc[mt][1]);
+                    }
+                    if (st + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NMF * MT / 2, 0);
                 }
 #undef WS_FRAG
             }
+            c1 = DIAG_T();
             __syncthreads();                               // hand stage ks&1 back to the producers
+            d_cmp += c1 - c0; d_cbar += DIAG_T() - c1;
         }
+        DIAG_ADD(4, d_cmp); DIAG_ADD(5, d_cbar);           // [4] consumer MFMA loop, [5] consumer at barrier
     }
+    const unsigned long long e0 = DIAG_T();
 
     // ---------------------------------------------------------------------- epilogue (consumers work, everyone syncs)
     const bool cons = !producer;
@@ -183,16 +254,16 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
         const int n = n0 + 32 * nt + r;
         bcol[nt] = (p.bias && n < p.Np) ? p.bias[n] : 0.f;
     }
-    unsigned vmask = 0;
+    unsigned long long vmask = 0;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int m = 64 * cw + 32 * mt + acc_row(e, h);
-            if (y0 + m / TW < p.H && x0 + m % TW < p.W) vmask |= 1u << (mt * 16 + e);
+            const int m = 32 * MT * cw + 32 * mt + acc_row(e, h);
+            if (y0 + m / TW < p.H && x0 + m % TW < p.W) vmask |= 1ull << (mt * 16 + e);
         }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -207,7 +278,7 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
         if (cons) {
             float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -246,7 +317,7 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
         for (int j = 0; j < 8; ++j) bs[k][j] = 0.f;
     const bool do_bn = p.bn_y != nullptr;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         __syncthreads();
         if (cons) {
 #pragma unroll
@@ -259,7 +330,7 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 const int row = ps * 8 + (lane >> 3), cgp = lane & 7;
-                const int m = 64 * cw + 32 * mt + row;
+                const int m = 32 * MT * cw + 32 * mt + row;
                 const int yy = y0 + m / TW, xx = x0 + m % TW;
                 const int n = n0 + cgp * 8;
                 if (yy < p.H && xx < p.W && n < p.Np) {
@@ -309,24 +380,38 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
             if (n0 + c < p.Np) atomicAdd(p.bn_sums + ((size_t)(blockIdx.x % STAT_REPLICAS) * 5 + k) * p.Np + n0 + c, t);
         }
     }
+    if (wave == 0) DIAG_ADD(6, DIAG_T() - e0);             // [6] epilogue (one wave per workgroup)
+    if (wave == 0) DIAG_ADD(7, 1);                         // [7] workgroups
 }
 
 template <typename T>
-static int launch_ws_t(const IgemmParams& p, hipStream_t s) {
+static int launch_ws_t(const IgemmParams& p, hipStream_t s, int mt) {
     const bool wide = p.W >= 32;
-    const int TW = wide ? 32 : 16, TH = 256 / TW;
+    if (!wide) mt = 2;                       // 16-wide tiles: 256 pixels (16 x 16)
+    const int TW = wide ? 32 : 16, TH = 128 * mt / TW;
     const long long tiles = (long long)((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.B;
     const long long nblk = tiles * ((p.Np + 63) / 64);
     if (nblk <= 0 || nblk > 0x7fffffff) return clamd_fail("igemm_ws: grid out of range");
-    if (wide) hipLaunchKernelGGL((igemm_ws_kernel<T, 32>), dim3((unsigned)nblk), dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((igemm_ws_kernel<T, 16>), dim3((unsigned)nblk), dim3(512), 0, s, p);
+    if (!wide) hipLaunchKernelGGL((igemm_ws_kernel<T, 16, 2>), dim3((unsigned)nblk), dim3(512), 0, s, p);
+    else if (mt == 4) hipLaunchKernelGGL((igemm_ws_kernel<T, 32, 4>), dim3((unsigned)nblk), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((igemm_ws_kernel<T, 32, 2>), dim3((unsigned)nblk), dim3(512), 0, s, p);
     return clamd_check_launch("igemm_ws");
 }
 
-int launch_igemm_ws(const IgemmParams& p, int dtype, hipStream_t s) {
-    if (dtype == CLAMD_BF16) return launch_ws_t<bf16_t>(p, s);
-    if (dtype == CLAMD_F32) return launch_ws_t<float>(p, s);
-    if (dtype == CLAMD_SPLIT) return launch_ws_t<split_t>(p, s);
+}  // namespace clamd
+#ifdef CLAMD_DIAG
+extern "C" int clamd_debug_ws_diag(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(clamd::g_ws_diag), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(clamd::g_ws_diag), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+namespace clamd {
+
+int launch_igemm_ws(const IgemmParams& p, int dtype, hipStream_t s, int mt) {
+    if (dtype == CLAMD_BF16) return launch_ws_t<bf16_t>(p, s, mt);
+    if (dtype == CLAMD_F32) return launch_ws_t<float>(p, s, mt);
+    if (dtype == CLAMD_SPLIT) return launch_ws_t<split_t>(p, s, mt);
     return clamd_fail("igemm_ws: bad dtype");
 }
 

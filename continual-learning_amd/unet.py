@@ -17,6 +17,8 @@ from .ops import PackTable, cpad
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
+FUSE_BN_SUMS = False     # see _Engine.__init__: fused BN-backward sums in the dgrad epilogue measured slower in situ
+
 # bench.py sets this to a list to get per-launch HIP-event timings of the MFMA kernels:
 # entries (tag, algorithmic_flops, start_event, end_event), recorded on the stream the kernel is launched on.
 KERNEL_TIMING = None
@@ -226,8 +228,10 @@ class _Engine:
             b.g_in = act(k, cpad(cout))                             # grad w.r.t. ua
             a.g_src = (b.g_in, b.g_in.shape[-1], None)               # where conv a's BN-output gradient comes from
             b.g_src = (self.gcat[k], self.gcat[k].shape[-1], self.gpool[k])
-            # b's data-gradient kernel writes the gradient w.r.t. a's BatchNorm output: it also accumulates a's BN-bwd sums
-            b.consumer, a.fused_reduce = a, True
+            # The data-gradient kernels CAN accumulate the consumer's BN-backward sums in their epilogue (bn_y/bn_sums
+            # arguments, covered by tests), but in situ that made every dgrad launch 30-80 us slower (the epilogue is
+            # instruction-bound) while the separate HBM-bound reduce pass it replaces costs ~33 us: disabled (FUSE_BN_SUMS).
+            b.consumer, a.fused_reduce = (a, True) if FUSE_BN_SUMS else (None, False)
             a.consumer, b.fused_reduce = None, False                # a's dgrad feeds a pooled / concat gradient: separate reduce
             self.stages.append(dict(kind='enc', convs=(a, b)))
             prev = (self.pool[k], self.pool[k].shape[-1], [(cout, cpad(cout))])
@@ -251,8 +255,8 @@ class _Engine:
             g_ub = act(level, cpad(mid))
             a.g_src = (b.g_in, b.g_in.shape[-1], None)
             b.g_src = (g_ub, g_ub.shape[-1], None)
-            b.consumer, a.fused_reduce = a, True
-            a.consumer, b.fused_reduce = None, True                 # b's gradient comes from the tail's data-gradient kernel
+            b.consumer, a.fused_reduce = (a, True) if FUSE_BN_SUMS else (None, False)
+            a.consumer, b.fused_reduce = None, FUSE_BN_SUMS         # b's gradient comes from the tail's data-gradient kernel
             kind, ti, tcin, tcout = st['tail']
             tail = _Conv()
             tail.kind = kind
@@ -260,7 +264,7 @@ class _Engine:
             tail.keys = (f'{pre}.{ti}.weight', f'{pre}.{ti}.bias')
             tail.cin, tail.cin_p, tail.cout = tcin, cpad(tcin), tcout
             tail.x, tail.g_x, tail.level = ub, g_ub, level
-            tail.consumer = b
+            tail.consumer = b if FUSE_BN_SUMS else None
             if kind == 'convT':
                 tail.cout_p = cpad(tcout)
                 tail.wf = torch.zeros(4 * tail.cout_p * tail.cin_p, dtype=T, device=dev)
@@ -413,7 +417,8 @@ class _Engine:
                          t.cout, t.cout_p, t.cin, t.cin_p, dc, s)
                     call('clamd_channel_sum', ptr(self.dl), self.Kp, g[t.keys[1]], B * h * w, self.Kp, t.cout, dc, s)
                     call('clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], None,
-                         ptr(t.consumer.y), ptr(t.consumer.sums), B, h, w, t.cout_p, t.cin_p, 0, dc, s)
+                         ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
+                         B, h, w, t.cout_p, t.cin_p, 0, dc, s)
                 else:
                     call('clamd_wgrad', _lib.WGRAD_UP2, ptr(t.x), t.x.shape[-1], ptr(t.gy_slice), t.y_ldc, ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cin_p, t.cout_p, t.cin, t.cout,
@@ -421,7 +426,8 @@ class _Engine:
                     call('clamd_channel_sum', ptr(t.gy_slice), t.y_ldc, g[t.keys[1]], B * 4 * h * w, t.cout_p,
                          t.cout, dc, s)
                     call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
-                         ptr(t.consumer.y), ptr(t.consumer.sums), B, h, w, t.cin_p, t.cout_p, dc, s)
+                         ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
+                         B, h, w, t.cin_p, t.cout_p, dc, s)
             for u in reversed(st['convs']):
                 self._conv_bwd(u, s)
             if sync is not None:

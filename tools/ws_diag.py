@@ -1,0 +1,29 @@
+"""Diagnostic (needs `python continual-learning_amd/build.py --diag`): cycle shares of the producer/consumer igemm."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import continual_learning_amd as C
+from continual_learning_amd._lib import call, ptr
+lib = ctypes.CDLL(C._lib.LIB_PATH)
+dt = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+mode = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dc = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[dt]
+T = C.ops.TORCH_DT[dc]
+B = 16
+C._lib.load().clamd_set_tuning(b'igemm_ws', mode)
+out = (ctypes.c_ulonglong * 8)()
+for cin, cout, hw in [(64, 64, 256), (256, 256, 64), (1024, 512, 32)]:
+    x = torch.randn(B, hw, hw, cin, device='cuda').to(T)
+    w = torch.randn(cout, cin, 3, 3, device='cuda') / (3 * cin ** 0.5)
+    wf = torch.zeros(9 * cout * cin, dtype=T, device='cuda'); bias = torch.zeros(cout, device='cuda')
+    tab = C.ops.PackTable(dc); tab.conv3x3(w, wf, None, [(cin, cin)], cout); tab.finalize('cuda').run(dc)
+    y = torch.empty(B, hw, hw, cout, dtype=T, device='cuda'); stats = torch.zeros(16, 2, cout, device='cuda')
+    s = C._lib.stream_ptr()
+    for _ in range(2):
+        call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, B, hw, hw, cin, cout, 1, 0, dc, s)
+    torch.cuda.synchronize(); lib.clamd_debug_ws_diag(out, 1)
+    call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, B, hw, hw, cin, cout, 1, 0, dc, s)
+    torch.cuda.synchronize(); lib.clamd_debug_ws_diag(out, 1)
+    v = list(out); nb = max(v[7], 1)
+    names = ['prod prologue', 'prod load-wait+store+issue', 'prod at barrier', 'cons wait stage0 + PROD vmcnt wait', 'cons MFMA loop', 'cons at barrier', 'epilogue + PROD wait+store']
+    print(f'{cin}->{cout}@{hw}: blocks {nb}; per-wave cycles per block: ' + ', '.join(f'{n} {v[i] / (nb * 4):.0f}' for i, n in enumerate(names)))
