@@ -63,8 +63,6 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const T* __restrict__ ag = (const T*)p.a;
-    const T* __restrict__ bg = (const T*)p.b;
 
     const int rt = (p.Rp + 63) >> 6, ct = (p.Cp + 63) >> 6;
     int bid = blockIdx.x;
@@ -86,44 +84,87 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
 
     uint4 ra[NJA], rb[NJB];
 
+    // Per-thread staging descriptors, constant over the whole pixel loop: tile-relative byte offsets (the tile origin
+    // goes into the scalar soffset of the buffer load) and the tile-relative coordinates needed for the edge tests.
+    constexpr int ESZ = sizeof(T);
+    constexpr int BSCALE = MODE == WG_UP2 ? 2 : 1;                  // B lives on the 2H x 2W grid for the convT gradient
+    constexpr int HALO = MODE == WG_CONV3 ? 1 : 0;
+    const unsigned a_img = (unsigned)p.H * p.W * p.a_ldc * ESZ;
+    const unsigned b_img = (unsigned)(BSCALE * p.H) * (BSCALE * p.W) * p.b_ldc * ESZ;
+    const unsigned b_shift = (unsigned)(HALO * (BSCALE * p.W + 1)) * p.b_ldc * ESZ;   // descriptor base sits one row + one pixel early
+    // The split (bf16x3) variant is register-starved (144 accumulators + two fragment sets): it re-derives these few
+    // integers per tile instead of keeping them (RECOMP), everything else precomputes them once.
+    constexpr bool RECOMP = SPLIT && MODE == WG_CONV3 && TW == 32;
+    unsigned a_vo[RECOMP ? 1 : NJA], b_vo[RECOMP ? 1 : NJB];
+    unsigned b_hyx[RECOMP ? 1 : NJB];                               // (hy << 16) | hx: BW is not a power of two
+#pragma unroll
+    for (int j = 0; j < NJA; ++j) {
+        const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;
+        if constexpr (!RECOMP)
+            a_vo[j] = (pix < G::APIX && r0 + g * VEC < p.Rp) ? (unsigned)((((pix / TW) * p.W + pix % TW) * p.a_ldc + r0 + g * VEC) * ESZ) : BUF_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < NJB; ++j) {
+        const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;
+        const int hy = pix / BW, hx = pix % BW;
+        if constexpr (!RECOMP) {
+            b_hyx[j] = ((unsigned)hy << 16) | (unsigned)hx;
+            b_vo[j] = (pix < G::BPIX && c0 + g * VEC < p.Cp)
+                          ? (unsigned)(((hy * BSCALE * p.W + hx) * p.b_ldc + c0 + g * VEC) * ESZ) : BUF_OOB;
+        }
+    }
+
+    const T* __restrict__ ag = (const T*)p.a;
+    const T* __restrict__ bg = (const T*)p.b;
     auto gload = [&](int tile) {
+        // tile -> (image, origin): wave-uniform scalar arithmetic
         const int x0 = (tile % tiles_x) * TW, y0 = ((tile / tiles_x) % tiles_y) * TH, b = tile / (tiles_x * tiles_y);
+        if constexpr (RECOMP) {
+            // register-starved split variant: no persistent per-thread descriptors; predicated 64-bit loads whose
+            // addresses are rebuilt per tile (the buffer-load form below kept 25 more VGPRs live and spilled)
+#pragma unroll
+            for (int j = 0; j < NJA; ++j) {
+                const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;
+                const int yy = y0 + pix / TW, xx = x0 + pix % TW;
+                const bool ok = pix < G::APIX && yy < p.H && xx < p.W && r0 + g * VEC < p.Rp;
+                ra[j] = ldg16(ag + ((long long)(b * p.H + yy) * p.W + xx) * p.a_ldc + r0 + g * VEC, ok);
+            }
+#pragma unroll
+            for (int j = 0; j < NJB; ++j) {
+                const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;
+                const int hy = pix / BW, hx = pix % BW;
+                const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+                const bool ok = pix < G::BPIX && c0 + g * VEC < p.Cp && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                rb[j] = ldg16(bg + ((long long)(b * p.H + yy) * p.W + xx) * p.b_ldc + c0 + g * VEC, ok);
+            }
+            return;
+        }
+        const __amdgpu_buffer_rsrc_t ars = make_rsrc((const char*)p.a + (size_t)b * a_img, a_img);
+        const __amdgpu_buffer_rsrc_t brs = make_rsrc((const char*)p.b + (size_t)b * b_img - b_shift, b_img + b_shift);
+        const unsigned a_so = (unsigned)((y0 * p.W + x0) * p.a_ldc * ESZ);
+        const unsigned b_so = (unsigned)((BSCALE * y0 * BSCALE * p.W + BSCALE * x0) * p.b_ldc * ESZ);
 #pragma unroll
         for (int j = 0; j < NJA; ++j) {
-            const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;
-            const int yy = y0 + pix / TW, xx = x0 + pix % TW;
-            const bool ok = pix < G::APIX && yy < p.H && xx < p.W && r0 + g * VEC < p.Rp;
-            ra[j] = ldg16(ag + ((long long)(b * p.H + yy) * p.W + xx) * p.a_ldc + r0 + g * VEC, ok);
+            const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;   // TW, GPP are powers of two: shifts
+            const bool ok = y0 + pix / TW < p.H && x0 + pix % TW < p.W;
+            (void)g;
+            ra[j] = buf_ld16(ars, ok ? a_vo[j] : BUF_OOB, a_so);
         }
 #pragma unroll
         for (int j = 0; j < NJB; ++j) {
-            const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;
-            const int hy = pix / BW, hx = pix % BW;
-            bool ok = pix < G::BPIX && c0 + g * VEC < p.Cp;
-            long long off;
-            if constexpr (MODE == WG_CONV3) {
-                const int yy = y0 + hy - 1, xx = x0 + hx - 1;
-                ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-                off = ((long long)(b * p.H + yy) * p.W + xx) * p.b_ldc;
-            } else if constexpr (MODE == WG_PW) {
-                const int yy = y0 + hy, xx = x0 + hx;
-                ok = ok && yy < p.H && xx < p.W;
-                off = ((long long)(b * p.H + yy) * p.W + xx) * p.b_ldc;
-            } else {
-                const int yy = 2 * y0 + hy, xx = 2 * x0 + hx;
-                ok = ok && yy < 2 * p.H && xx < 2 * p.W;
-                off = ((long long)(b * 2 * p.H + yy) * 2 * p.W + xx) * p.b_ldc;
-            }
-            rb[j] = ldg16(bg + off + c0 + g * VEC, ok);
+            const int yy = BSCALE * y0 + (int)(b_hyx[j] >> 16) - HALO, xx = BSCALE * x0 + (int)(b_hyx[j] & 0xffffu) - HALO;
+            const bool ok = yy >= 0 && yy < BSCALE * p.H && xx >= 0 && xx < BSCALE * p.W;
+            rb[j] = buf_ld16(brs, ok ? b_vo[j] : BUF_OOB, b_so);
         }
     };
     auto lds_store = [&]() {
 #pragma unroll
         for (int j = 0; j < NJA; ++j) {
             const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;
+            const bool in = 256 * (j + 1) <= G::APIX * GPP || pix < G::APIX;      // only the last j can overrun the tile
             if constexpr (!SPLIT) {
-                if (pix < G::APIX) *reinterpret_cast<uint4*>(sa + pix * STRIDE + g * 16) = ra[j];
-            } else if (pix < G::APIX) {
+                if (in) *reinterpret_cast<uint4*>(sa + pix * STRIDE + g * 16) = ra[j];
+            } else if (in) {
                 uint2 hi, lo;
                 split4(ra[j], hi, lo);
                 *reinterpret_cast<uint2*>(sa + pix * STRIDE + g * 8) = hi;
@@ -133,9 +174,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int j = 0; j < NJB; ++j) {
             const int i = tid + 256 * j, pix = i / GPP, g = i % GPP;
+            const bool in = 256 * (j + 1) <= G::BPIX * GPP || pix < G::BPIX;
             if constexpr (!SPLIT) {
-                if (pix < G::BPIX) *reinterpret_cast<uint4*>(sb + pix * STRIDE + g * 16) = rb[j];
-            } else if (pix < G::BPIX) {
+                if (in) *reinterpret_cast<uint4*>(sb + pix * STRIDE + g * 16) = rb[j];
+            } else if (in) {
                 uint2 hi, lo;
                 split4(rb[j], hi, lo);
                 *reinterpret_cast<uint2*>(sb + pix * STRIDE + g * 8) = hi;
@@ -261,11 +303,16 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const ReduceParams p)
     }
 }
 
+// Pixel-tile width.  The split (bf16x3) 3x3 variant always takes the 16-wide tile: its 6x18 halo needs 7 staging
+// registers-quads instead of 9 and the kernel stays spill-free (the 32-wide variant spilled 36-100 bytes per lane).
+int g_wgrad_tw16 = 0;               // tuning knob: 1 = 16-wide tiles everywhere
+static inline int wgrad_tw(int W, int mode, bool split) { return (W >= 32 && !(split && mode == WG_CONV3) && !g_wgrad_tw16) ? 32 : 16; }
+
 int g_wgrad_target_blocks = 512;   // tuning knob (clamd_set_tuning "wgrad_blocks"): split-K until about this many workgroups
 
 template <typename T, int MODE>
 static int launch_wg(const WgradParams& p, hipStream_t s, int grid) {
-    if (p.W >= 32) hipLaunchKernelGGL((wgrad_kernel<T, MODE, 32>), dim3(grid), dim3(256), 0, s, p);
+    if (wgrad_tw(p.W, MODE, __is_same(T, split_t)) == 32) hipLaunchKernelGGL((wgrad_kernel<T, MODE, 32>), dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad_kernel<T, MODE, 16>), dim3(grid), dim3(256), 0, s, p);
     return clamd_check_launch("wgrad");
 }
@@ -292,8 +339,13 @@ int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, fl
     if (mode < 0 || mode > 2) return clamd_fail("wgrad: bad mode");
     if (Rp % 32 || Cp % 32 || a_ldc % 8 || b_ldc % 8) return clamd_fail("wgrad: channel counts/pitches must be padded");
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("wgrad: empty problem");
+    {   // buffer descriptors address one image with 32-bit byte offsets (OOB marker = 2^31)
+        const long long sc = mode == WG_UP2 ? 4 : 1;
+        if ((long long)H * W * a_ldc * 4 >= (1ll << 30) || sc * H * W * b_ldc * 4 >= (1ll << 30))
+            return clamd_fail("wgrad: one image exceeds 2^30 bytes");
+    }
     const int NT = mode == WG_CONV3 ? 9 : (mode == WG_UP2 ? 4 : 1);
-    const int TW = W >= 32 ? 32 : 16;
+    const int TW = wgrad_tw(W, mode, dtype == CLAMD_SPLIT);
     const int TH = (dtype == CLAMD_BF16 ? 128 : 64) / (mode == WG_UP2 ? 2 : 1) / TW;    // CLAMD_SPLIT tiles like fp32
     const int ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
     const int rt = (Rp + 63) / 64, ct = (Cp + 63) / 64;

@@ -281,15 +281,19 @@ def test_gradsync_rccl_world1_on_gpu(C):
                 gs = C.ddp.GradSync(m, opt, min_bucket_bytes=16 << 10)
                 assert opt.grad_scale == 1.0
             crit = C.CrossEntropyLoss()
-            for _ in range(2):
-                out = m(x); opt.zero_grad(); loss = crit(out, y); loss.backward(); opt.step()
+            out = m(x); opt.zero_grad(); loss = crit(out, y); loss.backward()
+            if use_ddp:
+                gs.wait()
+            grads = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+            w_before = m.state_dict()['dec2.block.0.weight'].clone()
+            opt.step()
             torch.cuda.synchronize()
-            outs.append((float(loss), m.state_dict()['dec2.block.0.weight'].clone()))
-        # BN statistics are accumulated with float atomics (order varies run to run) and Adam's first steps are
-        # sign-like, so two runs agree to ~1e-5 absolute, not bitwise
+            outs.append((float(loss), grads, float((m.state_dict()['dec2.block.0.weight'] - w_before).abs().max())))
+        # same seed, same data: the all-reduced (world 1) gradients equal the plain ones up to the run-to-run noise of
+        # the float-atomic BatchNorm statistics; Adam moved the weights in both runs
         assert abs(outs[0][0] - outs[1][0]) < 1e-4
-        d = (outs[0][1] - outs[1][1]).abs()
-        assert float(d.max()) <= 2.5e-3 and float((d > 1e-4).float().mean()) < 0.05      # <= 2 steps x lr, rarely
+        assert float((outs[0][1] - outs[1][1]).norm() / outs[0][1].norm()) < 1e-3
+        assert outs[0][2] > 0 and outs[1][2] > 0
     finally:
         if created:
             dist.destroy_process_group()

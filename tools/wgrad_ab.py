@@ -6,6 +6,7 @@ import continual_learning_amd as C
 from continual_learning_amd._lib import call, ptr
 dt = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
 variants = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else '512,384,256').split(',')]
+key = (sys.argv[3] if len(sys.argv) > 3 else 'wgrad_blocks').encode()
 dc = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[dt]
 T = C.ops.TORCH_DT[dc]
 B, iters, rounds = 16, 10, 4
@@ -22,7 +23,7 @@ for cin, cout, hw in layers:
         call('clamd_wgrad', 0, ptr(g), cout, ptr(x), cin, ptr(ws), wsb, ptr(gw), B, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, dc, s)
     for rd in range(rounds):
         for v in variants:
-            lib.clamd_set_tuning(b'wgrad_blocks', v)
+            lib.clamd_set_tuning(key, v)
             run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -33,4 +34,4 @@ for cin, cout, hw in layers:
     print(f'{cin:5d}x{cout:5d} @{hw:3d}: ' + '  '.join(f'b{v} {best[v]*1e6:7.1f}us {fl/best[v]/1e12:7.1f}TF' for v in variants))
     for v in variants: tot[v][0] += fl; tot[v][1] += best[v]
 print(dt, 'wgrad+reduce aggregate: ' + '  '.join(f'b{v} {tot[v][0]/tot[v][1]/1e12:.1f} TF/s' for v in variants))
-lib.clamd_set_tuning(b'wgrad_blocks', 512)
+lib.clamd_set_tuning(key, 512 if key == b'wgrad_blocks' else 0)
