@@ -46,6 +46,8 @@ SIGNATURES = {
     'clamd_ce_fwd_bwd': (_I, [_P, _P, _P, _I, _I, _D, _D, _P, _P, _P, _SZ, _I, _I, _I, _I, _LL, _D, _P]),
     'clamd_adam_step': (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
     'clamd_argmax_confusion': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'clamd_voc_prepare': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'clamd_label_to_rgb': (_I, [_P, _P, _LL, _LL, _P]),
     'clamd_fill_f32': (_I, [_P, _LL, _D, _P]),
     'clamd_set_tuning': (_I, [c_char_p, _I]),
 }

@@ -296,6 +296,62 @@ __global__ void argmax_confusion_kernel(const float* __restrict__ logits, const 
             if (hist[i]) atomicAdd(&conf[i], (unsigned long long)hist[i]);
 }
 
+// ------------------------------------------------------------------------------------------------ data path
+// the reference's per-sample CPU pipeline
+//   image: transforms.Pad(10) -> CenterCrop(h,w) -> ToTensor -> Normalize(0.5,0.5)        (main.py:18-23)
+//   mask : Pad(10) -> CenterCrop(h,w) -> voc.to_mask (per-pixel Python loop over a 22-colour palette; void -> 0)
+//                                                                                     (datasets/voc.py:56-72,140-142)
+// as one kernel on interleaved uint8 RGB inputs.  Pad fills with 0 (torchvision default); CenterCrop of an image
+// smaller than the crop pads with 0 as torchvision.transforms.functional.center_crop does.  (oy, ox) = position of the
+// padded-and-cropped window's origin inside the source image (may be negative), computed on the host.
+__constant__ unsigned int c_voc_palette[22] = {
+    0x000000, 0x800000, 0x008000, 0x808000, 0x000080, 0x800080, 0x008080, 0x808080, 0x400000, 0xC00000, 0x408000,
+    0xC08000, 0x400080, 0xC00080, 0x408080, 0xC08080, 0x004000, 0x804000, 0x00C000, 0x80C000, 0x004080, 0xE0E0C0};
+
+__global__ void voc_prepare_kernel(const unsigned char* __restrict__ img, const unsigned char* __restrict__ mask,
+                                   float* image_out, long long* label_out, int Hs, int Ws, int oy, int ox, int h, int w,
+                                   unsigned int* bad) {
+    const int n = h * w;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int y = i / w, x = i - y * w;
+        const int sy = y + oy, sx = x + ox;
+        const bool in = sy >= 0 && sy < Hs && sx >= 0 && sx < Ws;
+        if (image_out) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = in ? (float)img[((long long)sy * Ws + sx) * 3 + c] / 255.f : 0.f;   // ToTensor
+                image_out[(long long)c * n + i] = (v - 0.5f) / 0.5f;                                 // Normalize(0.5, 0.5)
+            }
+        }
+        if (label_out) {
+            unsigned int key = 0;
+            if (in) {
+                const unsigned char* m = mask + ((long long)sy * Ws + sx) * 3;
+                key = ((unsigned int)m[0] << 16) | ((unsigned int)m[1] << 8) | m[2];
+            }
+            int cls = -1;
+#pragma unroll
+            for (int k = 0; k < 22; ++k) cls = (cls < 0 && c_voc_palette[k] == key) ? k : cls;
+            if (cls == 21) cls = 0;                      // void -> background (voc.py:67-68)
+            if (cls < 0) { atomicAdd(bad, 1u); cls = 0; }   // the reference raises ValueError (list.index): reported to the host
+            label_out[i] = cls;
+        }
+    }
+}
+
+// labels [N,H,W] int64 -> RGB [N,3,H,W] float64-compatible values as float (datasets/voc.py:74-89 to_rgb), classes >= 22 -> 0
+__global__ void label_to_rgb_kernel(const long long* __restrict__ labels, float* rgb, long long n_img, long long hw) {
+    const long long n = n_img * hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / hw, p = i - b * hw;
+        const long long l = labels[i];
+        const unsigned int key = (l >= 0 && l < 22) ? c_voc_palette[l] : 0u;
+        rgb[(b * 3 + 0) * hw + p] = (float)((key >> 16) & 255u);
+        rgb[(b * 3 + 1) * hw + p] = (float)((key >> 8) & 255u);
+        rgb[(b * 3 + 2) * hw + p] = (float)(key & 255u);
+    }
+}
+
 __global__ void fill_kernel(float* p, long long n, float v) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -370,6 +426,26 @@ int clamd_argmax_confusion(const float* logits, const long long* labels, long lo
     hipLaunchKernelGGL(argmax_confusion_kernel, dim3(g), dim3(256), Kc * Kc * sizeof(unsigned int), (hipStream_t)stream,
                        logits, labels, pred, conf, B, K, Kc, (long long)H * W);
     return clamd_check_launch("argmax_confusion");
+}
+
+int clamd_voc_prepare(const unsigned char* img_rgb, const unsigned char* mask_rgb, float* image_out, long long* label_out,
+                      int Hs, int Ws, int oy, int ox, int h, int w, unsigned int* bad_count, void* stream) {
+    if ((!image_out && !label_out) || h <= 0 || w <= 0 || Hs <= 0 || Ws <= 0) return clamd_fail("voc_prepare: bad arguments");
+    if ((image_out && !img_rgb) || (label_out && (!mask_rgb || !bad_count))) return clamd_fail("voc_prepare: missing input");
+    int g = (h * w + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(voc_prepare_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, img_rgb, mask_rgb, image_out, label_out,
+                       Hs, Ws, oy, ox, h, w, bad_count);
+    return clamd_check_launch("voc_prepare");
+}
+
+int clamd_label_to_rgb(const long long* labels, float* rgb, long long n_img, long long hw, void* stream) {
+    long long n = n_img * hw;
+    int g = (int)((n + 255) / 256);
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(label_to_rgb_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, labels, rgb, n_img, hw);
+    return clamd_check_launch("label_to_rgb");
 }
 
 int clamd_fill_f32(float* p, long long n, double v, void* stream) {

@@ -283,21 +283,31 @@ __device__ inline int wg_phys2log(int p, int seg0, int seg0p, int L) {
 }
 
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const ReduceParams p) {
-    __shared__ float red[4][64];
+    // 64 lanes x 4 consecutive (t,rp,cp) elements (16-byte loads, 1 KB per wave row) x 4 split-phases per block
+    __shared__ float4 red[4][64];
     const int le = threadIdx.x & 63, kp = threadIdx.x >> 6;
-    const long long E = (long long)p.NT * p.Rp * p.Cp;
-    for (long long base = (long long)blockIdx.x * 64; base < E; base += (long long)gridDim.x * 64) {
-        const long long e = base + le;
-        float s = 0.f;
+    const long long E = (long long)p.NT * p.Rp * p.Cp;          // multiple of 4 (Cp % 32 == 0)
+    for (long long base = (long long)blockIdx.x * 256; base < E; base += (long long)gridDim.x * 256) {
+        const long long e = base + 4 * le;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e < E)
-            for (int k = kp; k < p.nsplit; k += 4) s += p.partial[(size_t)k * E + e];
+            for (int k = kp; k < p.nsplit; k += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(p.partial + (size_t)k * E + e);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
         red[kp][le] = s;
         __syncthreads();
         if (kp == 0 && e < E) {
-            s = (red[0][le] + red[1][le]) + (red[2][le] + red[3][le]);
-            const int cp = (int)(e % p.Cp), rp = (int)((e / p.Cp) % p.Rp), t = (int)(e / ((long long)p.Cp * p.Rp));
-            const int rl = wg_phys2log(rp, p.r_seg0, p.r_seg0p, p.R), cl = wg_phys2log(cp, p.c_seg0, p.c_seg0p, p.C);
-            if (rl >= 0 && cl >= 0) p.out[((long long)rl * p.C + cl) * p.NT + t] = s;
+            const float4 a = red[0][le], b = red[1][le], c = red[2][le], d = red[3][le];
+            const float out4[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
+                                   (a.w + b.w) + (c.w + d.w)};
+            const int cp0 = (int)(e % p.Cp), rp = (int)((e / p.Cp) % p.Rp), t = (int)(e / ((long long)p.Cp * p.Rp));
+            const int rl = wg_phys2log(rp, p.r_seg0, p.r_seg0p, p.R);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cl = wg_phys2log(cp0 + i, p.c_seg0, p.c_seg0p, p.C);
+                if (rl >= 0 && cl >= 0) p.out[((long long)rl * p.C + cl) * p.NT + t] = out4[i];
+            }
         }
         __syncthreads();
     }
@@ -373,7 +383,7 @@ int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, fl
     if (e) return e;
     ReduceParams rp{workspace, out, nsplit, NT, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p};
     const long long n = (long long)NT * Rp * Cp;
-    int g = (int)((n + 63) / 64);
+    int g = (int)((n + 255) / 256);
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, s, rp);
     return clamd_check_launch("wgrad_reduce");

@@ -13,6 +13,7 @@ Continual learning (config 4): ``begin_task2(c_old, ...)`` snapshots the model a
 DistillationCrossEntropy and/or enables the L2-to-old-weights term (both build-defined).
 """
 import copy
+import os
 import warnings
 from types import SimpleNamespace
 
@@ -61,6 +62,55 @@ class Trainer:
         self.distill = DistillationCrossEntropy(c_old, temperature, distill_lambda) if distill_lambda > 0 else None
         if l2_lambda > 0:
             self.optim.set_l2_anchor([p.detach().clone() for p in self.old_model.parameters()], l2_lambda)
+
+    # ---- checkpoints: same file name and keys as trainer.py:68-102, but the model never leaves
+    # the GPU: the reference does network.cpu() ... network.cuda() (a full D2H + H2D round trip of 124 MB every
+    # epoch, trainer.py:75,80-81,258); here the state is copied into pinned host buffers on a side stream.
+    def snapshot(self, epoch):
+        """Starts an asynchronous device->pinned-host copy of model/optimizer state; returns a handle for write()."""
+        if not hasattr(self, '_snap_stream'):
+            self._snap_stream = torch.cuda.Stream()
+            self._snap_bufs = {}
+        st = self._snap_stream
+        st.wait_stream(torch.cuda.current_stream())
+        host = {}
+        with torch.cuda.stream(st):
+            for k, v in self.model.state_dict().items():
+                buf = self._snap_bufs.get(k)
+                if buf is None or buf.shape != v.shape or buf.dtype != v.dtype:
+                    buf = self._snap_bufs[k] = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                buf.copy_(v, non_blocking=True)
+                host[k] = buf
+            opt = self.optim.state_dict()
+            opt_host = {'param_groups': opt['param_groups'],
+                        'state': {i: {n: (t.to('cpu', non_blocking=True) if torch.is_tensor(t) and t.is_cuda else t)
+                                      for n, t in s.items()} for i, s in opt['state'].items()}}
+            done = torch.cuda.Event()
+            done.record(st)
+        return {'epoch': epoch + 1, 'model_state': host, 'optimizer_state': opt_host,
+                'scheduler_state': self.scheduler.state_dict(), '_event': done}
+
+    def save_network(self, network_label, epoch_label, epoch, save_dir):
+        """trainer.py:68-81: '<epoch_label>_net_<network_label>.pth' with keys epoch/model_state/optimizer_state/
+        scheduler_state (loadable by the reference's load_network and by torch.optim.Adam)."""
+        snap = self.snapshot(epoch)
+        snap.pop('_event').synchronize()
+        snap['model_state'] = {k: v.clone() for k, v in snap['model_state'].items()}   # pinned buffers are reused
+        path = os.path.join(save_dir, '%s_net_%s.pth' % (epoch_label, network_label))
+        torch.save(snap, path)
+        return path
+
+    def load_network(self, network_label, epoch_label, save_dir):
+        """trainer.py:84-102 (without the bare except that hides load errors there)."""
+        path = os.path.join(save_dir, '%s_net_%s.pth' % (epoch_label, network_label))
+        if not os.path.isfile(path):
+            return False
+        ck = torch.load(path, map_location='cpu', weights_only=False)
+        self.model.load_state_dict(ck['model_state'])
+        self.start_epoch = ck['epoch']
+        self.optim.load_state_dict(ck['optimizer_state'])
+        self.scheduler.load_state_dict(ck['scheduler_state'])
+        return True
 
     def train_step(self, inputs, labels):
         """trainer.py:172-176."""

@@ -129,6 +129,14 @@ int clamd_adam_step(const void* tensors_dev, const void* chunks_dev, int nchunks
 /* argmax over classes + confusion matrix (trainer.py:183-188, metrics.py:32-38). */
 int clamd_argmax_confusion(const float* logits, const long long* labels, long long* pred, unsigned long long* conf,
                            int B, int K, int Kc, int H, int W, void* stream);
+/* Data path: Pad(10)+CenterCrop+ToTensor+Normalize(0.5,0.5) of an interleaved uint8 RGB image
+ * (main.py:18-23) -> image_out fp32 [3,h,w]; Pad+CenterCrop+voc.to_mask of the RGB mask (datasets/voc.py:56-72,
+ * 140-142) -> label_out int64 [h,w] (void -> 0).  (oy, ox): source coordinate of output pixel (0,0).  Pixels whose
+ * colour is not in the palette are counted in *bad_count (the reference raises ValueError) and set to 0. */
+int clamd_voc_prepare(const unsigned char* img_rgb, const unsigned char* mask_rgb, float* image_out, long long* label_out,
+                      int Hs, int Ws, int oy, int ox, int h, int w, unsigned int* bad_count, void* stream);
+/* voc.to_rgb (datasets/voc.py:74-89): labels int64 [N,H,W] -> palette colours [N,3,H,W] (0..255 as float). */
+int clamd_label_to_rgb(const long long* labels, float* rgb, long long n_img, long long hw, void* stream);
 int clamd_fill_f32(float* p, long long n, double v, void* stream);
 /* performance experiments only (never changes results): e.g. ("igemm_variant", 0|1|2). */
 int clamd_set_tuning(const char* key, int value);

@@ -267,6 +267,47 @@ def eval_metrics(targets, preds, num_classes):
             per_valid.max() if per_valid.size else np.float32(np.nan), m)
 
 
+# --------------------------------------------------------------------------- data path
+VOC_PALETTE = [(0, 0, 0), (128, 0, 0), (0, 128, 0), (128, 128, 0), (0, 0, 128), (128, 0, 128), (0, 128, 128),
+               (128, 128, 128), (64, 0, 0), (192, 0, 0), (64, 128, 0), (192, 128, 0), (64, 0, 128), (192, 0, 128),
+               (64, 128, 128), (192, 128, 128), (0, 64, 0), (128, 64, 0), (0, 192, 0), (128, 192, 0), (0, 64, 128),
+               (224, 224, 192)]          # datasets/voc.py:32-53 (data); index 21 = void
+
+
+def pad_center_crop(a, h, w, pad=10):
+    """transforms.Pad(pad) then CenterCrop((h, w)) on an [H,W,C] array (main.py:19-20, voc.py:140-141).  torchvision
+    is not installed in the build container, so this follows torchvision.transforms.functional.{pad,center_crop} as
+    documented (zero fill; undersized images zero-padded (d//2, (d+1)//2); top = int(round((H-h)/2.0))): this part of
+    the data path is restated, not pinned by running the reference."""
+    a = np.pad(a, ((pad, pad), (pad, pad), (0, 0)))
+    H, W = a.shape[:2]
+    if h > H or w > W:
+        pt, pb = ((h - H) // 2, (h - H + 1) // 2) if h > H else (0, 0)
+        pl, pr = ((w - W) // 2, (w - W + 1) // 2) if w > W else (0, 0)
+        a = np.pad(a, ((pt, pb), (pl, pr), (0, 0)))
+        H, W = a.shape[:2]
+    top, left = int(round((H - h) / 2.0)), int(round((W - w) / 2.0))
+    return a[top:top + h, left:left + w]
+
+
+def voc_prepare(img_u8, mask_u8, h, w):
+    """VOC.__getitem__ (datasets/voc.py:127-144): image -> Pad, CenterCrop, ToTensor, Normalize(0.5, 0.5) [3,h,w] f32;
+    mask -> Pad, CenterCrop, to_mask (voc.py:56-72: palette index, void -> 0) [h,w] int64."""
+    img = pad_center_crop(img_u8, h, w).astype(np.float32) / np.float32(255)
+    image = ((img - np.float32(0.5)) / np.float32(0.5)).transpose(2, 0, 1)
+    m = pad_center_crop(mask_u8, h, w).reshape(-1, 3)
+    lab = np.empty(m.shape[0], np.int64)
+    for i, px in enumerate(map(tuple, m)):           # the reference's per-pixel loop, voc.py:64-70
+        lab[i] = 0 if px == (224, 224, 192) else VOC_PALETTE.index(px)
+    return np.ascontiguousarray(image), lab.reshape(h, w)
+
+
+def to_rgb(labels):
+    """voc.to_rgb (datasets/voc.py:74-89)."""
+    pal = np.array(VOC_PALETTE, np.float32)
+    return pal[labels].transpose(0, 3, 1, 2)
+
+
 # --------------------------------------------------------------------------- network
 def layer_table(num_classes, in_dim=3, conv_dim=64):
     """state_dict naming of models/unet.py:49-72 as a flat table.

@@ -97,3 +97,18 @@ def test_fused_adam_state_dict_layout_without_gpu(C):
     p.grad = torch.zeros(3)
     with pytest.raises(RuntimeError):
         opt.step()                                     # CPU parameters: fails loudly
+
+
+def test_crop_origin_matches_pad_center_crop(C):
+    """Host geometry of the GPU data path vs the oracle's Pad(10)+CenterCrop restatement, incl. undersized images."""
+    from oracle import np_unet as O
+    rng = np.random.default_rng(0)
+    for hs, ws, h, w in [(300, 500, 256, 256), (375, 500, 512, 256), (100, 90, 256, 256), (237, 333, 256, 256), (256, 256, 256, 256)]:
+        a = rng.integers(1, 255, (hs, ws, 1)).astype(np.uint8)
+        ref = O.pad_center_crop(a, h, w)[..., 0]
+        oy, ox = C.data.crop_origin(hs, ws, h, w)
+        ys, xs = np.arange(h) + oy, np.arange(w) + ox
+        got = np.zeros((h, w), np.uint8)
+        vy, vx = (ys >= 0) & (ys < hs), (xs >= 0) & (xs < ws)
+        got[np.ix_(vy, vx)] = a[np.ix_(ys[vy], xs[vx])][..., 0]
+        assert np.array_equal(got, ref), (hs, ws, h, w)

@@ -534,3 +534,23 @@ def test_metrics_golden(C, golden):
     tie = torch.zeros(1, 5, 16, 16, device='cuda')
     _, pr = C.argmax_confusion(tie, torch.zeros(1, 16, 16, dtype=torch.int64, device='cuda'), 5, want_pred=True)
     assert int(pr.max()) == 0
+
+
+def test_voc_data_path_vs_oracle(C):
+    """Pad/CenterCrop/ToTensor/Normalize + palette lookup on the GPU vs the oracle restatement of
+    main.py:18-23 and datasets/voc.py:56-72 (incl. void -> 0, an undersized image, an off-palette colour)."""
+    rng = np.random.default_rng(30)
+    pal = np.array(O.VOC_PALETTE, np.uint8)
+    for hs, ws, h, w in [(120, 200, 64, 96), (40, 50, 64, 64), (77, 131, 32, 48)]:
+        img = rng.integers(0, 256, (hs, ws, 3)).astype(np.uint8)
+        mask = pal[rng.integers(0, 22, (hs, ws))]
+        ri, rl = O.voc_prepare(img, mask, h, w)
+        gi, gl = C.data.prepare_sample(torch.from_numpy(img).cuda(), torch.from_numpy(mask).cuda(), (h, w))
+        sync()
+        np.testing.assert_allclose(gi.cpu().numpy(), ri, rtol=0, atol=1e-6)
+        assert np.array_equal(gl.cpu().numpy(), rl)
+        back = C.data.to_rgb(gl[None])
+        assert np.array_equal(back.cpu().numpy(), O.to_rgb(rl[None]))
+    bad = mask.copy(); bad[hs // 2, ws // 2] = (1, 2, 3)          # a pixel inside the centre crop
+    with pytest.raises(ValueError):
+        C.data.prepare_sample(torch.from_numpy(img).cuda(), torch.from_numpy(bad).cuda(), (h, w))

@@ -5,6 +5,8 @@ north_star tolerance: logits within 1e-3 relative (rel L2 and max-abs/max-abs) f
 reported against the tolerance it can reach (bf16 storage of 23 stacked conv layers) and must keep
 mIoU within +-0.1 of the reference.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -297,3 +299,27 @@ def test_gradsync_rccl_world1_on_gpu(C):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_checkpoint_roundtrip_and_resume(C, tmp_path):
+    """save_network / load_network keep the reference's file name and keys (trainer.py:68-102); a
+    resumed trainer continues exactly like the uninterrupted one, and the file loads into stock torch objects."""
+    cfg = C.default_config(n_iters=6, lr=1e-3, num_classes=4, conv_dim=4, compute_dtype='fp32', stats_every=1)
+    data = [(torch.from_numpy(C.synth.images(11, 2, 3, 32, 32)), torch.from_numpy(C.synth.labels(11, 2, 32, 32, 4)))]
+    torch.manual_seed(0)
+    a = C.Trainer(data, cfg)
+    a.train_val(epochs=2)
+    path = a.save_network('UNET_VOC', 'latest', a.start_epoch - 1, str(tmp_path))
+    assert os.path.basename(path) == 'latest_net_UNET_VOC.pth'
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    assert set(ck) == {'epoch', 'model_state', 'optimizer_state', 'scheduler_state'} and ck['epoch'] == 2
+    ref = TC.build_unet(4, 3, 4)
+    ref.load_state_dict(ck['model_state'], strict=True)                      # the reference module layout
+    ropt = TC.make_optimizer(ref, lr=1e-3)
+    ropt.load_state_dict(ck['optimizer_state'])                               # torch.optim.Adam accepts the state
+    assert float(ropt.state[next(iter(ref.parameters()))]['step']) == 2.0
+    b = C.Trainer(data, cfg)
+    assert b.load_network('UNET_VOC', 'latest', str(tmp_path)) and b.start_epoch == 2
+    sa, sb = a.train_val(epochs=1)[0], b.train_val(epochs=1)[0]
+    assert abs(sa['lr'] - sb['lr']) < 1e-12
+    assert abs(sa['loss'] - sb['loss']) < 2e-3 * abs(sa['loss'])
