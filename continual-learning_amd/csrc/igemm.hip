@@ -481,12 +481,14 @@ int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* b
                   int m_fastest, int dtype, void* stream) {
     IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, m_fastest, bn_y, bn_sums};
     if (int e = check_common(p, "conv3x3")) return e;
-    if (g_igemm_ws == 1 || g_igemm_ws == 3) return launch_igemm_ws(p, dtype, (hipStream_t)stream, g_igemm_ws == 1 ? 2 : 4);
+    if (g_igemm_ws == 1 || g_igemm_ws == 3 || g_igemm_ws == 4)      // forced: 256- / 512- / 128-pixel tiles
+        return launch_igemm_ws(p, dtype, (hipStream_t)stream, g_igemm_ws == 1 ? 2 : g_igemm_ws == 3 ? 4 : 1);
     if (g_igemm_ws == 2 && Cin_p >= 256) {
         // one workgroup per CU: take the 512-pixel tile only if it still gives every CU a workgroup
         const long long ntn = (Cout_p + 63) / 64;
         const long long blocks4 = (long long)B * ((H + 15) / 16) * ((W + 31) / 32) * ntn;
-        return launch_igemm_ws(p, dtype, (hipStream_t)stream, (W >= 32 && blocks4 >= 224) ? 4 : 2);
+        const long long blocks2 = (long long)B * (W >= 32 ? ((H + 7) / 8) * ((W + 31) / 32) : ((H + 15) / 16) * ((W + 15) / 16)) * ntn;
+        return launch_igemm_ws(p, dtype, (hipStream_t)stream, (W >= 32 && blocks4 >= 224) ? 4 : blocks2 >= 224 ? 2 : 1);
     }
     return launch<MODE_CONV3, EPI_NHWC>(p, dtype, (hipStream_t)stream);
 }

@@ -387,12 +387,14 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
 template <typename T>
 static int launch_ws_t(const IgemmParams& p, hipStream_t s, int mt) {
     const bool wide = p.W >= 32;
-    if (!wide) mt = 2;                       // 16-wide tiles: 256 pixels (16 x 16)
+    if (!wide && mt > 2) mt = 2;             // 16-wide tiles: 256 pixels (16 x 16) or 128 (16 x 8)
     const int TW = wide ? 32 : 16, TH = 128 * mt / TW;
     const long long tiles = (long long)((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.B;
     const long long nblk = tiles * ((p.Np + 63) / 64);
     if (nblk <= 0 || nblk > 0x7fffffff) return clamd_fail("igemm_ws: grid out of range");
-    if (!wide) hipLaunchKernelGGL((igemm_ws_kernel<T, 16, 2>), dim3((unsigned)nblk), dim3(512), 0, s, p);
+    if (!wide && mt == 1) hipLaunchKernelGGL((igemm_ws_kernel<T, 16, 1>), dim3((unsigned)nblk), dim3(512), 0, s, p);
+    else if (!wide) hipLaunchKernelGGL((igemm_ws_kernel<T, 16, 2>), dim3((unsigned)nblk), dim3(512), 0, s, p);
+    else if (mt == 1) hipLaunchKernelGGL((igemm_ws_kernel<T, 32, 1>), dim3((unsigned)nblk), dim3(512), 0, s, p);
     else if (mt == 4) hipLaunchKernelGGL((igemm_ws_kernel<T, 32, 4>), dim3((unsigned)nblk), dim3(512), 0, s, p);
     else hipLaunchKernelGGL((igemm_ws_kernel<T, 32, 2>), dim3((unsigned)nblk), dim3(512), 0, s, p);
     return clamd_check_launch("igemm_ws");

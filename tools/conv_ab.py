@@ -11,6 +11,8 @@ dc = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[dt]
 T = C.ops.TORCH_DT[dc]
 B, iters, rounds = 16, 10, 5
 layers = [(64, 64, 256), (128, 64, 256), (128, 128, 128), (256, 128, 128), (256, 256, 64), (512, 512, 32), (1024, 512, 32), (1024, 1024, 16)]
+if os.environ.get('CONV_LAYERS'):      # e.g. CONV_LAYERS='1024,512,16;512,1024,16'
+    layers = [tuple(int(v) for v in l.split(',')) for l in os.environ['CONV_LAYERS'].split(';')]
 lib = C._lib.load(); s = C._lib.stream_ptr()
 tot = {v: [0.0, 0.0] for v in variants}
 for cin, cout, hw in layers:
