@@ -414,6 +414,7 @@ extern int g_wgrad_target_blocks;
 extern int g_wgrad_tw16;
 extern int g_wgrad_ws;
 static int g_igemm_variant = 0;
+static int g_igemm_pws = 1;        // persistent producer/consumer kernel: 1 = short-K layers (< 256 input channels), 2 = every layer, 0 = never
 static int g_igemm_ws = 2;         // 0: never, 1: always (128x2-pixel tiles), 3: always (128x4), 2: where it measured faster
                                    // (interleaved A/B, tools/conv_ab.py): long K loops (>= 256 input channels), where the
                                    // two-stage pipeline fills and the 512-pixel tile halves the filter traffic per MFMA
@@ -470,6 +471,7 @@ extern "C" {
 int clamd_set_tuning(const char* key, int value) {
     if (!strcmp(key, "igemm_variant")) { g_igemm_variant = value; return 0; }
     if (!strcmp(key, "igemm_ws")) { g_igemm_ws = value; return 0; }
+    if (!strcmp(key, "igemm_pws")) { g_igemm_pws = value; return 0; }
     if (!strcmp(key, "wgrad_tw16")) { g_wgrad_tw16 = value; return 0; }
     if (!strcmp(key, "wgrad_ws")) { g_wgrad_ws = value; return 0; }
     if (!strcmp(key, "wgrad_blocks")) { if (value < 1 || value > 512) return clamd_fail("wgrad_blocks: 1..512"); g_wgrad_target_blocks = value; return 0; }
@@ -481,6 +483,10 @@ int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* b
                   int m_fastest, int dtype, void* stream) {
     IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, m_fastest, bn_y, bn_sums};
     if (int e = check_common(p, "conv3x3")) return e;
+    if (g_igemm_pws == 2 || (g_igemm_pws == 1 && Cin_p < 256)) {
+        const int e = launch_igemm_pws(p, dtype, (hipStream_t)stream);
+        if (e != -1) return e;                                       // -1: shape not supported there, fall through
+    }
     if (g_igemm_ws == 1 || g_igemm_ws == 3 || g_igemm_ws == 4)      // forced: 256- / 512- / 128-pixel tiles
         return launch_igemm_ws(p, dtype, (hipStream_t)stream, g_igemm_ws == 1 ? 2 : g_igemm_ws == 3 ? 4 : 1);
     if (g_igemm_ws == 2 && Cin_p >= 256) {

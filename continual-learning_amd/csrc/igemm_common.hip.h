@@ -43,7 +43,24 @@ template <int MODE, int TW> struct Geo {
 };
 
 
+// Geometry of one LDS stage for a (128*MT)-pixel x 64-channel tile (MT = 32-pixel MFMA row tiles per consumer wave).
+template <int TW, int MT> struct WsGeo {
+    static constexpr int TH = 128 * MT / TW;
+    static constexpr int NT = 9;
+    static constexpr int HW_ = TW + 2, HH_ = TH + 2;
+    static constexpr int NPIX = HW_ * HH_;
+    static constexpr int NPIXP = NPIX + ((10 - NPIX % 8) % 8);     // == 2 (mod 8)
+    static constexpr int NJ = (NPIX * 4 + 255) / 256;
+    static constexpr int IN_SLOTS = 4 * NPIXP;
+    static constexpr int WG = 66;
+    static constexpr int WT_SLOTS = NT * 4 * WG;
+};
+
 // igemm_ws.hip: producer/consumer variant of the CONV3/NHWC kernel (same results)
 int launch_igemm_ws(const IgemmParams& p, int dtype, hipStream_t s, int mt);   // mt: 32-pixel row tiles per consumer wave (2 or 4)
+
+// igemm_pws.hip: persistent producer/consumer variant for short-K layers (same results up to the order of the
+// per-channel statistics atomics); returns -1 without launching when the shape is not supported
+int launch_igemm_pws(const IgemmParams& p, int dtype, hipStream_t s);
 
 }  // namespace clamd

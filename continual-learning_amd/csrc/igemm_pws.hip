@@ -1,0 +1,327 @@
+// Persistent producer/consumer implicit-GEMM 3x3 convolution for gfx950: the short-K layers (64 / 128 input channels).
+//
+// igemm_ws.hip runs ONE 512-thread workgroup per CU (two 60-KB LDS stages), so nothing covers a workgroup's prologue
+// (tile descriptors, first two stages from HBM) and epilogue; with 2-4 K-steps per tile those cost more than the
+// K loop, and the 2-workgroups-per-CU baseline kernel (igemm.hip) stayed faster there.  Here a workgroup is launched
+// once per CU and walks its share of the pixel tiles of ONE 64-channel output slab:
+//   * waves 4-7 (producers) run ONE flattened (tile, K-step) pipeline: while the consumers finish a tile and write
+//     it out, the first stage of the next tile is already in LDS and the second in flight;
+//   * waves 0-3 (consumers) do MFMAs, then an epilogue without workgroup barriers: every wave transposes its own
+//     32x64 accumulator block through a private LDS region outside the two stages;
+//   * the per-channel Sigma / Sigma^2 of the fused BatchNorm statistics stay in registers across tiles and are flushed
+//     with one set of atomics per workgroup instead of one per tile.
+// Tile (256 pixels x 64 channels), LDS image, fragment maps and per-element results are those of igemm_ws.hip (MT = 2).
+#include "common.hip.h"
+#include "igemm_common.hip.h"
+#include "clamd_internal.h"
+
+namespace clamd {
+
+template <typename T, int TW>
+__global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, const int gm) {
+    constexpr int MT = 2;
+    using G = WsGeo<TW, MT>;
+    constexpr int TH = G::TH, NT = G::NT, HW_ = G::HW_, NPIX = G::NPIX, NPIXP = G::NPIXP, NJ = G::NJ;
+    constexpr int KC = DT<T>::KC, VEC = DT<T>::VEC;
+    constexpr bool SPLIT = __is_same(T, split_t);
+    constexpr int STAGE = G::IN_SLOTS + G::WT_SLOTS;
+    constexpr int EPI_SLOTS = (4 * 32 * 68 + 8 * 64) / 4;        // 4 waves x [32][68] fp32 + statistics hand-over
+    static_assert((2 * STAGE + EPI_SLOTS) * 16 <= 160 * 1024, "two LDS stages + the epilogue region must fit one CU");
+    __shared__ uint4 smem[2 * STAGE + EPI_SLOTS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int ltid = tid & 255;                    // index inside the role (4 waves each)
+    const int cw = wave & 3;                       // consumer wave index (M quarter of the tile)
+    const int r = lane & 31, h = lane >> 5;
+
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int ntm = tiles_x * tiles_y * p.B, ntn = (p.Np + 63) >> 6;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);            // gridDim.x == ntn * gm
+    const int tn = bid % ntn, mg = bid / ntn;                    // this workgroup: pixel tiles mg, mg + gm, ... of slab tn
+    const int T_ = (ntm - mg + gm - 1) / gm;                     // >= 1
+    const int n0 = tn * 64;
+    const int nk = p.Kp / KC;                                    // even (checked by the launcher)
+    const int S = T_ * nk;                                       // flattened K-steps
+
+    float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};              // consumers: running sum / sum of squares, columns 32*nt + r
+
+    if (producer) {
+        // ------------------------------------------------------------------ producers: global -> registers -> LDS
+        constexpr int ESZ = sizeof(T);
+        const int g4 = ltid & 3;
+        const unsigned img_elems = (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc;
+        const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.w, (unsigned)(9u * p.Np * p.Kp * ESZ));
+        const int wco = ltid >> 2;
+        const unsigned w_vo = n0 + wco < p.Np ? (unsigned)(((n0 + wco) * KC + g4 * VEC) * ESZ) : BUF_OOB;
+        const unsigned w_slab = (unsigned)(p.Np * KC * ESZ);
+        unsigned in_vo[NJ];
+        __amdgpu_buffer_rsrc_t xrs;
+        // halo pixel of staging slot j; the ragged last pass wraps around and re-stages the first pixels (same data,
+        // same LDS slot) so that every load has an unconditional store
+        auto slot_pix = [&](int j) { const int pix = (ltid >> 2) + 64 * j; return pix >= NPIX ? pix - NPIX : pix; };
+        auto set_tile = [&](int tm) {
+            const int x0 = (tm % tiles_x) * TW, y0 = ((tm / tiles_x) % tiles_y) * TH, b = tm / (tiles_x * tiles_y);
+            xrs = make_rsrc((const char*)p.x + (size_t)b * img_elems * ESZ, img_elems * ESZ);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int pix = slot_pix(j);
+                const int hy = pix / HW_, hx = pix - hy * HW_;
+                const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+                in_vo[j] = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
+                               ? (unsigned)(((yy * p.W + xx) * p.x_ldc + g4 * VEC) * ESZ) : BUF_OOB;
+            }
+        };
+        // Input chunks are fetched in PAIRS (two back-to-back 64-byte pieces = one full 128-byte line per pixel), see
+        // igemm_ws.hip; nk is even, so a pair never straddles two tiles.
+        uint4 rinA[NJ], rinB[NJ], rw[NT];
+#define PWS_GLOAD_IN2(kp_)                                                                                        \
+    do {                                                                                                          \
+        const unsigned so_ = (unsigned)(2 * (kp_) * KC * ESZ);                                                    \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                          \
+            rinA[j] = buf_ld16(xrs, in_vo[j], so_);                                                               \
+            rinB[j] = buf_ld16(xrs, in_vo[j], so_ + KC * ESZ);                                                    \
+        }                                                                                                         \
+    } while (0)
+#define PWS_GLOAD_W(ks_)                                                                                          \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                            \
+            rw[t] = buf_ld16(wrs, w_vo, (unsigned)((ks_) * NT + t) * w_slab);                                     \
+    } while (0)
+#define PWS_STORE(st_, RIN)                                                                                       \
+    do {                                                                                                          \
+        uint4* sm_ = smem + (st_) * STAGE;                                                                        \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                          \
+            const int pix_ = slot_pix(j);                                                                         \
+            if constexpr (!SPLIT) {                                                                               \
+                sm_[g4 * NPIXP + pix_] = RIN[j];                                                                  \
+            } else {                                                                                              \
+                uint2 hi_, lo_;                                                                                   \
+                split4(RIN[j], hi_, lo_);                                                                         \
+                char* b_ = reinterpret_cast<char*>(sm_) + ((g4 >> 1) * NPIXP + pix_) * 16 + 8 * (g4 & 1);         \
+                *reinterpret_cast<uint2*>(b_) = hi_;                                                              \
+                *reinterpret_cast<uint2*>(b_ + 2 * NPIXP * 16) = lo_;                                             \
+            }                                                                                                     \
+        }                                                                                                         \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) sm_[G::IN_SLOTS + (t * 4 + g4) * G::WG + wco] = rw[t];     \
+    } while (0)
+
+        int l_tile = 0, l_pair = 0;                // load cursor: tile index of this workgroup, K-step pair inside it
+        const int npair = nk >> 1;
+        set_tile(mg);
+        PWS_GLOAD_IN2(0);
+        PWS_GLOAD_W(0);
+        PWS_STORE(0, rinA);
+        PWS_GLOAD_W(1);
+        __syncthreads();                                   // step 0 is staged
+        int ks2 = 2 == nk ? 0 : 2;                         // K-step index (inside its tile) of flattened step 2q + 2
+        for (int q = 0; q < (S >> 1); ++q) {
+            const bool more = 2 * q + 2 < S;               // wave-uniform; false only in the last iteration
+            // consumers are on step 2q (stage 0): stage step 2q + 1, then fetch steps 2q + 2 / 2q + 3
+            PWS_STORE(1, rinB);
+            if (more) {
+                PWS_GLOAD_W(ks2);
+                if (++l_pair == npair) { l_pair = 0; ++l_tile; set_tile(mg + l_tile * gm); }
+                PWS_GLOAD_IN2(l_pair);
+            }
+            __syncthreads();
+            // consumers are on step 2q + 1 (stage 1): stage step 2q + 2, fetch the filter slab of step 2q + 3
+            if (more) {
+                PWS_STORE(0, rinA);
+                PWS_GLOAD_W(ks2 + 1);
+            }
+            __syncthreads();
+            ks2 = ks2 + 2 == nk ? 0 : ks2 + 2;
+        }
+#undef PWS_GLOAD_IN2
+#undef PWS_GLOAD_W
+#undef PWS_STORE
+    } else {
+        // ------------------------------------------------------------------ consumers: LDS fragments -> MFMA -> epilogue
+        int apix[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = 32 * MT * cw + 32 * mt + r;
+            apix[mt] = (m / TW) * HW_ + (m % TW);
+        }
+        float bcol[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + 32 * nt + r;
+            bcol[nt] = (p.bias && n < p.Np) ? p.bias[n] : 0.f;
+        }
+        float* const wbuf = reinterpret_cast<float*>(smem + 2 * STAGE) + cw * 32 * 68;   // this wave's transposition block
+        T* const out = (T*)p.y;
+
+        __syncthreads();                                   // step 0 is staged
+        for (int ti = 0; ti < T_; ++ti) {
+            f32x16 acc[MT][2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+            for (int ks = 0; ks < nk; ++ks) {
+                const uint4* sm = smem + (ks & 1) * STAGE;         // nk is even: the stage parity restarts with every tile
+                if constexpr (SPLIT) {
+                    uint4 f[2][2 * MT + 4];      // [buffer][a_hi[mt], a_lo[mt] ..., bh0, bl0, bh1, bl1]
+#define PWS_FRAG_S(t_, d_)                                                                                        \
+    do {                                                                                                          \
+        const int ib_ = ((t_) / 3) * HW_ + ((t_) % 3);                                                            \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) {                                                    \
+            d_[2 * mt_] = sm[ib_ + h * NPIXP + apix[mt_]];                                                        \
+            d_[2 * mt_ + 1] = sm[ib_ + (2 + h) * NPIXP + apix[mt_]];                                              \
+        }                                                                                                         \
+        d_[2 * MT + 0] = sm[G::IN_SLOTS + ((t_) * 4 + h) * G::WG + r];                                            \
+        d_[2 * MT + 1] = sm[G::IN_SLOTS + ((t_) * 4 + 2 + h) * G::WG + r];                                        \
+        d_[2 * MT + 2] = sm[G::IN_SLOTS + ((t_) * 4 + h) * G::WG + 32 + r];                                       \
+        d_[2 * MT + 3] = sm[G::IN_SLOTS + ((t_) * 4 + 2 + h) * G::WG + 32 + r];                                   \
+    } while (0)
+                    PWS_FRAG_S(0, f[0]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 4, 0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if (t + 1 < NT) PWS_FRAG_S(t + 1, f[(t + 1) & 1]);
+                        const uint4* c = f[t & 1];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            mma_bf16(c[2 * mt + 1], c[2 * MT + 0], acc[mt][0]); mma_bf16(c[2 * mt], c[2 * MT + 1], acc[mt][0]);
+                            mma_bf16(c[2 * mt], c[2 * MT + 0], acc[mt][0]);
+                            mma_bf16(c[2 * mt + 1], c[2 * MT + 2], acc[mt][1]); mma_bf16(c[2 * mt], c[2 * MT + 3], acc[mt][1]);
+                            mma_bf16(c[2 * mt], c[2 * MT + 2], acc[mt][1]);
+                        }
+                        if (t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT, 0);
+                    }
+#undef PWS_FRAG_S
+                } else {
+                    constexpr int NSTEP = 2 * NT;
+                    constexpr int NMF = sizeof(T) == 2 ? 4 : 16;
+                    uint4 f[2][MT + 2];      // [buffer][a[mt] ..., b0, b1]
+#define PWS_FRAG(s_, d_)                                                                                          \
+    do {                                                                                                          \
+        const int t_ = (s_) >> 1, g_ = ((s_) & 1) * 2 + h;                                                        \
+        const int ib_ = (t_ / 3) * HW_ + (t_ % 3);                                                                \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) d_[mt_] = sm[ib_ + g_ * NPIXP + apix[mt_]];          \
+        d_[MT] = sm[G::IN_SLOTS + (t_ * 4 + g_) * G::WG + r];                                                     \
+        d_[MT + 1] = sm[G::IN_SLOTS + (t_ * 4 + g_) * G::WG + 32 + r];                                            \
+    } while (0)
+                    PWS_FRAG(0, f[0]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);
+#pragma unroll
+                    for (int st = 0; st < NSTEP; ++st) {
+                        if (st + 1 < NSTEP) PWS_FRAG(st + 1, f[(st + 1) & 1]);
+                        const uint4* c = f[st & 1];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            mma16<T>(c[mt], c[MT], acc[mt][0]);
+                            mma16<T>(c[mt], c[MT + 1], acc[mt][1]);
+                        }
+                        if (st + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, NMF * MT / 2, 0);
+                    }
+#undef PWS_FRAG
+                }
+                __syncthreads();                           // hand the stage back to the producers
+            }
+
+            // ---- epilogue of this tile: bias, ReLU, statistics, wave-private transposition, 16-byte stores.
+            // No workgroup barrier: the producers are already staging the next tile and meet the consumers again at
+            // the barrier of its first K-step.
+            const int tm = mg + ti * gm;
+            const int x0 = (tm % tiles_x) * TW, y0 = ((tm / tiles_x) % tiles_y) * TH, b = tm / (tiles_x * tiles_y);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = acc[mt][nt][e] + bcol[nt];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        const int m = 32 * MT * cw + 32 * mt + acc_row(e, h);
+                        const bool valid = y0 + m / TW < p.H && x0 + m % TW < p.W;
+                        const float vs = valid ? v : 0.f;
+                        st1[nt] += vs;
+                        st2[nt] += vs * vs;
+                        wbuf[acc_row(e, h) * 68 + 32 * nt + r] = v;
+                    }
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int row = ps * 8 + (lane >> 3), cgp = lane & 7;
+                    const int m = 32 * MT * cw + 32 * mt + row;
+                    const int yy = y0 + m / TW, xx = x0 + m % TW;
+                    const int n = n0 + cgp * 8;
+                    const float4 lo = *reinterpret_cast<const float4*>(wbuf + row * 68 + cgp * 8);
+                    const float4 hi = *reinterpret_cast<const float4*>(wbuf + row * 68 + cgp * 8 + 4);
+                    if (yy < p.H && xx < p.W && n < p.Np) {
+                        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        const long long pixo = ((long long)b * p.H + yy) * p.W + xx;
+                        Vec8<T>::store(out + pixo * p.y_ldc + n, v);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------------- statistics: one flush per workgroup
+    if (p.stats) {
+        float* sbuf = reinterpret_cast<float*>(smem + 2 * STAGE) + 4 * 32 * 68;
+        if (!producer) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                st1[nt] += __shfl_xor(st1[nt], 32);
+                st2[nt] += __shfl_xor(st2[nt], 32);
+            }
+            if (h == 0) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    sbuf[(cw * 2 + 0) * 64 + 32 * nt + r] = st1[nt];
+                    sbuf[(cw * 2 + 1) * 64 + 32 * nt + r] = st2[nt];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int k = tid >> 6, c = tid & 63;
+            const float t = sbuf[(0 * 2 + k) * 64 + c] + sbuf[(1 * 2 + k) * 64 + c] + sbuf[(2 * 2 + k) * 64 + c] +
+                            sbuf[(3 * 2 + k) * 64 + c];
+            if (n0 + c < p.Np) atomicAdd(p.stats + ((size_t)(blockIdx.x % STAT_REPLICAS) * 2 + k) * p.Np + n0 + c, t);
+        }
+    }
+}
+
+static int g_num_cus = 0;
+
+template <typename T>
+static int launch_pws_t(const IgemmParams& p, hipStream_t s) {
+    if (p.bn_y) return -1;                                   // fused BN-backward sums: igemm_ws / igemm only
+    if (p.Kp % (2 * DT<T>::KC)) return -1;                   // K-steps are staged in pairs
+    if (!g_num_cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_num_cus = n;
+    }
+    const bool wide = p.W >= 32;
+    const int TW = wide ? 32 : 16, TH = 256 / TW;
+    const long long ntm = (long long)((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.B;
+    const int ntn = (p.Np + 63) / 64;
+    long long gm = g_num_cus / ntn;
+    if (gm < 1) gm = 1;
+    if (gm > ntm) gm = ntm;
+    const long long nblk = gm * ntn;
+    if (ntm > 0x7fffffff) return clamd_fail("igemm_pws: grid out of range");
+    if (wide) hipLaunchKernelGGL((igemm_pws_kernel<T, 32>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm);
+    else hipLaunchKernelGGL((igemm_pws_kernel<T, 16>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm);
+    return clamd_check_launch("igemm_pws");
+}
+
+int launch_igemm_pws(const IgemmParams& p, int dtype, hipStream_t s) {
+    if (dtype == CLAMD_BF16) return launch_pws_t<bf16_t>(p, s);
+    if (dtype == CLAMD_F32) return launch_pws_t<float>(p, s);
+    if (dtype == CLAMD_SPLIT) return launch_pws_t<split_t>(p, s);
+    return clamd_fail("igemm_pws: bad dtype");
+}
+
+}  // namespace clamd

@@ -27,19 +27,6 @@ __device__ unsigned long long g_ws_diag[8];
 #define DIAG_ADD(i_, v_) do { } while (0)
 #endif
 
-// Geometry of one LDS stage for a (128*MT)-pixel x 64-channel tile (MT = 32-pixel MFMA row tiles per consumer wave).
-template <int TW, int MT> struct WsGeo {
-    static constexpr int TH = 128 * MT / TW;
-    static constexpr int NT = 9;
-    static constexpr int HW_ = TW + 2, HH_ = TH + 2;
-    static constexpr int NPIX = HW_ * HH_;
-    static constexpr int NPIXP = NPIX + ((10 - NPIX % 8) % 8);     // == 2 (mod 8)
-    static constexpr int NJ = (NPIX * 4 + 255) / 256;
-    static constexpr int IN_SLOTS = 4 * NPIXP;
-    static constexpr int WG = 66;
-    static constexpr int WT_SLOTS = NT * 4 * WG;
-};
-
 template <typename T, int TW, int MT>
 __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
     using G = WsGeo<TW, MT>;
