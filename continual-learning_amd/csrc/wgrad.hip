@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256, 2) wgrad_kernel(const WgradPar
                 // A fragment of a k-step shared by its three groups).  Prefetches past the last k-step read valid LDS
                 // (the halo rows TH, TH+1 / the neighbouring image) and are never used.
                 constexpr int XPR = TW / 16, NU = TH * XPR;               // k-steps per tile row / per tile
-                constexpr int D = SPLIT ? 1 : 2, RS = D + 1;
+                constexpr int D = 1, RS = D + 1;
                 static_assert(NU % 2 == 0 && 6 % RS == 0, "two k-steps (six groups) per loop iteration");
                 constexpr int NRD = (SPLIT ? 2 : 1) * 6, NRA = (SPLIT ? 2 : 1) * 2, NMF = SPLIT ? 9 : 3;
                 uint4 Ah[2], Al[2], Bh[RS][3], Bl[RS][3];

@@ -238,6 +238,79 @@ def test_conv3x3_dgrad_and_wgrad(C, name, dcode, shape):
     np.testing.assert_allclose(got[3:], want[3:], rtol=1e-5, atol=1e-3)
 
 
+# Every structure of the 3x3 kernels (baseline two-workgroups-per-CU, producer/consumer with 128/256/512-pixel tiles,
+# persistent producer/consumer) is forced in turn through clamd_set_tuning and must (a) match the oracle and (b) give
+# bit-identical activations -- they share the tile, the LDS image and the summation order of every output element.
+VARIANT_SHAPES = [  # B, Cin, Cout, H, W
+    (2, 64, 64, 40, 64),      # short K, ragged tile rows
+    (1, 256, 96, 16, 16),     # long K, 16-wide tiles, ragged Cout tile
+    (3, 128, 130, 24, 40),    # 3 Cout slabs (persistent kernel: several workgroups per slab), ragged in x and y
+]
+CONV_VARIANTS = [('igemm_pws', 0, 'igemm_ws', 0), ('igemm_pws', 0, 'igemm_ws', 1), ('igemm_pws', 0, 'igemm_ws', 3),
+                 ('igemm_pws', 0, 'igemm_ws', 4), ('igemm_pws', 2, 'igemm_ws', 2), ('igemm_pws', 1, 'igemm_ws', 2)]
+
+
+@pytest.mark.parametrize('name,dcode', DT)
+@pytest.mark.parametrize('shape', VARIANT_SHAPES)
+def test_conv3x3_kernel_structures_agree(C, name, dcode, shape):
+    B, cin, cout, H, W = shape
+    rng = np.random.default_rng(12)
+    segs = [(cin, C.ops.cpad(cin))]
+    x, w, b, xt, wf, wd, bp, cin_p, cout_p = _conv_case(C, rng, B, segs, cout, H, W, dcode)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    T = C.ops.TORCH_DT[dcode]
+    R = lib.load().clamd_stat_replicas()
+    ref = O.relu_fwd(O.conv3x3_fwd(x, w, b))
+    first = None
+    try:
+        for k1, v1, k2, v2 in CONV_VARIANTS:
+            lib.load().clamd_set_tuning(k1.encode(), v1)
+            lib.load().clamd_set_tuning(k2.encode(), v2)
+            y = torch.full((B, H, W, cout_p), 7.0, dtype=T, device='cuda')
+            stats = torch.zeros(R, 2, cout_p, device='cuda')
+            lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, B, H, W, cin_p,
+                     cout_p, 1, 0, dcode, s)
+            sync()
+            got = C.ops.from_nhwc(y, cout, dcode).cpu().numpy()
+            assert rel_l2(got, ref) < TOL[dcode], (k1, v1, k2, v2)
+            st = stats.sum(0).cpu().numpy()
+            np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=2e-3 if dcode == 1 else 1e-4, atol=1e-2 if dcode == 1 else 1e-3)
+            np.testing.assert_allclose(st[1, :cout], (ref ** 2).sum((0, 2, 3)), rtol=4e-3 if dcode == 1 else 1e-4, atol=1e-2 if dcode == 1 else 1e-3)
+            if first is None:
+                first = y.clone()
+            else:
+                assert torch.equal(first, y), f'{k1}={v1} {k2}={v2} changed the activations'
+    finally:
+        lib.load().clamd_set_tuning(b'igemm_pws', 1)
+        lib.load().clamd_set_tuning(b'igemm_ws', 2)
+
+
+@pytest.mark.parametrize('name,dcode', DT)
+@pytest.mark.parametrize('shape', [(2, 64, 64, 40, 64), (1, 256, 96, 16, 16), (5, 40, 130, 24, 40)])
+def test_wgrad_kernel_structures_agree(C, name, dcode, shape):
+    """wgrad: two-workgroups-per-CU vs producer/consumer kernel (different split-K widths: equal up to rounding)."""
+    B, cin, cout, H, W = shape
+    rng = np.random.default_rng(13)
+    x = rb(rnd(rng, B, cin, H, W), dcode)
+    gz = rb(rnd(rng, B, cout, H, W), dcode)
+    xt, gzt = C.ops.to_nhwc(dev(x), dcode), C.ops.to_nhwc(dev(gz), dcode)
+    cin_p, cout_p = C.ops.cpad(cin), C.ops.cpad(cout)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    wsb = lib.load().clamd_wgrad_workspace_bytes(0, B, H, W, cout_p, cin_p, dcode)
+    ws = torch.empty(wsb // 4 + 4, device='cuda')
+    rgw = O.conv3x3_bwd(x, np.zeros((cout, cin, 3, 3), np.float32), gz)[1]
+    try:
+        for v in (0, 1):
+            lib.load().clamd_set_tuning(b'wgrad_ws', v)
+            gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
+            lib.call('clamd_wgrad', 0, ptr(gzt), cout_p, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, cin_p, cout, cin,
+                     cout, cout_p, cin, cin_p, dcode, s)
+            sync()
+            assert rel_l2(gw.cpu().numpy(), rgw) < (6e-5 if dcode == 2 else 2e-5), v
+    finally:
+        lib.load().clamd_set_tuning(b'wgrad_ws', 1)
+
+
 @pytest.mark.parametrize('name,dcode', DT)
 @pytest.mark.parametrize('shape', [(2, 6, 3, 4, 5), (1, 128, 64, 16, 16), (2, 70, 40, 8, 48)])
 def test_convT2x2_fwd_dgrad_wgrad(C, name, dcode, shape):

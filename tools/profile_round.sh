@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round profile on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh <tag>
+# Writes gpurun_out/<tag>_*: un-profiled default bench, per-dtype rocprofv3 kernel stats, per-dtype PMC traffic passes.
+set -o pipefail
+tag=${1:-rXX}
+root=$PWD
+cd /tmp && export TMPDIR=/tmp && cd "$root"
+timeout -k 10 400 python bench.py --steps 10 --warmup 3 --also bf16x3,bf16 > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err || exit 1
+for dt in fp32 bf16x3 bf16; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_$dt -o $tag -- python3 bench.py --steps 6 --warmup 2 --dtype $dt --no-cpu-baseline --also "" > gpurun_out/${tag}_bench_${dt}_under_rocprof.json 2> gpurun_out/${tag}_prof_$dt.err || exit 2
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_${dt}_$c -o pmc -- python3 bench.py --steps 2 --warmup 1 --dtype $dt --no-cpu-baseline --also "" --no-kernel-timing > gpurun_out/${tag}_pmc_${dt}_$c.json 2> gpurun_out/${tag}_pmc_${dt}_$c.err || exit 3
+  done
+  echo "done $dt"
+done

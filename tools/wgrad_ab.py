@@ -21,10 +21,17 @@ for cin, cout, hw in layers:
     best = {v: 1e9 for v in variants}
     def run():
         call('clamd_wgrad', 0, ptr(g), cout, ptr(x), cin, ptr(ws), wsb, ptr(gw), B, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, dc, s)
+    ref = None
     for rd in range(rounds):
         for v in variants:
             lib.clamd_set_tuning(key, v)
             run()
+            if rd == 0:      # variants may differ in split-K / summation order, never by more than rounding
+                torch.cuda.synchronize()
+                if ref is None: ref = gw.clone()
+                else:
+                    err = ((gw - ref).norm() / ref.norm()).item()
+                    assert err < 2e-3, f'variant {v}: rel diff {err}'
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters): run()
