@@ -115,7 +115,7 @@ def pmc_traffic(dtype):
     d = json.load(open(files[-1]))
     tot, n = 0.0, 0
     for k, v in d['kernels'].items():
-        if (k.startswith('igemm_kernel<') and k.replace(' ', '').split(',')[1:3] == ['0', '0']) or k.startswith('igemm_ws_kernel<'):
+        if (k.startswith('igemm_kernel<') and k.replace(' ', '').split(',')[1:3] == ['0', '0']) or k.startswith(('igemm_ws_kernel<', 'igemm_pws_kernel<')):
             tot += (v['hbm_read_bytes_per_launch'] + v['hbm_write_bytes_per_launch']) * v['launches']
             n += v['launches']
     return round(tot / n) if n else None
@@ -162,8 +162,8 @@ def main():
             traffic = pmc_traffic(args.dtype)
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK[args.dtype], 'unit': 'TFLOP/s',
                                'frac': round(ach / PEAK[args.dtype], 4), 'traffic': traffic,
-                               'kernel': 'conv3x3 implicit GEMM, fwd + dgrad launches: clamd::igemm_kernel<T,CONV3,NHWC,TW,0> (short K) and '
-                                         'clamd::igemm_ws_kernel<T,TW,MT> (>= 256 input channels)',
+                               'kernel': 'conv3x3 implicit GEMM, fwd + dgrad launches: clamd::igemm_pws_kernel<T,TW> (persistent, < 256 input '
+                                         'channels) and clamd::igemm_ws_kernel<T,TW,MT> (>= 256 input channels)',
                                'launches': n, 'avg_launch_ms': round(sec / n * 1e3, 4),
                                'ms_per_step': round(sec / 2 * 1e3, 3),
                                'timing': 'HIP events around every launch, 2 instrumented steps after the timed region'}

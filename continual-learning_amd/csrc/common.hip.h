@@ -155,6 +155,19 @@ __device__ inline float wave_sum(float v) {
     return v;
 }
 
+// Issue-order hint for a software-pipelined MFMA loop: NM MFMAs of the current step interleaved with the NR LDS reads
+// that prefetch the next one, reads spread evenly BEHIND the MFMAs (first an MFMA, then its share of reads, ...), so the
+// reads issue while an MFMA occupies the matrix pipe instead of in a burst between two MFMA bursts.
+template <int NM, int NR, int I = 0>
+__device__ inline void sched_mfma_reads() {
+    if constexpr (I < NM) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        constexpr int n = ((I + 1) * NR) / NM - (I * NR) / NM;
+        if constexpr (n > 0) __builtin_amdgcn_sched_group_barrier(0x100, n, 0);
+        sched_mfma_reads<NM, NR, I + 1>();
+    }
+}
+
 constexpr int STAT_REPLICAS = 16;   // per-channel atomic accumulators are replicated to spread contention
 
 }  // namespace clamd

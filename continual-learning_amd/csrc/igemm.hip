@@ -413,6 +413,7 @@ static_assert(Geo<MODE_PW, 16>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4, "L
 extern int g_wgrad_target_blocks;
 extern int g_wgrad_tw16;
 extern int g_wgrad_ws;
+extern int g_wgrad_xcd;
 static int g_igemm_variant = 0;
 static int g_igemm_pws = 1;        // persistent producer/consumer kernel: 1 = short-K layers (< 256 input channels), 2 = every layer, 0 = never
 static int g_igemm_ws = 2;         // 0: never, 1: always (128x2-pixel tiles), 3: always (128x4), 2: where it measured faster
@@ -474,6 +475,7 @@ int clamd_set_tuning(const char* key, int value) {
     if (!strcmp(key, "igemm_pws")) { g_igemm_pws = value; return 0; }
     if (!strcmp(key, "wgrad_tw16")) { g_wgrad_tw16 = value; return 0; }
     if (!strcmp(key, "wgrad_ws")) { g_wgrad_ws = value; return 0; }
+    if (!strcmp(key, "wgrad_xcd")) { g_wgrad_xcd = value; return 0; }
     if (!strcmp(key, "wgrad_blocks")) { if (value < 1 || value > 512) return clamd_fail("wgrad_blocks: 1..512"); g_wgrad_target_blocks = value; return 0; }
     return clamd_fail("set_tuning: unknown key");
 }

@@ -193,8 +193,8 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
                         mma_bf16(c[2 * mt + 1], c[2 * MT + 2], acc[mt][1]); mma_bf16(c[2 * mt], c[2 * MT + 3], acc[mt][1]);
                         mma_bf16(c[2 * mt], c[2 * MT + 2], acc[mt][1]);
                     }
-                    if (t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT, 0);
+                    if (t + 1 < NT) sched_mfma_reads<6 * MT, 2 * MT + 4>();
+                    else __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT, 0);
                 }
 #undef WS_FRAG_S
             } else {
@@ -220,8 +220,8 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
                         mma16<T>(c[mt], c[MT], acc[mt][0]);
                         mma16<T>(c[mt], c[MT + 1], acc[mt][1]);
                     }
-                    if (st + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, NMF * MT / 2, 0);
+                    if (st + 1 < NSTEP) sched_mfma_reads<NMF * MT / 2, MT + 2>();
+                    else __builtin_amdgcn_sched_group_barrier(0x008, NMF * MT / 2, 0);
                 }
 #undef WS_FRAG
             }

@@ -40,6 +40,7 @@ struct WgradParams {
     int B, H, W;           // pixel grid of A
     int Rp, Cp;            // physical channels of A / B
     int nsplit, tiles_per_split;
+    int xcd;               // XCD-aware block order (tuning knob "wgrad_xcd")
 };
 
 template <typename T, int MODE, int TW> struct WGeo {
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(WS ? 512 : 256, 2) wgrad_kernel(const WgradPar
     const int wr = wave >> 1, wc = wave & 1;
 
     const int rt = (p.Rp + 63) >> 6, ct = (p.Cp + 63) >> 6;
-    int bid = blockIdx.x;
+    int bid = p.xcd ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;     // an XCD gets a contiguous id range: neighbouring (tr, tc) tiles of ONE pixel range share its L2
     const int tr = bid % rt; bid /= rt;
     const int tc = bid % ct; bid /= ct;
     const int split = bid;
@@ -281,8 +282,14 @@ __global__ void __launch_bounds__(WS ? 512 : 256, 2) wgrad_kernel(const WgradPar
             }                                                                                                      \
             mma_bf16(Ah[par_s], Bh[sl_][dx], acc[3 * dy_s + dx]);                                                  \
         }                                                                                                          \
-        __builtin_amdgcn_sched_group_barrier(0x100, NRD + (gn_ % 3 == 0 ? NRA : 0), 0);   /* R(g+D) ... */         \
-        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);                              /* ... then M(g) */      \
+        /* issue order: the MFMAs of group g interleaved with the reads of group g+D, one tap at a time, so the */   \
+        /* reads issue while an MFMA occupies the pipe instead of between two bursts                             */   \
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF / 3, 0);                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD / 3, 0);                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF / 3, 0);                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD / 3, 0);                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF / 3, 0);                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD / 3 + (gn_ % 3 == 0 ? NRA : 0), 0);                         \
     } while (0)
 #pragma unroll 1
                 for (int ub = 0; ub < NU; ub += 2) {
@@ -380,6 +387,9 @@ __global__ void __launch_bounds__(WS ? 512 : 256, 2) wgrad_kernel(const WgradPar
     } else {
         unsigned long long c0 = WGD_T(), c1, dm = 0, dc = 0;
         (void)c1; (void)dm; (void)dc;
+#ifdef CLAMD_DIAG
+        const unsigned long long k0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
         __syncthreads();                                   // stage 0 is ready
         const int n2 = max(t_end - t_begin, 0) + (max(t_end - t_begin, 0) & 1);        // periods: tiles rounded up to even
         for (int tile = t_begin; tile < t_begin + n2; ++tile) {
@@ -390,6 +400,12 @@ __global__ void __launch_bounds__(WS ? 512 : 256, 2) wgrad_kernel(const WgradPar
             dm += c1 - c0; dc += WGD_T() - c1;
         }
         WGD_ADD(5, dm); WGD_ADD(6, dc);                    // [5] consumer multiply [6] consumer at barrier
+#ifdef CLAMD_DIAG
+        if (wave == 0) {                                   // [2] shader cycles, [3] 100-MHz ticks of the tile loop: the clock the chip held
+            WGD_ADD(2, __builtin_amdgcn_s_memtime() - k0);
+            WGD_ADD(3, __builtin_amdgcn_s_memrealtime() - rt0);
+        }
+#endif
         if (wave == 0) WGD_ADD(7, 1);                      // [7] workgroups
     }
 
@@ -493,6 +509,7 @@ int g_wgrad_tw16 = 0;               // tuning knob: 1 = 16-wide tiles everywhere
 static inline int wgrad_tw(int W, int mode, bool split) { return (W >= 32 && !(split && mode == WG_CONV3) && !g_wgrad_tw16) ? 32 : 16; }
 
 int g_wgrad_target_blocks = 512;   // tuning knob (clamd_set_tuning "wgrad_blocks"): split-K until about this many workgroups
+int g_wgrad_xcd = 1;
 int g_wgrad_ws = 1;                // tuning knob "wgrad_ws": producer/consumer kernel (one 512-thread workgroup per CU) for the 3x3 convs
 
 template <typename T, int MODE, bool WS>
@@ -576,7 +593,7 @@ int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, fl
     nsplit = (ntiles + per - 1) / per;
     const size_t need = (size_t)nsplit * NT * Rp * Cp * sizeof(float);
     if (need > ws_bytes) return clamd_fail("wgrad: workspace too small");
-    WgradParams p{a, a_ldc, b, b_ldc, workspace, B, H, W, Rp, Cp, nsplit, per};
+    WgradParams p{a, a_ldc, b, b_ldc, workspace, B, H, W, Rp, Cp, nsplit, per, g_wgrad_xcd};
     const int grid = rt * ct * nsplit;
     hipStream_t s = (hipStream_t)stream;
     int e;

@@ -1,0 +1,67 @@
+"""Turns the output of tools/profile_round.sh (gpurun_out/<tag>_*) into the committed evidence under profiles/:
+
+    python tools/make_profiles.py r01b r01      # scratch tag -> committed prefix
+
+copies the kernel-stats CSVs and bench JSON lines, builds the per-kernel HBM traffic JSONs (tools/pmc_summary.py) and
+rewrites profiles/README.md.
+"""
+import csv, glob, json, os, shutil, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = sys.argv[1], sys.argv[2]
+G, P = os.path.join(ROOT, 'gpurun_out'), os.path.join(ROOT, 'profiles')
+DT = ['fp32', 'bf16x3', 'bf16']
+STEPS_PROF, STEPS_PMC = 10, 3          # 6 + 2 warm-up + 2 instrumented steps; 2 + 1 warm-up
+
+
+def last_json(path):
+    return json.loads([l for l in open(path).read().splitlines() if l.startswith('{')][-1])
+
+
+shutil.copy(f'{G}/{src}_bench_default.json', f'{P}/{dst}_bench_default.json')
+for dt in DT:
+    shutil.copy(f'{G}/{src}_prof_{dt}/{src}_kernel_stats.csv', f'{P}/{dst}_{dt}_kernel_stats.csv')
+    shutil.copy(f'{G}/{src}_bench_{dt}_under_rocprof.json', f'{P}/{dst}_bench_{dt}_under_rocprof.json')
+    out = subprocess.run([sys.executable, f'{ROOT}/tools/pmc_summary.py', f'{G}/{src}_pmc_{dt}_FETCH_SIZE',
+                          f'{G}/{src}_pmc_{dt}_WRITE_SIZE', dt, str(STEPS_PMC)], capture_output=True, text=True, check=True).stdout
+    open(f'{P}/{dst}_traffic_{dt}.json', 'w').write(out)
+
+b = last_json(f'{P}/{dst}_bench_default.json')
+L = []
+L.append(f'# profiles/ — round evidence `{dst}` (MI355X, ROCm 7.2, one GPU)\n')
+L.append('All files come from one `gpurun` box: `bash tools/profile_round.sh <tag>` then `python tools/make_profiles.py <tag> ' + dst + '`.\n')
+L.append('| file | what |\n|---|---|')
+L.append(f'| `{dst}_bench_default.json` | `python bench.py --steps 10 --warmup 3` (the driver\'s command): fp32 headline + `also` bf16x3 / bf16 + `cpu_baseline` |')
+L.append(f'| `{dst}_<dtype>_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 6 --warmup 2 --dtype <dtype> --no-cpu-baseline --also ""` (8 steps + 2 instrumented steps) |')
+L.append(f'| `{dst}_bench_<dtype>_under_rocprof.json` | the JSON line that same profiled command printed (clocks are lower under the profiler) |')
+L.append(f'| `{dst}_traffic_<dtype>.json` | per-kernel HBM bytes from two separate `--pmc` passes (FETCH_SIZE, WRITE_SIZE), `tools/pmc_summary.py`; FETCH_SIZE doubled per the gfx950 rule in MI355X_MICROARCH.md §HBM |\n')
+L.append('## Headline (un-profiled run)\n')
+L.append('| dtype | images/s | ms/step | step FLOP/s ÷ MFMA peak | conv3x3 fwd+dgrad kernels | conv3x3 wgrad (+reduce) |\n|---|---|---|---|---|---|')
+r, w = b['roofline'], b['roofline_wgrad']
+L.append(f"| f32 (exact fp32 MFMA) — default | {b['value']} | {b['ms_per_step']} | {b['step_frac_of_mfma_peak']} of {r['peak']} TF | {r['achieved']} TF/s = {r['frac']} | {w['achieved']} TF/s = {w['frac']} |")
+PK = {'bf16x3': 833.3, 'bf16': 2500.0}
+for a in b.get('also', []):
+    key = 'bf16x3' if a['dtype'].startswith('bf16x3') else 'bf16'
+    L.append(f"| {key} | {a['value']} | {a['ms_per_step']} | {a['step_frac_of_mfma_peak']} of {PK[key]:.0f} TF | {a.get('conv3x3_igemm_tflops')} TF/s = {a.get('conv3x3_igemm_frac_of_peak')} | {a.get('conv3x3_wgrad_tflops')} TF/s = {round(a.get('conv3x3_wgrad_tflops', 0) / PK[key], 4)} |")
+c = b.get('cpu_baseline')
+if c:
+    L.append(f"\nCPU baseline (stock torch.nn counterpart, same box): {c['value']} {c['unit']} on {c['cores']} cores ({c['sample']}).\n")
+L.append('## Time per step by kernel (rocprofv3, 10 steps per profile)\n')
+for dt in DT:
+    rows = list(csv.DictReader(open(f'{P}/{dst}_{dt}_kernel_stats.csv')))
+    tot = sum(float(x['TotalDurationNs']) for x in rows)
+    tr = json.load(open(f'{P}/{dst}_traffic_{dt}.json'))
+    L.append(f"### {dt}: {tot / STEPS_PROF / 1e6:.2f} ms of GPU time per step, {tr['hbm_bytes_per_step_all_kernels'] / 1e9:.1f} GB of HBM traffic per step\n")
+    L.append('| % | avg µs | launches/step | kernel |\n|---|---|---|---|')
+    for x in rows[:14]:
+        name = x['Name'].replace('void ', '').replace('clamd::', '').split('(')[0]
+        L.append(f"| {float(x['TotalDurationNs']) / tot * 100:.1f} | {float(x['AverageNs']) / 1e3:.1f} | {int(x['Calls']) / STEPS_PROF:.1f} | `{name}` |")
+    L.append('')
+    L.append('HBM bytes per launch (PMC) of the dominant kernels:\n')
+    L.append('| kernel | read MB | write MB | avg µs | GB/s |\n|---|---|---|---|---|')
+    for k, v in list(tr['kernels'].items())[:8]:
+        by = v['hbm_read_bytes_per_launch'] + v['hbm_write_bytes_per_launch']
+        L.append(f"| `{k}` | {v['hbm_read_bytes_per_launch'] / 1e6:.1f} | {v['hbm_write_bytes_per_launch'] / 1e6:.1f} | {v['avg_launch_us']} | {by / max(v['avg_launch_us'], 1e-9) / 1e3:.0f} |")
+    L.append('')
+open(f'{P}/README.md', 'w').write('\n'.join(L) + '\n')
+print('\n'.join(L[:30]))

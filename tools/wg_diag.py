@@ -19,8 +19,11 @@ for cin, cout, hw in [(64, 64, 256), (256, 256, 64), (512, 512, 32), (1024, 1024
     s = C._lib.stream_ptr()
     def run():
         call('clamd_wgrad', 0, ptr(g), cout, ptr(x), cin, ptr(ws), wsb, ptr(gw), B, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, dc, s)
-    run(); run(); torch.cuda.synchronize(); lib.clamd_debug_wg_diag(out, 1)
+    for _ in range(300): run()
+    torch.cuda.synchronize(); lib.clamd_debug_wg_diag(out, 1)
     run(); torch.cuda.synchronize(); lib.clamd_debug_wg_diag(out, 1)
     v = list(out); nb = max(v[7], 1)
-    names = ['prod prologue', 'prod load wait', 'prod LDS store', 'prod load issue', 'prod at barrier', 'cons multiply', 'cons at barrier']
-    print(f'{cin}x{cout}@{hw}: blocks {nb}; per-wave cycles per block: ' + ', '.join(f'{n} {v[i] / (nb * 4):.0f}' for i, n in enumerate(names)))
+    names = ['prod prologue', 'prod wait+store+issue', None, None, 'prod at barrier', 'cons multiply', 'cons at barrier']
+    clk = v[2] / max(v[3], 1) * 0.1
+    print(f'   in-kernel clock {clk:.2f} GHz (shader cycles / 100-MHz ticks over the tile loop, wave 0 of each workgroup)')
+    print(f'{cin}x{cout}@{hw}: blocks {nb}; per-wave cycles per block: ' + ', '.join(f'{n} {v[i] / (nb * 4):.0f}' for i, n in enumerate(names) if n))
