@@ -41,8 +41,12 @@ __device__ inline uint16_t f2bf(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(uint16_t, b);
 }
-__device__ inline uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ inline uint32_t pack2bf(float lo, float hi) {      // one v_cvt_pk_bf16_f32
+    bf16x2_t r;
+    r.x = (__bf16)lo;
+    r.y = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, r);
 }
 
 // 8 consecutive channels <-> fp32 registers
@@ -137,6 +141,21 @@ __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned by
 __device__ inline uint4 buf_ld16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ inline void buf_st16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const uint4& v) {
+    u32x4 d; d.x = v.x; d.y = v.y; d.z = v.z; d.w = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff, soff, 0);
+}
+// 8 consecutive channels (fp32 registers) -> one (bf16) or two (fp32 storage) range-checked 16-byte buffer stores;
+// lanes whose offset is BUF_OOB store nothing
+template <typename T> __device__ inline void buf_st8(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        buf_st16(rs, voff, soff, make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])));
+    } else {
+        buf_st16(rs, voff, soff, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
+        buf_st16(rs, voff, soff + 16, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])));
+    }
 }
 
 // Row of accumulator register `reg` (0..15) for lane half h in a 32x32 MFMA tile; column = lane & 31.

@@ -415,7 +415,7 @@ extern int g_wgrad_tw16;
 extern int g_wgrad_ws;
 extern int g_wgrad_xcd;
 static int g_igemm_variant = 0;
-static int g_igemm_pws = 1;        // persistent producer/consumer kernel: 1 = short-K layers (< 256 input channels), 2 = every layer, 0 = never
+static int g_igemm_pws = 1;        // persistent producer/consumer kernel: 1 = short-K layers (<= 256 input channels), 2 = every layer, 0 = never
 static int g_igemm_ws = 2;         // 0: never, 1: always (128x2-pixel tiles), 3: always (128x4), 2: where it measured faster
                                    // (interleaved A/B, tools/conv_ab.py): long K loops (>= 256 input channels), where the
                                    // two-stage pipeline fills and the 512-pixel tile halves the filter traffic per MFMA
@@ -459,6 +459,7 @@ static int check_common(const IgemmParams& p, const char* who) {
     // buffer descriptors address ONE image with 32-bit byte offsets (OOB marker = 2^31)
     const long long img_bytes = (long long)p.H * p.W * p.x_ldc * (who[0] == 'u' ? 4 : 1) * 4;
     if (img_bytes >= (1ll << 31)) return clamd_fail("igemm: one image exceeds 2^31 bytes");
+    if ((long long)p.H * p.W * p.y_ldc * (who[0] == 'u' ? 4 : 1) * 4 >= (1ll << 31)) return clamd_fail("igemm: one output image exceeds 2^31 bytes");
     if ((long long)9 * p.Np * p.Kp * 4 >= (1ll << 31)) return clamd_fail("igemm: packed filter exceeds 2^31 bytes");
     return 0;
 }
@@ -485,13 +486,13 @@ int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* b
                   int m_fastest, int dtype, void* stream) {
     IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, m_fastest, bn_y, bn_sums};
     if (int e = check_common(p, "conv3x3")) return e;
-    if (g_igemm_pws == 2 || (g_igemm_pws == 1 && Cin_p < 256)) {
+    if (g_igemm_pws == 2 || (g_igemm_pws == 1 && Cin_p <= 256)) {     // measured: faster up to 256 input channels (tools/conv_ab.py)
         const int e = launch_igemm_pws(p, dtype, (hipStream_t)stream);
         if (e != -1) return e;                                       // -1: shape not supported there, fall through
     }
     if (g_igemm_ws == 1 || g_igemm_ws == 3 || g_igemm_ws == 4)      // forced: 256- / 512- / 128-pixel tiles
         return launch_igemm_ws(p, dtype, (hipStream_t)stream, g_igemm_ws == 1 ? 2 : g_igemm_ws == 3 ? 4 : 1);
-    if (g_igemm_ws == 2 && Cin_p >= 256) {
+    if (g_igemm_ws == 2 && Cin_p >= 256) {                           // (exactly 256 only when the persistent kernel declined)
         // one workgroup per CU: take the 512-pixel tile only if it still gives every CU a workgroup
         const long long ntn = (Cout_p + 63) / 64;
         const long long blocks4 = (long long)B * ((H + 15) / 16) * ((W + 31) / 32) * ntn;

@@ -17,6 +17,16 @@
 
 namespace clamd {
 
+#ifdef CLAMD_DIAG
+// diagnostic build only (python build.py --diag): consumer-side cycle shares, summed over workgroups
+__device__ unsigned long long g_pws_diag[8];
+#define PWD_T() __builtin_amdgcn_s_memtime()
+#define PWD_ADD(i_, v_) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_pws_diag[i_], (unsigned long long)(v_)); } while (0)
+#else
+#define PWD_T() 0ull
+#define PWD_ADD(i_, v_) do { } while (0)
+#endif
+
 template <typename T, int TW>
 __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, const int gm) {
     constexpr int MT = 2;
@@ -151,9 +161,21 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             bcol[nt] = (p.bias && n < p.Np) ? p.bias[n] : 0.f;
         }
         float* const wbuf = reinterpret_cast<float*>(smem + 2 * STAGE) + cw * 32 * 68;   // this wave's transposition block
-        T* const out = (T*)p.y;
+        const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+        const unsigned y_img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.y_ldc * (unsigned)sizeof(T);
+        unsigned st_vo[MT][4];                     // tile-relative byte offsets of the 8-channel pieces this lane stores
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int m = 32 * MT * cw + 32 * mt + ps * 8 + (lane >> 3), n = n0 + (lane & 7) * 8;
+                st_vo[mt][ps] = n < p.Np ? (unsigned)(((m / TW) * p.W + m % TW) * p.y_ldc + n) * (unsigned)sizeof(T) : BUF_OOB;
+            }
 
+        unsigned long long d0 = PWD_T(), d1, d2, dk = 0, db = 0, de = 0;
+        (void)d1; (void)d2; (void)dk; (void)db; (void)de;
         __syncthreads();                                   // step 0 is staged
+        PWD_ADD(0, PWD_T() - d0);                          // [0] wait for the first stage
         for (int ti = 0; ti < T_; ++ti) {
             f32x16 acc[MT][2];
 #pragma unroll
@@ -164,6 +186,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
             for (int ks = 0; ks < nk; ++ks) {
+                d0 = PWD_T();
                 const uint4* sm = smem + (ks & 1) * STAGE;         // nk is even: the stage parity restarts with every tile
                 if constexpr (SPLIT) {
                     uint4 f[2][2 * MT + 4];      // [buffer][a_hi[mt], a_lo[mt] ..., bh0, bl0, bh1, bl1]
@@ -224,45 +247,70 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                     }
 #undef PWS_FRAG
                 }
+                d1 = PWD_T();
                 __syncthreads();                           // hand the stage back to the producers
+                dk += d1 - d0; db += PWD_T() - d1;
             }
+            d2 = PWD_T();
 
             // ---- epilogue of this tile: bias, ReLU, statistics, wave-private transposition, 16-byte stores.
             // No workgroup barrier: the producers are already staging the next tile and meet the consumers again at
-            // the barrier of its first K-step.
+            // the barrier of its first K-step.  Kept lean on purpose -- with 2-4 K-steps per tile this code, not the
+            // MFMA loop, was 44 % of the consumer cycles of the 64-channel bf16 layers (tools/ws_diag.py ... pws):
+            // ReLU is a max with 0 / -inf (no select), the stores are range-checked buffer stores whose per-lane offsets
+            // are tile-relative constants (tile origin = scalar offset), edge masks exist only on ragged tiles.
             const int tm = mg + ti * gm;
             const int x0 = (tm % tiles_x) * TW, y0 = ((tm / tiles_x) % tiles_y) * TH, b = tm / (tiles_x * tiles_y);
+            const __amdgpu_buffer_rsrc_t yrs = make_rsrc((const char*)p.y + (size_t)b * y_img, y_img);
+            const unsigned y_so = (unsigned)((y0 * p.W + x0) * p.y_ldc) * (unsigned)sizeof(T);
+            const bool full = y0 + TH <= p.H && x0 + TW <= p.W;            // wave-uniform
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+                if (full) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float v = acc[mt][nt][e] + bcol[nt];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        const int m = 32 * MT * cw + 32 * mt + acc_row(e, h);
-                        const bool valid = y0 + m / TW < p.H && x0 + m % TW < p.W;
-                        const float vs = valid ? v : 0.f;
-                        st1[nt] += vs;
-                        st2[nt] += vs * vs;
-                        wbuf[acc_row(e, h) * 68 + 32 * nt + r] = v;
-                    }
+                        for (int e = 0; e < 16; ++e) {
+                            const float v = fmaxf(acc[mt][nt][e] + bcol[nt], relu_lo);
+                            st1[nt] += v;
+                            st2[nt] = fmaf(v, v, st2[nt]);
+                            wbuf[acc_row(e, h) * 68 + 32 * nt + r] = v;
+                        }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float v = fmaxf(acc[mt][nt][e] + bcol[nt], relu_lo);
+                            const int m = 32 * MT * cw + 32 * mt + acc_row(e, h);
+                            const float vs = (y0 + m / TW < p.H && x0 + m % TW < p.W) ? v : 0.f;
+                            st1[nt] += vs;
+                            st2[nt] = fmaf(vs, vs, st2[nt]);
+                            wbuf[acc_row(e, h) * 68 + 32 * nt + r] = v;
+                        }
+                }
+                float4 lo[4], hi[4];                       // all four row pieces first: one LDS round trip, not four
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
                     const int row = ps * 8 + (lane >> 3), cgp = lane & 7;
-                    const int m = 32 * MT * cw + 32 * mt + row;
-                    const int yy = y0 + m / TW, xx = x0 + m % TW;
-                    const int n = n0 + cgp * 8;
-                    const float4 lo = *reinterpret_cast<const float4*>(wbuf + row * 68 + cgp * 8);
-                    const float4 hi = *reinterpret_cast<const float4*>(wbuf + row * 68 + cgp * 8 + 4);
-                    if (yy < p.H && xx < p.W && n < p.Np) {
-                        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                        const long long pixo = ((long long)b * p.H + yy) * p.W + xx;
-                        Vec8<T>::store(out + pixo * p.y_ldc + n, v);
+                    lo[ps] = *reinterpret_cast<const float4*>(wbuf + row * 68 + cgp * 8);
+                    hi[ps] = *reinterpret_cast<const float4*>(wbuf + row * 68 + cgp * 8 + 4);
+                }
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const float v[8] = {lo[ps].x, lo[ps].y, lo[ps].z, lo[ps].w, hi[ps].x, hi[ps].y, hi[ps].z, hi[ps].w};
+                    unsigned vo = st_vo[mt][ps];
+                    if (!full) {
+                        const int m = 32 * MT * cw + 32 * mt + ps * 8 + (lane >> 3);
+                        if (!(y0 + m / TW < p.H && x0 + m % TW < p.W)) vo = BUF_OOB;
                     }
+                    buf_st8<T>(yrs, vo, y_so, v);
                 }
             }
+            de += PWD_T() - d2;
         }
+        PWD_ADD(1, dk); PWD_ADD(2, db); PWD_ADD(3, de);    // [1] MFMA loops [2] at the K-step barriers [3] epilogues
+        if (wave == 0) PWD_ADD(7, 1);                      // [7] workgroups
     }
 
     // ---------------------------------------------------------------------- statistics: one flush per workgroup
@@ -293,6 +341,17 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
 }
 
 static int g_num_cus = 0;
+
+}  // namespace clamd
+#ifdef CLAMD_DIAG
+extern "C" int clamd_debug_pws_diag(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(clamd::g_pws_diag), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(clamd::g_pws_diag), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+namespace clamd {
+
 
 template <typename T>
 static int launch_pws_t(const IgemmParams& p, hipStream_t s) {

@@ -67,13 +67,17 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
         const unsigned img_elems = (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc;
         const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x + (size_t)b * img_elems * ESZ, img_elems * ESZ);
         const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.w, (unsigned)(9u * p.Np * p.Kp * ESZ));
+        // halo pixel of staging slot j; the ragged last pass wraps around and re-stages the first pixels (same data, same
+        // LDS slot), so every load has an unconditional store (a store guarded by "slot < NPIX" lets the compiler sink
+        // the load next to it, behind a full s_waitcnt vmcnt(0))
+        auto slot_pix = [&](int j) { const int pix = (ltid >> 2) + 64 * j; return pix >= NPIX ? pix - NPIX : pix; };
         unsigned in_vo[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int pix = (ltid >> 2) + 64 * j;
+            const int pix = slot_pix(j);
             const int hy = pix / HW_, hx = pix - hy * HW_;
             const int yy = y0 + hy - 1, xx = x0 + hx - 1;
-            in_vo[j] = (pix < NPIX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
+            in_vo[j] = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
                            ? (unsigned)(((yy * p.W + xx) * p.x_ldc + g4 * VEC) * ESZ) : BUF_OOB;
         }
         const int wco = ltid >> 2;
@@ -82,31 +86,33 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
         // Input chunks are fetched in PAIRS (two back-to-back 64-byte pieces = one full 128-byte line per pixel while the
         // line is still in L1): fetching one 64-byte piece per K-step, a whole period apart, made every line cross the
         // L2->CU path twice and capped the producers at ~11.5 B/clk/CU (tools/ws_diag.py, diagnostic build).
+        // live_ = false issues the same instructions with every lane out of range (a fixed load schedule lets the compiler
+        // count vmcnt instead of draining it).
         uint4 rinA[NJ], rinB[NJ], rw[NT];
 
-#define WS_GLOAD_IN2(kp_)                                                                                         \
+#define WS_GLOAD_IN2(kp_, RA, RB, live_)                                                                          \
     do {                                                                                                          \
         const unsigned so_ = (unsigned)(2 * (kp_) * KC * ESZ);                                                    \
-        const bool two_ = 2 * (kp_) + 1 < nk;                      /* wave-uniform */                             \
+        const bool l_ = (live_);                                   /* wave-uniform */                             \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                          \
-            rinA[j] = buf_ld16(xrs, in_vo[j], so_);                                                               \
-            if (two_) rinB[j] = buf_ld16(xrs, in_vo[j], so_ + KC * ESZ);                                          \
+            RA[j] = buf_ld16(xrs, l_ ? in_vo[j] : BUF_OOB, so_);                                                  \
+            RB[j] = buf_ld16(xrs, l_ ? in_vo[j] : BUF_OOB, so_ + KC * ESZ);                                       \
         }                                                                                                         \
     } while (0)
-#define WS_GLOAD_W(ks_)                                                                                           \
+#define WS_GLOAD_W(ks_, live_)                                                                                    \
     do {                                                                                                          \
+        const unsigned wv_ = (live_) ? w_vo : BUF_OOB;                                                            \
         _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                            \
-            rw[t] = buf_ld16(wrs, w_vo, (unsigned)((ks_) * NT + t) * w_slab);                                     \
+            rw[t] = buf_ld16(wrs, wv_, (unsigned)((ks_) * NT + t) * w_slab);                                      \
     } while (0)
 #define WS_STORE(st_, RIN)                                                                                        \
     do {                                                                                                          \
         uint4* sm_ = smem + (st_) * STAGE;                                                                        \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                          \
-            const int pix_ = (ltid >> 2) + 64 * j;                                                                \
-            const bool in_ = 64 * (j + 1) <= NPIX || pix_ < NPIX;                                                 \
+            const int pix_ = slot_pix(j);                                                                         \
             if constexpr (!SPLIT) {                                                                               \
-                if (in_) sm_[g4 * NPIXP + pix_] = RIN[j];                                                         \
-            } else if (in_) {                                                                                     \
+                sm_[g4 * NPIXP + pix_] = RIN[j];                                                                  \
+            } else {                                                                                              \
                 uint2 hi_, lo_;                                                                                   \
                 split4(RIN[j], hi_, lo_);                                                                         \
                 char* b_ = reinterpret_cast<char*>(sm_) + ((g4 >> 1) * NPIXP + pix_) * 16 + 8 * (g4 & 1);         \
@@ -117,37 +123,63 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
         _Pragma("unroll") for (int t = 0; t < NT; ++t) sm_[G::IN_SLOTS + (t * 4 + g4) * G::WG + wco] = rw[t];     \
     } while (0)
 
-        unsigned long long t0 = DIAG_T(), t1, d_store = 0, d_bar = 0, d_wait = 0, d_st = 0;
-        (void)d_wait; (void)d_st;
-        WS_GLOAD_IN2(0);
-        WS_GLOAD_W(0);
-        WS_STORE(0, rinA);
-        if (nk > 1) WS_GLOAD_W(1);
-        __syncthreads();                                   // stage 0 is ready
-        DIAG_ADD(0, DIAG_T() - t0);                        // [0] producer prologue
-        for (int ks = 0; ks < nk; ++ks) {
+        unsigned long long t0 = DIAG_T(), t1, d_store = 0, d_bar = 0;
+        (void)t1; (void)d_store; (void)d_bar;
+#define WS_PERIOD_END()                                                                                           \
+    do { t1 = DIAG_T(); __syncthreads(); d_store += t1 - t0; d_bar += DIAG_T() - t1; t0 = DIAG_T(); } while (0)
+        if ((nk & 3) == 0) {
+            // Deep schedule (K-steps in fours, every layer with >= 128 input channels): TWO pair sets, a pair is fetched
+            // 3-4 periods before it is staged.  With one set the data of every other K-step had a single period
+            // (2.3-4.6k cycles in bf16) to arrive from HBM; whenever it was late the consumers sat at the barrier -- 20-30 %
+            // of their cycles on the long-K bf16 / bf16x3 layers (tools/ws_diag.py).  Filters come from L2: one set.
+            uint4 rinC[NJ], rinD[NJ];
+            const int npair = nk >> 1;
+            WS_GLOAD_IN2(0, rinA, rinB, true);
+            WS_GLOAD_IN2(1, rinC, rinD, true);
+            WS_GLOAD_W(0, true);
+            WS_STORE(0, rinA);
+            WS_GLOAD_W(1, true);
+            __syncthreads();                               // stage 0 is ready
+            DIAG_ADD(0, DIAG_T() - t0);                    // [0] producer prologue
             t0 = DIAG_T();
-#ifdef CLAMD_DIAG
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            d_wait += DIAG_T() - t0;
-#endif
-            if (ks + 1 < nk) {                             // consumers are reading stage ks&1
-                if ((ks + 1) & 1) WS_STORE((ks + 1) & 1, rinB); else WS_STORE((ks + 1) & 1, rinA);
-#ifdef CLAMD_DIAG
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                d_st += DIAG_T() - t0;
-#endif
-                if (ks + 2 < nk) {
-                    WS_GLOAD_W(ks + 2);                    // lands during the next period
-                    if ((ks + 1) & 1) WS_GLOAD_IN2((ks + 2) >> 1);   // both input buffers are free again
-                }
+            for (int ks = 0; ks < nk; ks += 4) {           // consumers are reading stage ks&1 in period ks
+                const int pr = ks >> 1;                    // pair of steps ks, ks+1 (set A/B); pr + 1: steps ks+2, ks+3 (set C/D)
+                WS_STORE(1, rinB);                         // step ks+1
+                WS_GLOAD_W(ks + 2, true);
+                WS_GLOAD_IN2(pr + 2, rinA, rinB, pr + 2 < npair);
+                WS_PERIOD_END();
+                WS_STORE(0, rinC);                         // step ks+2
+                WS_GLOAD_W(ks + 3, true);
+                WS_PERIOD_END();
+                WS_STORE(1, rinD);                         // step ks+3
+                WS_GLOAD_W(ks + 4, ks + 4 < nk);
+                WS_GLOAD_IN2(pr + 3, rinC, rinD, pr + 3 < npair);
+                WS_PERIOD_END();
+                if (ks + 4 < nk) WS_STORE(0, rinA);        // step ks+4
+                WS_GLOAD_W(ks + 5, ks + 5 < nk);
+                WS_PERIOD_END();
             }
-            t1 = DIAG_T();
-            __syncthreads();
-            d_store += t1 - t0; d_bar += DIAG_T() - t1;
+        } else {
+            WS_GLOAD_IN2(0, rinA, rinB, true);             // (an odd last step loads one chunk past its pair: in range or zero)
+            WS_GLOAD_W(0, true);
+            WS_STORE(0, rinA);
+            if (nk > 1) WS_GLOAD_W(1, true);
+            __syncthreads();                               // stage 0 is ready
+            DIAG_ADD(0, DIAG_T() - t0);                    // [0] producer prologue
+            t0 = DIAG_T();
+            for (int ks = 0; ks < nk; ++ks) {
+                if (ks + 1 < nk) {                         // consumers are reading stage ks&1
+                    if ((ks + 1) & 1) WS_STORE((ks + 1) & 1, rinB); else WS_STORE((ks + 1) & 1, rinA);
+                    if (ks + 2 < nk) {
+                        WS_GLOAD_W(ks + 2, true);          // lands during the next period
+                        if ((ks + 1) & 1) WS_GLOAD_IN2((ks + 2) >> 1, rinA, rinB, true);   // both input buffers are free again
+                    }
+                }
+                WS_PERIOD_END();
+            }
         }
         DIAG_ADD(1, d_store); DIAG_ADD(2, d_bar);          // [1] producer wait-loads+store+issue, [2] producer at barrier
-        DIAG_ADD(3, d_wait); DIAG_ADD(6, d_st);            // diag build: [3] += vmcnt wait, [6] += wait+store (cumulative)
+#undef WS_PERIOD_END
 #undef WS_GLOAD_IN2
 #undef WS_GLOAD_W
 #undef WS_STORE

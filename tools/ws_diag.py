@@ -7,12 +7,15 @@ from continual_learning_amd._lib import call, ptr
 lib = ctypes.CDLL(C._lib.LIB_PATH)
 dt = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+pws = len(sys.argv) > 3 and sys.argv[3] == 'pws'      # persistent kernel: consumer-side shares only
 dc = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[dt]
 T = C.ops.TORCH_DT[dc]
 B = 16
 C._lib.load().clamd_set_tuning(b'igemm_ws', mode)
+C._lib.load().clamd_set_tuning(b'igemm_pws', 2 if pws else 0)
+diag = lib.clamd_debug_pws_diag if pws else lib.clamd_debug_ws_diag
 out = (ctypes.c_ulonglong * 8)()
-for cin, cout, hw in [(64, 64, 256), (256, 256, 64), (1024, 512, 32)]:
+for cin, cout, hw in [(64, 64, 256), (128, 64, 256), (128, 128, 128), (256, 256, 64), (1024, 512, 32)]:
     x = torch.randn(B, hw, hw, cin, device='cuda').to(T)
     w = torch.randn(cout, cin, 3, 3, device='cuda') / (3 * cin ** 0.5)
     wf = torch.zeros(9 * cout * cin, dtype=T, device='cuda'); bias = torch.zeros(cout, device='cuda')
@@ -21,9 +24,12 @@ for cin, cout, hw in [(64, 64, 256), (256, 256, 64), (1024, 512, 32)]:
     s = C._lib.stream_ptr()
     for _ in range(2):
         call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, B, hw, hw, cin, cout, 1, 0, dc, s)
-    torch.cuda.synchronize(); lib.clamd_debug_ws_diag(out, 1)
+    torch.cuda.synchronize(); diag(out, 1)
     call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, B, hw, hw, cin, cout, 1, 0, dc, s)
-    torch.cuda.synchronize(); lib.clamd_debug_ws_diag(out, 1)
+    torch.cuda.synchronize(); diag(out, 1)
     v = list(out); nb = max(v[7], 1)
+    if pws:
+        print(f'{cin}->{cout}@{hw}: workgroups {nb}; consumer cycles per wave per workgroup: ' + ', '.join(f'{n} {v[i] / (nb * 4):.0f}' for i, n in enumerate(['wait first stage', 'MFMA loops', 'at K-step barriers', 'epilogues'])))
+        continue
     names = ['prod prologue', 'prod load-wait+store+issue', 'prod at barrier', 'cons wait stage0 + PROD vmcnt wait', 'cons MFMA loop', 'cons at barrier', 'epilogue + PROD wait+store']
     print(f'{cin}->{cout}@{hw}: blocks {nb}; per-wave cycles per block: ' + ', '.join(f'{n} {v[i] / (nb * 4):.0f}' for i, n in enumerate(names)))
