@@ -55,6 +55,16 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
     const int S = T_ * nk;                                       // flattened K-steps
 
     float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};              // consumers: running sum / sum of squares, columns 32*nt + r
+    // bf16 data-gradient launches may also accumulate the five per-channel sums of the consumer's fused ReLU/BatchNorm
+    // backward (IgemmParams::bn_y / bn_sums): registers across tiles, one flush per workgroup; the saved activation
+    // pieces are fetched while the last K-step of the tile is still multiplying.
+    constexpr bool BN = sizeof(T) == 2;
+    const bool do_bn = BN && p.bn_y != nullptr;
+    float bs[BN ? 5 : 1][8];
+#pragma unroll
+    for (int k = 0; k < (BN ? 5 : 1); ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bs[k][j] = 0.f;
 
     if (producer) {
         // ------------------------------------------------------------------ producers: global -> registers -> LDS
@@ -163,6 +173,9 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
         float* const wbuf = reinterpret_cast<float*>(smem + 2 * STAGE) + cw * 32 * 68;   // this wave's transposition block
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();
         const unsigned y_img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.y_ldc * (unsigned)sizeof(T);
+        const unsigned bn_img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.Np * (unsigned)sizeof(T);   // bn_y: dense pitch Np
+        unsigned bn_vo[BN ? MT : 1][4];
+        uint4 ypc[BN ? MT : 1][4];                 // saved-activation pieces (8 bf16 channels) of the tile being finished
         unsigned st_vo[MT][4];                     // tile-relative byte offsets of the 8-channel pieces this lane stores
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -170,6 +183,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             for (int ps = 0; ps < 4; ++ps) {
                 const int m = 32 * MT * cw + 32 * mt + ps * 8 + (lane >> 3), n = n0 + (lane & 7) * 8;
                 st_vo[mt][ps] = n < p.Np ? (unsigned)(((m / TW) * p.W + m % TW) * p.y_ldc + n) * (unsigned)sizeof(T) : BUF_OOB;
+                if constexpr (BN) bn_vo[mt][ps] = n < p.Np ? (unsigned)(((m / TW) * p.W + m % TW) * p.Np + n) * (unsigned)sizeof(T) : BUF_OOB;
             }
 
         unsigned long long d0 = PWD_T(), d1, d2, dk = 0, db = 0, de = 0;
@@ -188,6 +202,26 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             for (int ks = 0; ks < nk; ++ks) {
                 d0 = PWD_T();
                 const uint4* sm = smem + (ks & 1) * STAGE;         // nk is even: the stage parity restarts with every tile
+                if constexpr (BN) {
+                    if (do_bn && ks == nk - 1) {                   // wave-uniform
+                        const int tm_ = mg + ti * gm;
+                        const int x0_ = (tm_ % tiles_x) * TW, y0_ = ((tm_ / tiles_x) % tiles_y) * TH, b_ = tm_ / (tiles_x * tiles_y);
+                        const __amdgpu_buffer_rsrc_t brs = make_rsrc((const char*)p.bn_y + (size_t)b_ * bn_img, bn_img);
+                        const unsigned bso = (unsigned)((y0_ * p.W + x0_) * p.Np) * (unsigned)sizeof(T);
+                        const bool full_ = y0_ + TH <= p.H && x0_ + TW <= p.W;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int ps = 0; ps < 4; ++ps) {
+                                unsigned vo = bn_vo[mt][ps];
+                                if (!full_) {
+                                    const int m = 32 * MT * cw + 32 * mt + ps * 8 + (lane >> 3);
+                                    if (!(y0_ + m / TW < p.H && x0_ + m % TW < p.W)) vo = BUF_OOB;
+                                }
+                                ypc[mt][ps] = buf_ld16(brs, vo, bso);
+                            }
+                    }
+                }
                 if constexpr (SPLIT) {
                     uint4 f[2][2 * MT + 4];      // [buffer][a_hi[mt], a_lo[mt] ..., bh0, bl0, bh1, bl1]
 #define PWS_FRAG_S(t_, d_)                                                                                        \
@@ -305,6 +339,24 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                         if (!(y0 + m / TW < p.H && x0 + m % TW < p.W)) vo = BUF_OOB;
                     }
                     buf_st8<T>(yrs, vo, y_so, v);
+                    if constexpr (BN) {
+                        if (do_bn) {
+                            float yv[8];
+                            const uint4 u = ypc[mt][ps];
+                            yv[0] = __uint_as_float(u.x << 16); yv[1] = __uint_as_float(u.x & 0xffff0000u);
+                            yv[2] = __uint_as_float(u.y << 16); yv[3] = __uint_as_float(u.y & 0xffff0000u);
+                            yv[4] = __uint_as_float(u.z << 16); yv[5] = __uint_as_float(u.z & 0xffff0000u);
+                            yv[6] = __uint_as_float(u.w << 16); yv[7] = __uint_as_float(u.w & 0xffff0000u);
+                            const bool ok = vo != BUF_OOB;         // pixel inside the image and channel group inside Np
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float g = ok ? v[j] : 0.f;
+                                const float pos = yv[j] > 0.f ? 1.f : 0.f;
+                                bs[0][j] += g; bs[1][j] = fmaf(g, yv[j], bs[1][j]); bs[2][j] = fmaf(g, pos, bs[2][j]);
+                                bs[3][j] += pos; bs[4][j] += yv[j];
+                            }
+                        }
+                    }
                 }
             }
             de += PWD_T() - d2;
@@ -338,6 +390,27 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             if (n0 + c < p.Np) atomicAdd(p.stats + ((size_t)(blockIdx.x % STAT_REPLICAS) * 2 + k) * p.Np + n0 + c, t);
         }
     }
+    if constexpr (BN) {
+        if (do_bn) {
+            float* ebuf = reinterpret_cast<float*>(smem + 2 * STAGE);      // the wave-private transposition blocks are free now
+            if (!producer) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float t = bs[k][j];
+                        t += __shfl_xor(t, 8); t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+                        if (lane < 8) ebuf[cw * 32 * 68 + k * 64 + lane * 8 + j] = t;
+                    }
+            }
+            __syncthreads();
+            for (int i = tid; i < 5 * 64; i += 512) {
+                const int k = i >> 6, c = i & 63;
+                const float t = ebuf[0 * 32 * 68 + i] + ebuf[1 * 32 * 68 + i] + ebuf[2 * 32 * 68 + i] + ebuf[3 * 32 * 68 + i];
+                if (n0 + c < p.Np) atomicAdd(p.bn_sums + ((size_t)(blockIdx.x % STAT_REPLICAS) * 5 + k) * p.Np + n0 + c, t);
+            }
+        }
+    }
 }
 
 static int g_num_cus = 0;
@@ -355,7 +428,7 @@ namespace clamd {
 
 template <typename T>
 static int launch_pws_t(const IgemmParams& p, hipStream_t s) {
-    if (p.bn_y) return -1;                                   // fused BN-backward sums: igemm_ws / igemm only
+    if (p.bn_y && sizeof(T) != 2) return -1;                 // fused BN-backward sums here: bf16 only (register budget)
     if (p.Kp % (2 * DT<T>::KC)) return -1;                   // K-steps are staged in pairs
     if (!g_num_cus) {
         int dev = 0, n = 0;

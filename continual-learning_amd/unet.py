@@ -17,7 +17,11 @@ from .ops import PackTable, cpad
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
-FUSE_BN_SUMS = False     # see _Engine.__init__: fused BN-backward sums in the dgrad epilogue measured slower in situ
+# Fused BN-backward sums in the epilogue of the data-gradient kernel that produces the BN-output gradient:
+# 'auto' = where that kernel is the persistent bf16 kernel (sums stay in registers across tiles, one flush per workgroup,
+# the saved activation is prefetched under the last K-step); True = everywhere the kernels support it (every dgrad
+# launch of the other kernels got 30-80 us slower than the 33-us reduce pass it replaced); False = never.
+FUSE_BN_SUMS = 'auto'
 
 # bench.py sets this to a list to get per-launch HIP-event timings of the MFMA kernels:
 # entries (tag, algorithmic_flops, start_event, end_event), recorded on the stream the kernel is launched on.
@@ -228,10 +232,7 @@ class _Engine:
             b.g_in = act(k, cpad(cout))                             # grad w.r.t. ua
             a.g_src = (b.g_in, b.g_in.shape[-1], None)               # where conv a's BN-output gradient comes from
             b.g_src = (self.gcat[k], self.gcat[k].shape[-1], self.gpool[k])
-            # The data-gradient kernels CAN accumulate the consumer's BN-backward sums in their epilogue (bn_y/bn_sums
-            # arguments, covered by tests), but in situ that made every dgrad launch 30-80 us slower (the epilogue is
-            # instruction-bound) while the separate HBM-bound reduce pass it replaces costs ~33 us: disabled (FUSE_BN_SUMS).
-            b.consumer, a.fused_reduce = (a, True) if FUSE_BN_SUMS else (None, False)
+            b.consumer, a.fused_reduce = (a, True) if self._fuse_sums(b) else (None, False)
             a.consumer, b.fused_reduce = None, False                # a's dgrad feeds a pooled / concat gradient: separate reduce
             self.stages.append(dict(kind='enc', convs=(a, b)))
             prev = (self.pool[k], self.pool[k].shape[-1], [(cout, cpad(cout))])
@@ -255,8 +256,8 @@ class _Engine:
             g_ub = act(level, cpad(mid))
             a.g_src = (b.g_in, b.g_in.shape[-1], None)
             b.g_src = (g_ub, g_ub.shape[-1], None)
-            b.consumer, a.fused_reduce = (a, True) if FUSE_BN_SUMS else (None, False)
-            a.consumer, b.fused_reduce = None, FUSE_BN_SUMS         # b's gradient comes from the tail's data-gradient kernel
+            b.consumer, a.fused_reduce = (a, True) if self._fuse_sums(b) else (None, False)
+            a.consumer, b.fused_reduce = None, FUSE_BN_SUMS is True  # b's gradient comes from the tail's data-gradient kernel
             kind, ti, tcin, tcout = st['tail']
             tail = _Conv()
             tail.kind = kind
@@ -264,7 +265,7 @@ class _Engine:
             tail.keys = (f'{pre}.{ti}.weight', f'{pre}.{ti}.bias')
             tail.cin, tail.cin_p, tail.cout = tcin, cpad(tcin), tcout
             tail.x, tail.g_x, tail.level = ub, g_ub, level
-            tail.consumer = b if FUSE_BN_SUMS else None
+            tail.consumer = b if FUSE_BN_SUMS is True else None
             if kind == 'convT':
                 tail.cout_p = cpad(tcout)
                 tail.wf = torch.zeros(4 * tail.cout_p * tail.cin_p, dtype=T, device=dev)
@@ -434,6 +435,13 @@ class _Engine:
                 sync.stage_done(self, st)
         gf = self.gflat
         return [gf[o:o + k].view(self.gshape[n]) for n, (o, k) in ((n, self.goffset[n]) for n in self.param_names)]
+
+    def _fuse_sums(self, b):
+        """Does the data-gradient launch of conv `b` (3x3, K = b.cout_p gradient channels) also reduce the BN-backward sums
+        of the unit in front of it?"""
+        if FUSE_BN_SUMS == 'auto':     # persistent bf16 kernel: <= 256 input channels, K-steps in pairs (64 channels)
+            return self.dcode == _lib.BF16 and b.cout_p <= 256 and b.cout_p % 64 == 0
+        return bool(FUSE_BN_SUMS)
 
     def _conv_bwd(self, u, s):
         B, dc = self.B, self.dcode
