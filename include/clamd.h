@@ -138,7 +138,11 @@ int clamd_voc_prepare(const unsigned char* img_rgb, const unsigned char* mask_rg
 /* voc.to_rgb (datasets/voc.py:74-89): labels int64 [N,H,W] -> palette colours [N,3,H,W] (0..255 as float). */
 int clamd_label_to_rgb(const long long* labels, float* rgb, long long n_img, long long hw, void* stream);
 int clamd_fill_f32(float* p, long long n, double v, void* stream);
-/* performance experiments only (never changes results): e.g. ("igemm_variant", 0|1|2). */
+/* Kernel-structure selection for A/B measurements and tests (activations stay bit-identical; wgrad / statistics differ
+ * only in summation order).  Keys: "igemm_pws" 0|1|2 (persistent conv kernel: never | <= 256 input channels | always),
+ * "igemm_ws" 0|1|2|3|4 (producer/consumer kernel: never | 256-px | heuristic | 512-px | 128-px tiles),
+ * "igemm_variant" 0|1|2 (baseline kernel prefetch variants), "wgrad_ws" 0|1, "wgrad_xcd" 0|1, "wgrad_blocks" 1..512,
+ * "wgrad_tw16" 0|1.  Process-wide, not thread-safe: set before launching. */
 int clamd_set_tuning(const char* key, int value);
 
 #ifdef __cplusplus
