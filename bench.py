@@ -101,7 +101,7 @@ def run(args, dtype, rank, world, device, timing=True):
         k[0] += e0.elapsed_time(e1) * 1e-3
         k[1] += flops
         k[2] += 1
-    return dt, float(loss), kern
+    return dt, float(loss.detach()), kern
 
 
 def pmc_traffic(dtype):
@@ -143,13 +143,14 @@ def main():
     flop_img = FLOP_PER_IMAGE_256 * scale
 
     out = {
-        'metric': 'images/sec UNET 256x256 bs16 train step', 'value': round(value, 2), 'unit': 'images/sec',
+        'metric': 'images/sec UNET 256x256 bs16 train step' if (args.size, args.batch) == (256, 16) else
+                  f'images/sec UNET {args.size}x{args.size} bs{args.batch} train step', 'value': round(value, 2), 'unit': 'images/sec',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_NAME[args.dtype],
         'data': 'synthetic (splitmix64 images U(-1,1), blocky 21-class labels), random-init weights',
         'config': {'workload': f'UNet({args.num_classes},3,{args.conv_dim}) {args.size}x{args.size} bs{args.batch}/GPU '
                                f'{args.dtype} train step (fwd + CE + bwd + Adam), BASELINE.json configs['
-                               f'{2 if args.dtype == "bf16" else 1}]',
+                               f'{4 if (args.size, args.batch) == (512, 32) else 2 if args.dtype == "bf16" else 1}]',
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'final_loss': round(loss, 5)},
         'step_tflops': round(value * flop_img / 1e12, 2),
         'step_frac_of_mfma_peak': round(value * flop_img / 1e12 / (PEAK[args.dtype] * world), 4),

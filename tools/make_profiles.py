@@ -26,6 +26,10 @@ for dt in DT:
                           f'{G}/{src}_pmc_{dt}_WRITE_SIZE', dt, str(STEPS_PMC)], capture_output=True, text=True, check=True).stdout
     open(f'{P}/{dst}_traffic_{dt}.json', 'w').write(out)
 
+c5 = None
+if os.path.exists(f'{G}/{src}_bench_config5_bf16.json'):
+    shutil.copy(f'{G}/{src}_bench_config5_bf16.json', f'{P}/{dst}_bench_config5_bf16.json')
+    c5 = last_json(f'{P}/{dst}_bench_config5_bf16.json')
 b = last_json(f'{P}/{dst}_bench_default.json')
 L = []
 L.append(f'# profiles/ — round evidence `{dst}` (MI355X, ROCm 7.2, one GPU)\n')
@@ -46,6 +50,10 @@ for a in b.get('also', []):
 c = b.get('cpu_baseline')
 if c:
     L.append(f"\nCPU baseline (stock torch.nn counterpart, same box): {c['value']} {c['unit']} on {c['cores']} cores ({c['sample']}).\n")
+if c5:
+    L.append(f"BASELINE.json configs[4] on ONE GPU (`{dst}_bench_config5_bf16.json`: 512x512, bs32, bf16): {c5['value']} img/s, "
+             f"{c5['ms_per_step']} ms/step, conv3x3 fwd+dgrad {c5['roofline']['achieved']} TF/s = {c5['roofline']['frac']}, "
+             f"wgrad {c5['roofline_wgrad']['achieved']} TF/s = {c5['roofline_wgrad']['frac']} of the bf16 MFMA peak.\n")
 L.append('## Time per step by kernel (rocprofv3, 10 steps per profile)\n')
 for dt in DT:
     rows = list(csv.DictReader(open(f'{P}/{dst}_{dt}_kernel_stats.csv')))

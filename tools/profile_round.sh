@@ -6,6 +6,8 @@ tag=${1:-rXX}
 root=$PWD
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 timeout -k 10 400 python bench.py --steps 10 --warmup 3 --also bf16x3,bf16 > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err || exit 1
+# BASELINE.json configs[4] on one GPU (512x512, bs32 per GPU, bf16)
+timeout -k 10 400 python bench.py --steps 5 --warmup 2 --dtype bf16 --also "" --no-cpu-baseline --size 512 --batch 32 > gpurun_out/${tag}_bench_config5_bf16.json 2> gpurun_out/${tag}_bench_config5_bf16.err || exit 1
 for dt in fp32 bf16x3 bf16; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_$dt -o $tag -- python3 bench.py --steps 6 --warmup 2 --dtype $dt --no-cpu-baseline --also "" > gpurun_out/${tag}_bench_${dt}_under_rocprof.json 2> gpurun_out/${tag}_prof_$dt.err || exit 2
   for c in FETCH_SIZE WRITE_SIZE; do
