@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libclamd.so')
-SOURCES = ['igemm.hip', 'igemm_ws.hip', 'igemm_pws.hip', 'wgrad.hip', 'elementwise.hip', 'misc.hip']
+SOURCES = ['igemm.hip', 'igemm_ws.hip', 'igemm_pws.hip', 'wgrad.hip', 'wgrad_dma.hip', 'elementwise.hip', 'misc.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-I' + os.path.join(HERE, '..', 'include')]
 
@@ -31,6 +31,8 @@ def _digest():
 
 def build(force=False, verbose=True, diag=False):
     global FLAGS
+    if os.environ.get('CLAMD_EXTRA_FLAGS'):     # experiments (ablation builds): never for measurements that are reported
+        FLAGS = FLAGS + os.environ['CLAMD_EXTRA_FLAGS'].split()
     if diag:
         FLAGS = FLAGS + ['-DCLAMD_DIAG']      # diagnostic build: in-kernel cycle stamps (never for measurements)
     stamp = os.path.join(HERE, 'csrc', '.build_stamp')

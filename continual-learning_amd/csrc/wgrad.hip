@@ -18,10 +18,10 @@
 // ([Cout][Cin][3][3] / [Cin][Cout][2][2]) -- deterministic, no float atomics.
 #include "common.hip.h"
 #include "clamd_internal.h"
+#include "wgrad_common.hip.h"
 
 namespace clamd {
 
-enum { WG_CONV3 = 0, WG_PW = 1, WG_UP2 = 2 };
 
 #ifdef CLAMD_DIAG
 // diagnostic build only (python build.py --diag): per-role cycle shares of the pixel-tile loop, summed over workgroups
@@ -32,39 +32,6 @@ __device__ unsigned long long g_wg_diag[8];
 #define WGD_T() 0ull
 #define WGD_ADD(i_, v_) do { } while (0)
 #endif
-
-struct WgradParams {
-    const void* a; int a_ldc;
-    const void* b; int b_ldc;
-    float* partial;        // [nsplit][NT][Rp][Cp]
-    int B, H, W;           // pixel grid of A
-    int Rp, Cp;            // physical channels of A / B
-    int nsplit, tiles_per_split;
-    int xcd;               // XCD-aware block order (tuning knob "wgrad_xcd")
-};
-
-template <typename T, int MODE, int TW> struct WGeo {
-    static constexpr bool SPLIT = __is_same(T, split_t);   // fp32 storage, bf16 hi/lo LDS images, 3 MFMAs per product
-    static constexpr int TH = (sizeof(T) == 2 ? 128 : 64) / (MODE == 2 ? 2 : 1) / TW;   // pixel tile rows (UP2: B tile is 4x)
-    static constexpr int NT = MODE == WG_CONV3 ? 9 : (MODE == WG_UP2 ? 4 : 1);
-    static constexpr int BW = MODE == WG_CONV3 ? TW + 2 : (MODE == WG_UP2 ? 2 * TW : TW);
-    static constexpr int BH = MODE == WG_CONV3 ? TH + 2 : (MODE == WG_UP2 ? 2 * TH : TH);
-    static constexpr int STRIDE = (sizeof(T) == 2 || SPLIT) ? 192 : 256;        // bytes per pixel row (64 channels + pad)
-    static constexpr int APIX = TH * TW, BPIX = BH * BW;
-    static constexpr int GPP = 64 * sizeof(T) / 16;                             // 16-B groups per pixel (8 or 16)
-    static constexpr int NJA = (APIX * GPP + 255) / 256, NJB = (BPIX * GPP + 255) / 256;
-    static constexpr int BYTES = (APIX + BPIX) * STRIDE * (SPLIT ? 2 : 1);
-};
-
-// Staging slot of thread `i` in a tile image of `total` 16-byte pieces: the ragged last pass wraps around and re-stages the
-// first pieces (same data to the same LDS address), so every load has an unconditional use -- a store guarded by
-// "slot < total" lets the compiler sink the load next to it, behind a full s_waitcnt vmcnt(0).
-__device__ inline int wrap_idx(int i, int total) { return i >= total ? i - total : i; }
-
-__device__ inline uint2 ds_tr16(const char* lds_addr) {
-    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_addr));
-    return __builtin_bit_cast(uint2, v);
-}
 
 // WS = false: 256 threads, every wave stages and multiplies, two workgroups per CU cover each other's stalls.
 // WS = true : 512 threads, waves 4-7 (producers) stream pixel tile i+1 from global memory into LDS stage (i+1)&1 while
@@ -190,6 +157,9 @@ __global__ void __launch_bounds__(WS ? 512 : 256, 2) wgrad_kernel(const WgradPar
 #pragma unroll
         for (int j = 0; j < NJA; ++j) {
             const int i = wrap_idx(tid + 256 * j, G::APIX * GPP), pix = i / GPP, g = i % GPP;
+#ifdef WG_ABLATE_STORE
+            if (j > 0) { asm volatile("" :: "v"(ra[j].x), "v"(ra[j].y), "v"(ra[j].z), "v"(ra[j].w)); continue; }
+#endif
             if constexpr (!SPLIT) {
                 *reinterpret_cast<uint4*>(sa + pix * STRIDE + g * 16) = ra[j];
             } else {
@@ -202,6 +172,9 @@ __global__ void __launch_bounds__(WS ? 512 : 256, 2) wgrad_kernel(const WgradPar
 #pragma unroll
         for (int j = 0; j < NJB; ++j) {
             const int i = wrap_idx(tid + 256 * j, G::BPIX * GPP), pix = i / GPP, g = i % GPP;
+#ifdef WG_ABLATE_STORE
+            if (j > 0) { asm volatile("" :: "v"(rb[j].x), "v"(rb[j].y), "v"(rb[j].z), "v"(rb[j].w)); continue; }
+#endif
             if constexpr (!SPLIT) {
                 *reinterpret_cast<uint4*>(sb + pix * STRIDE + g * 16) = rb[j];
             } else {
@@ -509,6 +482,7 @@ int g_wgrad_tw16 = 0;               // tuning knob: 1 = 16-wide tiles everywhere
 static inline int wgrad_tw(int W, int mode, bool split) { return (W >= 32 && !(split && mode == WG_CONV3) && !g_wgrad_tw16) ? 32 : 16; }
 
 int g_wgrad_target_blocks = 512;   // tuning knob (clamd_set_tuning "wgrad_blocks"): split-K until about this many workgroups
+int g_wgrad_dma = 1;               // tuning knob "wgrad_dma": bf16 3x3 kernel with LDS-DMA staging (wgrad_dma.hip)
 int g_wgrad_xcd = 1;
 int g_wgrad_ws = 1;                // tuning knob "wgrad_ws": producer/consumer kernel (one 512-thread workgroup per CU) for the 3x3 convs
 
@@ -597,7 +571,9 @@ int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, fl
     const int grid = rt * ct * nsplit;
     hipStream_t s = (hipStream_t)stream;
     int e;
-    if (dtype == CLAMD_BF16) e = launch_wg_mode<bf16_t>(mode, ws, p, s, grid);
+    // LDS-DMA staging: +3..11 % except on the single-tile 64x64-channel layers (HBM-heavy, 6 % slower there); 2 = always
+    if (dtype == CLAMD_BF16 && ws && (g_wgrad_dma == 2 || (g_wgrad_dma == 1 && rt * ct > 1))) e = launch_wgrad_dma(p, s, grid, TW);
+    else if (dtype == CLAMD_BF16) e = launch_wg_mode<bf16_t>(mode, ws, p, s, grid);
     else if (dtype == CLAMD_F32) e = launch_wg_mode<float>(mode, ws, p, s, grid);
     else if (dtype == CLAMD_SPLIT) e = launch_wg_mode<split_t>(mode, ws, p, s, grid);
     else return clamd_fail("wgrad: bad dtype");

@@ -300,8 +300,9 @@ def test_wgrad_kernel_structures_agree(C, name, dcode, shape):
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     rgw = O.conv3x3_bwd(x, np.zeros((cout, cin, 3, 3), np.float32), gz)[1]
     try:
-        for v in (0, 1):
-            lib.load().clamd_set_tuning(b'wgrad_ws', v)
+        for v in (0, 1, 2):          # 2 = producer/consumer kernel with LDS-DMA staging forced (bf16 only; same as 1 otherwise)
+            lib.load().clamd_set_tuning(b'wgrad_ws', min(v, 1))
+            lib.load().clamd_set_tuning(b'wgrad_dma', 2 if v == 2 else 0)
             gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
             lib.call('clamd_wgrad', 0, ptr(gzt), cout_p, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, cin_p, cout, cin,
                      cout, cout_p, cin, cin_p, dcode, s)
@@ -309,6 +310,7 @@ def test_wgrad_kernel_structures_agree(C, name, dcode, shape):
             assert rel_l2(gw.cpu().numpy(), rgw) < (6e-5 if dcode == 2 else 2e-5), v
     finally:
         lib.load().clamd_set_tuning(b'wgrad_ws', 1)
+        lib.load().clamd_set_tuning(b'wgrad_dma', 1)
 
 
 @pytest.mark.parametrize('name,dcode', DT)
