@@ -40,7 +40,7 @@ def parse():
     ap.add_argument('--num-classes', type=int, default=21)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true', help='skip the per-launch HIP events')
-    ap.add_argument('--also', default='bf16x3,bf16',
+    ap.add_argument('--also', default=None,
                     help="comma list of further dtypes measured after the main run and reported under 'also' ('' = none)")
     return ap.parse_args()
 
@@ -175,7 +175,9 @@ def main():
                                      'unit': 'TFLOP/s', 'frac': round(ach / PEAK[args.dtype], 4), 'launches': n,
                                      'avg_launch_ms': round(sec / n * 1e3, 4), 'ms_per_step': round(sec / 2 * 1e3, 3),
                                      'note': 'wgrad kernel + its split-K reduce kernel'}
-    for other in [d for d in args.also.split(',') if d and d != args.dtype]:
+    # further dtypes: by default on the single-GPU run only (the N-GPU scaling runs measure the headline dtype and nothing else)
+    also = args.also if args.also is not None else ('bf16x3,bf16' if world == 1 else '')
+    for other in [d for d in also.split(',') if d and d != args.dtype]:
         dt2, loss2, k2 = run(args, other, rank, world, device, timing=not args.no_kernel_timing)
         v2 = images / dt2
         o = {'dtype': DTYPE_NAME[other], 'value': round(v2, 2), 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
