@@ -313,6 +313,54 @@ def test_wgrad_kernel_structures_agree(C, name, dcode, shape):
         lib.load().clamd_set_tuning(b'wgrad_dma', 1)
 
 
+def _random_conv_shapes(n, seed):
+    """Seeded random problem sizes that hit ragged tiles, several channel slabs, K-step pairs / fours / odd counts and
+    the split-K tail of every 3x3 kernel."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        B = int(rng.integers(1, 4))
+        cin = int(rng.choice([3, 20, 33, 64, 96, 128, 200, 256, 300]))
+        cout = int(rng.choice([5, 32, 64, 70, 128, 130]))
+        H, W = int(rng.integers(3, 41)), int(rng.integers(3, 70))
+        out.append((B, cin, cout, H, W))
+    return out
+
+
+@pytest.mark.parametrize('name,dcode', DT)
+@pytest.mark.parametrize('shape', _random_conv_shapes(10, 2024))
+def test_conv3x3_random_shapes(C, name, dcode, shape):
+    """Forward (+ReLU, BN statistics), data gradient and weight gradient of one 3x3 convolution on a random ragged shape."""
+    B, cin, cout, H, W = shape
+    rng = np.random.default_rng(hash(shape) % (2 ** 31))
+    segs = [(cin, C.ops.cpad(cin))]
+    x, w, b, xt, wf, wd, bp, cin_p, cout_p = _conv_case(C, rng, B, segs, cout, H, W, dcode)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    T = C.ops.TORCH_DT[dcode]
+    R = lib.load().clamd_stat_replicas()
+    y = torch.full((B, H, W, cout_p), 7.0, dtype=T, device='cuda')
+    stats = torch.zeros(R, 2, cout_p, device='cuda')
+    lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, B, H, W, cin_p, cout_p, 1, 0, dcode, s)
+    gz = rb(rnd(rng, B, cout, H, W), dcode)
+    gzt = C.ops.to_nhwc(dev(gz), dcode)
+    gx = torch.zeros(B, H, W, cin_p, dtype=T, device='cuda')
+    lib.call('clamd_conv3x3', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, None, None, B, H, W, cout_p, cin_p, 0, 0, dcode, s)
+    wsb = lib.load().clamd_wgrad_workspace_bytes(0, B, H, W, cout_p, cin_p, dcode)
+    ws = torch.empty(wsb // 4 + 4, device='cuda')
+    gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
+    lib.call('clamd_wgrad', 0, ptr(gzt), cout_p, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, cin_p, cout, cin,
+             cout, cout_p, cin, cin_p, dcode, s)
+    sync()
+    ref = O.relu_fwd(O.conv3x3_fwd(x, w, b))
+    assert rel_l2(C.ops.from_nhwc(y, cout, dcode).cpu().numpy(), ref) < TOL[dcode]
+    st = stats.sum(0).cpu().numpy()
+    np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=2e-3 if dcode == 1 else 1e-4, atol=2e-2 if dcode == 1 else 1e-3)
+    assert float(y[..., cout:].float().abs().max()) == 0.0 if cout < cout_p else True
+    rgx, rgw, _ = O.conv3x3_bwd(x, w, gz)
+    assert rel_l2(gx.float().cpu().numpy().transpose(0, 3, 1, 2)[:, :cin], rgx) < TOL[dcode]
+    assert rel_l2(gw.cpu().numpy(), rgw) < (6e-5 if dcode == 2 else 2e-5)
+
+
 @pytest.mark.parametrize('name,dcode', DT)
 @pytest.mark.parametrize('shape', [(2, 6, 3, 4, 5), (1, 128, 64, 16, 16), (2, 70, 40, 8, 48)])
 def test_convT2x2_fwd_dgrad_wgrad(C, name, dcode, shape):
