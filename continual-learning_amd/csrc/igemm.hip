@@ -51,13 +51,16 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
     const unsigned img_elems = (MODE == MODE_UP2 ? 4u : 1u) * (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc;
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x + (size_t)b * img_elems * ESZ, img_elems * ESZ);
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.w, (unsigned)((MODE == MODE_CONV3 ? 9u : 1u) * p.Np * p.Kp * ESZ));
+    // staging slot j of this thread; the ragged last pass wraps around and re-stages the first pixels (same data, same
+    // LDS slot), so no store is conditional (a store guarded by "slot < NPIX" lets hipcc sink the load next to it)
+    auto slot_pix = [&](int j) { const int pix = (tid >> 2) + 64 * j; return pix >= NPIX ? pix - NPIX : pix; };
     unsigned in_vo[NJ];   // byte offset of this thread's 16-B group at channel 0 inside the image, or BUF_OOB (-> zeros)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int pix = (tid >> 2) + 64 * j;
+        const int pix = slot_pix(j);
         const int hy = pix / HW_, hx = pix - hy * HW_;
         unsigned off = BUF_OOB;
-        if (pix < NPIX) {
+        {
             if constexpr (MODE == MODE_CONV3) {
                 const int yy = y0 + hy - 1, xx = x0 + hx - 1;
                 if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) off = ((yy * p.W + xx) * p.x_ldc + g4 * VEC) * ESZ;
@@ -99,23 +102,24 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
                     const int q_ = k0_ / p.aux, c0_ = k0_ - q_ * p.aux;                                           \
                     koff_ = ((q_ >> 1) * 2 * p.W + (q_ & 1)) * p.x_ldc + c0_;                                     \
                 }                                                                                                 \
+                /* past-the-end K-steps load with every lane out of range (zeros, no traffic): a "load or zero" select */ \
+                /* on a runtime condition makes hipcc branch around each load and drain vmcnt per element            */ \
                 _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                    \
-                    rin[t][j] = kok_ ? buf_ld16(xrs, in_vo[j], (unsigned)(koff_ * ESZ)) : zero4_;                 \
-                rw[t] = kok_ ? buf_ld16(wrs, w_vo, (unsigned)(k0_ * ESZ)) : zero4_;                               \
+                    rin[t][j] = buf_ld16(xrs, kok_ ? in_vo[j] : BUF_OOB, (unsigned)(koff_ * ESZ));                \
+                rw[t] = buf_ld16(wrs, kok_ ? w_vo : BUF_OOB, (unsigned)(k0_ * ESZ));                              \
             }                                                                                                     \
         }                                                                                                         \
     } while (0)
 
-// Registers -> LDS.  Only the last j can fall outside the tile (pix >= NPIX): every other store is unconditional.
+// Registers -> LDS (unconditional: see slot_pix).
 #define IGEMM_LDS_STORE()                                                                                         \
     do {                                                                                                          \
         _Pragma("unroll") for (int t = 0; t < NIN; ++t)                                                           \
             _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                      \
-                const int pix_ = (tid >> 2) + 64 * j;                                                             \
-                const bool in_ = 64 * (j + 1) <= NPIX || pix_ < NPIX;                                             \
+                const int pix_ = slot_pix(j);                                                                     \
                 if constexpr (!SPLIT) {                                                                           \
-                    if (in_) smem[t * 4 * NPIXP + g4 * NPIXP + pix_] = rin[t][j];                                 \
-                } else if (in_) {                                                                                 \
+                    smem[t * 4 * NPIXP + g4 * NPIXP + pix_] = rin[t][j];                                          \
+                } else {                                                                                          \
                     /* groups 0,1 = hi channels 0-7 / 8-15, groups 2,3 = lo; this thread owns 4 channels */       \
                     uint2 hi_, lo_;                                                                               \
                     split4(rin[t][j], hi_, lo_);                                                                  \
@@ -417,11 +421,9 @@ extern int g_wgrad_xcd;
 extern int g_wgrad_dma;
 static int g_igemm_variant = 0;
 static int g_igemm_pws = 1;        // persistent producer/consumer kernel: 1 = short-K layers (<= 256 input channels), 2 = every layer, 0 = never
-static int g_igemm_ws = 2;         // 0: never, 1: always (128x2-pixel tiles), 3: always (128x4), 2: where it measured faster
-                                   // (interleaved A/B, tools/conv_ab.py): long K loops (>= 256 input channels), where the
-                                   // two-stage pipeline fills and the 512-pixel tile halves the filter traffic per MFMA
-                                   // (+10..25 % bf16/bf16x3, +2..8 % fp32); short K loops stay on the two-workgroups-per-CU
-                                   // kernel below, whose second workgroup hides prologue and epilogue.
+static int g_igemm_ws = 2;         // producer/consumer kernel: 0 never, 1 / 3 / 4 always with 256- / 512- / 128-pixel tiles, 2 = heuristic:
+                                   // layers the persistent kernel does not take (> 256 input channels), with the largest tile
+                                   // that still gives every CU a workgroup (interleaved A/B: tools/conv_ab.py)
 
 template <typename T, int MODE, int EPI>
 static int launch_tw(const IgemmParams& p, hipStream_t s) {
@@ -433,8 +435,11 @@ static int launch_tw(const IgemmParams& p, hipStream_t s) {
     const int var = (MODE == MODE_CONV3 && EPI == EPI_NHWC && !__is_same(T, split_t)) ? g_igemm_variant : 0;
 #define IGEMM_LAUNCH(TW_, V_) hipLaunchKernelGGL((igemm_kernel<T, MODE, EPI, TW_, V_>), dim3((unsigned)nblk), dim3(256), 0, s, p)
     if constexpr (MODE == MODE_CONV3 && EPI == EPI_NHWC && !__is_same(T, split_t)) {
-        if (wide) { if (var == 1) IGEMM_LAUNCH(32, 1); else if (var == 2) IGEMM_LAUNCH(32, 2); else if (var == 3) IGEMM_LAUNCH(32, 3);
-                    else if (var == 4) IGEMM_LAUNCH(32, 4); else if (var == 5) IGEMM_LAUNCH(32, 5); else if (var == 6) IGEMM_LAUNCH(32, 6);
+        if (wide) { if (var == 1) IGEMM_LAUNCH(32, 1); else if (var == 2) IGEMM_LAUNCH(32, 2);
+#ifdef CLAMD_DIAG   // timing ablations (results are wrong on purpose): diagnostic build only
+                    else if (var == 3) IGEMM_LAUNCH(32, 3); else if (var == 4) IGEMM_LAUNCH(32, 4);
+                    else if (var == 5) IGEMM_LAUNCH(32, 5); else if (var == 6) IGEMM_LAUNCH(32, 6);
+#endif
                     else IGEMM_LAUNCH(32, 0); }
         else { if (var == 1) IGEMM_LAUNCH(16, 1); else if (var == 2) IGEMM_LAUNCH(16, 2); else IGEMM_LAUNCH(16, 0); }
     } else {
@@ -472,7 +477,12 @@ using namespace clamd;
 extern "C" {
 
 int clamd_set_tuning(const char* key, int value) {
-    if (!strcmp(key, "igemm_variant")) { g_igemm_variant = value; return 0; }
+    if (!strcmp(key, "igemm_variant")) {
+#ifndef CLAMD_DIAG
+        if (value < 0 || value > 2) return clamd_fail("igemm_variant: 0..2 (3..6 are timing ablations of the diagnostic build)");
+#endif
+        g_igemm_variant = value; return 0;
+    }
     if (!strcmp(key, "igemm_ws")) { g_igemm_ws = value; return 0; }
     if (!strcmp(key, "igemm_pws")) { g_igemm_pws = value; return 0; }
     if (!strcmp(key, "wgrad_tw16")) { g_wgrad_tw16 = value; return 0; }
