@@ -42,6 +42,9 @@ SIGNATURES = {
     'clamd_nhwc_to_nchw': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'clamd_nchw_im2col3': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_pack': (_I, [_P, _I, _I, _I, _P]),
+    'clamd_sizeof_wino_pack_job': (_I, []),
+    'clamd_wino_pack': (_I, [_P, _I, _I, _P]),
+    'clamd_conv3x3_winograd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_ce_workspace_bytes': (_SZ, []),
     'clamd_ce_fwd_bwd': (_I, [_P, _P, _P, _I, _I, _D, _D, _P, _P, _P, _SZ, _I, _I, _I, _I, _LL, _D, _P]),
     'clamd_adam_step': (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),

@@ -92,6 +92,45 @@ class PackTable:
         call('clamd_pack', ptr(self.dev_table), len(self.jobs), self.nblocks, self.dcode, stream or _lib.stream_ptr())
 
 
+_WINO_DT = np.dtype({'names': ['w', 'dst', 'Np', 'Kp', 'N', 'K', 'n_seg0', 'n_seg0p', 'k_seg0', 'k_seg0p', 'dgrad', 'block0'],
+                     'formats': ['u8', 'u8', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4'],
+                     'offsets': [0, 8, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52], 'itemsize': 56})
+
+
+class WinoPackTable:
+    """Job table for clamd_wino_pack: Winograd F(2x2,3x3) filter transforms of every 3x3 conv in one launch (fp32 path)."""
+
+    def __init__(self):
+        self.jobs = []
+
+    def conv3x3(self, w, wf, wd, cin_segs, cout):
+        """w [Cout][Cin][3][3] fp32 -> wf [Cin_p/8][16][Cout_p][8] (forward) and wd [Cout_p/8][16][Cin_p][8] (data
+        gradient: tap-flipped, transposed).  cin_segs as in PackTable.conv3x3."""
+        cin = sum(s[0] for s in cin_segs)
+        cin_p = sum(s[1] for s in cin_segs)
+        cout_p = cpad(cout)
+        seg = (cin_segs[0][0], cin_segs[0][1]) if len(cin_segs) == 2 else (cin, cin_p)
+        self.jobs.append((w.data_ptr(), wf.data_ptr(), cout_p, cin_p, cout, cin, cout, cout_p, seg[0], seg[1], 0, 0))
+        if wd is not None:
+            self.jobs.append((w.data_ptr(), wd.data_ptr(), cin_p, cout_p, cin, cout, seg[0], seg[1], cout, cout_p, 1, 0))
+
+    def finalize(self, device):
+        lib = _lib.load()
+        assert lib.clamd_sizeof_wino_pack_job() == _WINO_DT.itemsize
+        arr = np.zeros(len(self.jobs), dtype=_WINO_DT)
+        blk = 0
+        for i, j in enumerate(self.jobs):
+            arr[i] = j
+            arr[i]['block0'] = blk
+            blk += (j[2] * j[3] + 255) // 256
+        self.dev_table = torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+        self.nblocks = blk
+        return self
+
+    def run(self, stream=None):
+        call('clamd_wino_pack', ptr(self.dev_table), len(self.jobs), self.nblocks, stream or _lib.stream_ptr())
+
+
 # ---- single-kernel wrappers (tests, small tools) ----------------------------------------------------------------
 def to_nhwc(x_nchw, dcode, cp=None):
     B, C, H, W = x_nchw.shape

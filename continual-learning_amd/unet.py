@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import call, ptr
-from .ops import PackTable, cpad
+from .ops import PackTable, WinoPackTable, cpad
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
@@ -22,6 +22,10 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 # the saved activation is prefetched under the last K-step); True = everywhere the kernels support it (every dgrad
 # launch of the other kernels got 30-80 us slower than the 33-us reduce pass it replaced); False = never.
 FUSE_BN_SUMS = 'auto'
+
+# fp32 path: forward and data gradient of the 3x3 convolutions by Winograd F(2x2,3x3) (csrc/wino.hip): 2.25x fewer MFMA
+# cycles, fp32 transforms (error vs fp64 3.5e-7 against 2.3e-7 for the direct sum).  False = direct implicit GEMM.
+WINOGRAD = True
 
 # bench.py sets this to a list to get per-launch HIP-event timings of the MFMA kernels:
 # entries (tag, algorithmic_flops, start_event, end_event), recorded on the stream the kernel is launched on.
@@ -150,6 +154,7 @@ class _Engine:
         self.model = model
         self.B, self.H, self.W, self.dev = B, H, W, device
         self.dcode, self.tdtype = _DTYPES[model.compute_dtype]
+        self.wino = bool(WINOGRAD) and self.dcode == _lib.F32
         self.R = lib.clamd_stat_replicas()
         self.NS = lib.clamd_bn_bwd_nsums()
         self.generation = 0
@@ -207,8 +212,10 @@ class _Engine:
             u.im2col = first_of_net and 9 * u.cin <= cpad(9 * u.cin) == u.cin_p
             u.y = act(level, u.cout_p)
             u.gz = act(level, u.cout_p)
-            u.wf = torch.zeros((1 if u.im2col else 9) * u.cout_p * u.cin_p, dtype=T, device=dev)
-            u.wd = None if first_of_net else torch.zeros(9 * u.cin_p * u.cout_p, dtype=T, device=dev)
+            u.wino = self.wino and not u.im2col and (u.h | u.w_) % 2 == 0
+            ntap = 1 if u.im2col else (16 if u.wino else 9)     # Winograd: [Cin_p/8][16][Cout_p][8] transformed filters
+            u.wf = torch.zeros(ntap * u.cout_p * u.cin_p, dtype=T, device=dev)
+            u.wd = None if first_of_net else torch.zeros(ntap * u.cin_p * u.cout_p, dtype=T, device=dev)
             u.bias_p = torch.zeros(u.cout_p, dtype=torch.float32, device=dev)
             u.vec = torch.zeros(7, u.cout_p, dtype=torch.float32, device=dev)   # scale, shift, mean, istd, k0, k1, k2
             u.stat_off = sum(stat_sizes)
@@ -306,9 +313,12 @@ class _Engine:
     # ------------------------------------------------------------------------------------------ pack table
     def _build_pack_table(self):
         tab = PackTable(self.dcode)
+        wtab = WinoPackTable()
         for u in self.convs:
             if u.im2col:
                 tab.head(u.w, u.wf, None, 9 * u.cin, u.cout)     # [Cout][Cin*9] is already the (c*9 + tap) K order
+            elif u.wino:
+                wtab.conv3x3(u.w, u.wf, u.wd, u.cin_segs, u.cout)
             else:
                 tab.conv3x3(u.w, u.wf, u.wd, u.cin_segs, u.cout)
             tab.vector(u.b, u.bias_p, u.cout)
@@ -322,6 +332,7 @@ class _Engine:
                 tab.head(t.w, t.wf, t.wd, t.cin, t.cout)
             tab.vector(t.b, t.bias_p, t.cout)
         self.pack_table = tab.finalize(self.dev)
+        self.wino_table = wtab.finalize(self.dev) if wtab.jobs else None
         self._param_ptrs = [p.data_ptr() for p in self.model.parameters()]
 
     def _check_ptrs(self, params):
@@ -349,6 +360,8 @@ class _Engine:
         if training:
             self.stat_arena.zero_()
         self.pack_table.run(dc, s)
+        if self.wino_table is not None:
+            self.wino_table.run(s)
         if self.convs[0].im2col:
             call('clamd_nchw_im2col3', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
                  self.x_in.shape[-1], dc, s)
@@ -379,6 +392,10 @@ class _Engine:
         if u.im2col:
             call('clamd_conv1x1', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
                  ptr(u.stats) if training else None, None, None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
+        elif u.wino:
+            _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout,
+                   'clamd_conv3x3_winograd', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
+                   ptr(u.stats) if training else None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, s)
         else:
             _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout,
                    'clamd_conv3x3', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
@@ -468,7 +485,11 @@ class _Engine:
         _timed('wgrad_conv3x3', flops,
                'clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
                g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, dc, s)
-        if u.g_in is not None:
+        if u.g_in is not None and u.wino:
+            _timed('igemm_conv3x3', flops,
+                   'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
+                   B, u.h, u.w_, u.cout_p, u.cin_p, 0, s)
+        elif u.g_in is not None:
             _timed('igemm_conv3x3', flops,
                    'clamd_conv3x3', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
                    ptr(u.consumer.y) if u.consumer is not None else None,

@@ -313,6 +313,56 @@ def test_wgrad_kernel_structures_agree(C, name, dcode, shape):
         lib.load().clamd_set_tuning(b'wgrad_dma', 1)
 
 
+WINO_SHAPES = [  # B, Cin segs, Cout, H, W (H, W even)
+    (1, [(64, 64)], 64, 16, 16),              # exactly one workgroup tile
+    (2, [(20, 32), (20, 32)], 130, 40, 64),   # concat input, three Cout slabs with a ragged last one, ragged tiles in y
+    (2, [(5, 32)], 7, 8, 12),                 # image smaller than a tile, heavy channel padding
+    (1, [(128, 128)], 96, 34, 18),            # ragged in both directions
+]
+
+
+@pytest.mark.parametrize('shape', WINO_SHAPES)
+def test_conv3x3_winograd_fp32(C, shape):
+    """Winograd F(2x2,3x3) forward (+bias, ReLU, BN statistics) and data gradient, fp32, against the oracle's direct
+    convolution at the SAME bound as the direct kernels (fp32 transforms add ~1e-7 relative error)."""
+    B, segs, cout, H, W = shape
+    rng = np.random.default_rng(21)
+    cin = sum(s[0] for s in segs)
+    x = rnd(rng, B, cin, H, W)
+    w = rnd(rng, cout, cin, 3, 3) * (1.0 / np.sqrt(9 * cin))
+    b = rnd(rng, cout)
+    cin_p, cout_p = sum(s[1] for s in segs), C.ops.cpad(cout)
+    xt = nhwc_with_segs(C, x, segs, 0)
+    wt, bt = dev(w), dev(b)
+    wf = torch.zeros(16 * cout_p * cin_p, device='cuda')
+    wd = torch.zeros(16 * cin_p * cout_p, device='cuda')
+    bp = torch.zeros(cout_p, device='cuda')
+    tab = C.ops.WinoPackTable(); tab.conv3x3(wt, wf, wd, segs, cout); tab.finalize('cuda').run()
+    pt = C.ops.PackTable(0); pt.vector(bt, bp, cout); pt.finalize('cuda').run(0)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    R = lib.load().clamd_stat_replicas()
+    y = torch.full((B, H, W, cout_p), 7.0, device='cuda')
+    stats = torch.zeros(R, 2, cout_p, device='cuda')
+    lib.call('clamd_conv3x3_winograd', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), B, H, W, cin_p, cout_p, 1, s)
+    gz = rnd(rng, B, cout, H, W)
+    gzt = C.ops.to_nhwc(dev(gz), 0)
+    gx = torch.full((B, H, W, cin_p), 3.0, device='cuda')
+    lib.call('clamd_conv3x3_winograd', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, B, H, W, cout_p, cin_p, 0, s)
+    sync()
+    ref = O.relu_fwd(O.conv3x3_fwd(x, w, b))
+    assert rel_l2(C.ops.from_nhwc(y, cout, 0).cpu().numpy(), ref) < TOL[0]
+    st = stats.sum(0).cpu().numpy()
+    np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(st[1, :cout], (ref ** 2).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    assert float(y[..., cout:].abs().max()) == 0.0 if cout < cout_p else True
+    rgx = O.conv3x3_bwd(x, w, gz)[0]
+    pm = phys_map(segs)
+    got_gx = gx.cpu().numpy().transpose(0, 3, 1, 2)
+    assert rel_l2(got_gx[:, [p_ for p_, l in enumerate(pm) if l >= 0]], rgx) < TOL[0]
+    pad = [p_ for p_, l in enumerate(pm) if l < 0]
+    assert not pad or float(np.abs(got_gx[:, pad]).max()) == 0.0
+
+
 def _random_conv_shapes(n, seed):
     """Seeded random problem sizes that hit ragged tiles, several channel slabs, K-step pairs / fours / odd counts and
     the split-K tail of every 3x3 kernel."""
