@@ -163,11 +163,19 @@ def main():
             traffic = pmc_traffic(args.dtype)
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK[args.dtype], 'unit': 'TFLOP/s',
                                'frac': round(ach / PEAK[args.dtype], 4), 'traffic': traffic,
-                               'kernel': 'conv3x3 implicit GEMM, fwd + dgrad launches: clamd::igemm_pws_kernel<T,TW> (persistent, < 256 input '
-                                         'channels) and clamd::igemm_ws_kernel<T,TW,MT> (>= 256 input channels)',
+                               'kernel': ('conv3x3 fwd + dgrad launches: clamd::wino_kernel (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)'
+                                          if args.dtype == 'fp32' else
+                                          'conv3x3 implicit GEMM, fwd + dgrad launches: clamd::igemm_pws_kernel<T,TW> (persistent, <= 256 input '
+                                          'channels) and clamd::igemm_ws_kernel<T,TW,MT> (> 256 input channels)'),
                                'launches': n, 'avg_launch_ms': round(sec / n * 1e3, 4),
                                'ms_per_step': round(sec / 2 * 1e3, 3),
                                'timing': 'HIP events around every launch, 2 instrumented steps after the timed region'}
+            if args.dtype == 'fp32':
+                # `achieved` counts ALGORITHMIC (direct-convolution) FLOPs; the Winograd kernel executes 16/36 of them
+                out['roofline']['executed_flop_fraction'] = round(16.0 / 36.0, 4)
+                out['roofline']['frac_executed'] = round(ach * 16.0 / 36.0 / PEAK[args.dtype], 4)
+                out['roofline']['note'] = ('Winograd F(2x2,3x3): 16 MFMA multiply-adds per 2x2 output tile and channel pair instead of 36; '
+                                           'frac = algorithmic FLOP/s / MFMA peak may exceed 1, frac_executed = MFMA pipe utilisation')
         sec, flops, n = kern.get('wgrad_conv3x3', (0, 0, 0))
         if sec > 0:
             ach = flops / sec / 1e12
