@@ -44,6 +44,8 @@ SIGNATURES = {
     'clamd_pack': (_I, [_P, _I, _I, _I, _P]),
     'clamd_sizeof_wino_pack_job': (_I, []),
     'clamd_wino_pack': (_I, [_P, _I, _I, _P]),
+    'clamd_wgrad_winograd_workspace_bytes': (_SZ, [_I, _I]),
+    'clamd_wgrad_winograd': (_I, [_P, _I, _P, _I, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_conv3x3_winograd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_ce_workspace_bytes': (_SZ, []),
     'clamd_ce_fwd_bwd': (_I, [_P, _P, _P, _I, _I, _D, _D, _P, _P, _P, _SZ, _I, _I, _I, _I, _LL, _D, _P]),

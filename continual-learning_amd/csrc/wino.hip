@@ -334,3 +334,252 @@ int clamd_conv3x3_winograd(const float* x, int x_ldc, const float* w_wino, const
 }
 
 }  // extern "C"
+
+namespace clamd {
+
+// =====================================================================================================================
+// Winograd weight gradient (fp32): dU[xi][r][c] = sum_tiles (A dY A^T)[xi][tile][r] * (B^T d B)[xi][tile][c], then
+// dg = G^T dU G.  Same 2.25x saving as the forward: 16 instead of 36 multiply-adds per 2x2 tile and channel pair.
+//
+// One 256-thread workgroup per CU owns a 64 (r: channels of gz) x 64 (c: channels of x) x 16 (xi) block of dU for a range of
+// pixel tiles (split-K, fp32 slabs, deterministic reduce as in wgrad.hip).  A pixel tile = 4 x 8 Winograd tiles = 8 x 16
+// output pixels: gz tile (128 px) and x halo (10 x 18 px) are staged as [pixel][64 channels] fp32 images (two stages); the
+// contraction index of the MFMA is the tile, so every operand is ONE float per lane (ds_read_b32, lanes = channels:
+// conflict-free) and both transforms happen in registers: wave w owns Winograd row i = w,
+//   A side: rc[q] = sum_p A[w][p] gz[p][q],      Yt[w][j] = sum_q A[j][q] rc[q]        (A = [[1,0],[1,1],[1,-1],[0,-1]])
+//   B side: t[b]  = sum_a B^T[w][a] d[a][b],     V[w][j]  = sum_b B^T[j][b] t[b]
+// and accumulates 4 (j) x 2 x 2 MFMA tiles = 256 accumulator registers.  Slabs are [split][i][r][c][j] (each wave stores
+// its own plane with contiguous 16-byte pieces); wino_wgrad_reduce_kernel sums the splits and applies G^T . G.
+struct WinoWgradParams {
+    const float* a; int a_ldc;       // gz  [B,H,W,a_ldc]
+    const float* b; int b_ldc;       // x   [B,H,W,b_ldc]
+    float* partial;                  // [nsplit][4][Rp][Cp][4]
+    int B, H, W, Rp, Cp, nsplit, tiles_per_split;
+};
+
+constexpr int WW_TY = 4, WW_TX = 8;                                   // Winograd tiles per pixel tile
+constexpr int WW_APIX = (2 * WW_TY) * (2 * WW_TX);                    // 128 gz pixels
+constexpr int WW_BW = 2 * WW_TX + 2, WW_BH = 2 * WW_TY + 2, WW_BPIX = WW_BW * WW_BH;   // 18 x 10 = 180 halo pixels
+constexpr int WW_PS = 256;                                            // bytes per pixel (64 fp32 channels)
+constexpr int WW_ABYTES = WW_APIX * WW_PS, WW_STAGE = (WW_APIX + WW_BPIX) * WW_PS;   // 32 KB + 45 KB
+constexpr int WW_NJA = WW_APIX * 16 / 256, WW_NJB = (WW_BPIX * 16 + 255) / 256;      // 8 + 12 staging loads per thread
+
+__global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const WinoWgradParams p) {
+    static_assert(2 * WW_STAGE <= 160 * 1024, "two stages must fit one CU");
+    __shared__ __attribute__((aligned(16))) char smem[2 * WW_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, kh = lane >> 5;
+
+    const int rt = (p.Rp + 63) >> 6, ct = (p.Cp + 63) >> 6;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tr = bid % rt; bid /= rt;
+    const int tc = bid % ct; bid /= ct;
+    const int split = bid;
+    const int r0 = tr * 64, c0 = tc * 64;
+    const int tiles_x = (p.W + 2 * WW_TX - 1) / (2 * WW_TX), tiles_y = (p.H + 2 * WW_TY - 1) / (2 * WW_TY);
+    const int ntiles = tiles_x * tiles_y * p.B;
+    const int t_begin = split * p.tiles_per_split;
+    const int t_end = min(ntiles, t_begin + p.tiles_per_split);
+    const int n = max(t_end - t_begin, 0);
+
+    const unsigned a_img = (unsigned)p.H * p.W * p.a_ldc * 4u, b_img = (unsigned)p.H * p.W * p.b_ldc * 4u;
+    const unsigned b_shift = (unsigned)(p.W + 1) * p.b_ldc * 4u;      // descriptor base sits one row + one pixel early
+    uint4 ra[WW_NJA], rb[WW_NJB];
+    auto gload = [&](int tile, bool live) {                            // piece = tid + 256*j: 16 lanes = the 256 bytes of one pixel
+        const int x0 = (tile % tiles_x) * (2 * WW_TX), y0 = ((tile / tiles_x) % tiles_y) * (2 * WW_TY), b = live ? tile / (tiles_x * tiles_y) : 0;
+        const __amdgpu_buffer_rsrc_t ars = make_rsrc((const char*)p.a + (size_t)b * a_img, a_img);
+        const __amdgpu_buffer_rsrc_t brs = make_rsrc((const char*)p.b + (size_t)b * b_img - b_shift, b_img + b_shift);
+        const unsigned a_so = (unsigned)((y0 * p.W + x0) * p.a_ldc) * 4u, b_so = (unsigned)((y0 * p.W + x0) * p.b_ldc) * 4u;
+        const int g = tid & 15;
+#pragma unroll
+        for (int j = 0; j < WW_NJA; ++j) {
+            const int pix = (tid >> 4) + 16 * j, py = pix / (2 * WW_TX), px = pix % (2 * WW_TX);
+            const bool ok = live && y0 + py < p.H && x0 + px < p.W && r0 + 4 * g < p.Rp;
+            ra[j] = buf_ld16(ars, ok ? (unsigned)(((py * p.W + px) * p.a_ldc + r0 + 4 * g) * 4) : BUF_OOB, a_so);
+        }
+#pragma unroll
+        for (int j = 0; j < WW_NJB; ++j) {
+            int pix = (tid >> 4) + 16 * j;
+            if (pix >= WW_BPIX) pix -= WW_BPIX;                        // the ragged last pass re-stages the first pixels
+            const int hy = pix / WW_BW, hx = pix % WW_BW;
+            const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+            const bool ok = live && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && c0 + 4 * g < p.Cp;
+            rb[j] = buf_ld16(brs, ok ? (unsigned)(((hy * p.W + hx) * p.b_ldc + c0 + 4 * g) * 4) : BUF_OOB, b_so);
+        }
+    };
+    auto lds_store = [&](int st) {
+        char* sa = smem + st * WW_STAGE;
+        char* sb = sa + WW_ABYTES;
+        const int g = tid & 15;
+#pragma unroll
+        for (int j = 0; j < WW_NJA; ++j) *reinterpret_cast<uint4*>(sa + ((tid >> 4) + 16 * j) * WW_PS + 16 * g) = ra[j];
+#pragma unroll
+        for (int j = 0; j < WW_NJB; ++j) {
+            int pix = (tid >> 4) + 16 * j;
+            if (pix >= WW_BPIX) pix -= WW_BPIX;
+            *reinterpret_cast<uint4*>(sb + pix * WW_PS + 16 * g) = rb[j];
+        }
+    };
+
+    // wave row i = w: coefficients of the two transforms
+    const float c0f = w == 3 ? 0.f : 1.f, c1f = w == 0 ? 0.f : (w == 1 ? 1.f : -1.f);          // A[w] = (c0, c1)
+    const int a1 = w == 0 ? 0 : 1, a2 = w == 3 ? 3 : 2;                                          // B^T[w]: rows a1, a2
+    const float s1 = w == 2 ? -1.f : 1.f, s2 = (w == 0 || w == 3) ? -1.f : 1.f;
+    // lane part of every fragment address: tile parity kh -> 2 pixels to the right, channel r (+32 for the second half)
+    const int a_lane = (2 * kh) * WW_PS + r * 4;
+    const int b_lane1 = WW_ABYTES + (a1 * WW_BW + 2 * kh) * WW_PS + r * 4, b_lane2 = WW_ABYTES + (a2 * WW_BW + 2 * kh) * WW_PS + r * 4;
+
+    f32x16 acc[4][2][2];                                               // [j][r half][c half]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][i >> 1][i & 1][e] = 0.f;
+
+    gload(t_begin, n > 0);
+    if (n > 0) lds_store(0);
+    __syncthreads();
+    for (int it = 0; it < n; ++it) {
+        gload(t_begin + it + 1, it + 1 < n);                           // in flight under this tile's 256 MFMAs
+        const char* sm = smem + (it & 1) * WW_STAGE;
+#pragma unroll
+        for (int s = 0; s < WW_TY * WW_TX / 2; ++s) {                  // one MFMA k-step = tiles 2s, 2s+1 (neighbours in x)
+            const int ty = s / (WW_TX / 2), tx2 = 2 * (s % (WW_TX / 2));      // this lane's tile = (ty, tx2 + kh)
+            const int apix = (2 * ty) * (2 * WW_TX) + 2 * tx2, bpix = (2 * ty) * WW_BW + 2 * tx2;
+            float Yt[4][2], V[4][2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const char* ap = sm + a_lane + apix * WW_PS + 128 * hf;
+                const float g00 = *reinterpret_cast<const float*>(ap), g01 = *reinterpret_cast<const float*>(ap + WW_PS);
+                const float g10 = *reinterpret_cast<const float*>(ap + 2 * WW_TX * WW_PS), g11 = *reinterpret_cast<const float*>(ap + (2 * WW_TX + 1) * WW_PS);
+                const float rc0 = fmaf(c1f, g10, c0f * g00), rc1 = fmaf(c1f, g11, c0f * g01);
+                Yt[0][hf] = rc0; Yt[1][hf] = rc0 + rc1; Yt[2][hf] = rc0 - rc1; Yt[3][hf] = -rc1;
+                const char* bp1 = sm + b_lane1 + bpix * WW_PS + 128 * hf;
+                const char* bp2 = sm + b_lane2 + bpix * WW_PS + 128 * hf;
+                float t[4];
+#pragma unroll
+                for (int bcol = 0; bcol < 4; ++bcol)
+                    t[bcol] = fmaf(s2, *reinterpret_cast<const float*>(bp2 + bcol * WW_PS), s1 * *reinterpret_cast<const float*>(bp1 + bcol * WW_PS));
+                V[0][hf] = t[0] - t[2]; V[1][hf] = t[1] + t[2]; V[2][hf] = t[2] - t[1]; V[3][hf] = t[1] - t[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch)
+                        acc[j][rh][ch] = __builtin_amdgcn_mfma_f32_32x32x2f32(Yt[j][rh], V[j][ch], acc[j][rh][ch], 0, 0, 0);
+        }
+        if (it + 1 < n) lds_store((it + 1) & 1);                       // that stage was released by the last barrier
+        __syncthreads();
+    }
+
+    // ---- slab: plane i = w, [r][c][j]: lane (col c = 32*ch + r, rows acc_row(e, kh) + 32*rh) stores 16 bytes (j = 0..3)
+    float* const plane = p.partial + (((size_t)split * 4 + w) * p.Rp + r0) * (size_t)p.Cp * 4;
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int col = c0 + 32 * ch + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 32 * rh + acc_row(e, kh);
+                if (r0 + row < p.Rp && col < p.Cp)
+                    *reinterpret_cast<float4*>(plane + ((size_t)row * p.Cp + col) * 4) =
+                        make_float4(acc[0][rh][ch][e], acc[1][rh][ch][e], acc[2][rh][ch][e], acc[3][rh][ch][e]);
+            }
+        }
+}
+
+// out[rl][cl][3][3] = G^T (sum_s dU_s) G.  256 threads = 16 (r,c) pairs x 4 planes x 4 split-phases.
+struct WinoReduceParams {
+    const float* partial; float* out;
+    int nsplit, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p;
+};
+
+__global__ void __launch_bounds__(256) wino_wgrad_reduce_kernel(const WinoReduceParams p) {
+    __shared__ float4 red[4][4][16];                                   // [phase][plane][pair]
+    const int pr = threadIdx.x & 15, pl = (threadIdx.x >> 4) & 3, ph = threadIdx.x >> 6;
+    const long long npair = (long long)p.Rp * p.Cp;
+    const size_t plane_sz = (size_t)npair * 4, split_sz = plane_sz * 4;
+    for (long long base = (long long)blockIdx.x * 16; base < npair; base += (long long)gridDim.x * 16) {
+        const long long e = base + pr;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < npair)
+            for (int k = ph; k < p.nsplit; k += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(p.partial + (size_t)k * split_sz + pl * plane_sz + (size_t)e * 4);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        red[ph][pl][pr] = s;
+        __syncthreads();
+        if (threadIdx.x < 16 && e < npair) {
+            float U[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 a = red[0][i][pr], b = red[1][i][pr], c = red[2][i][pr], d = red[3][i][pr];
+                U[i][0] = (a.x + b.x) + (c.x + d.x); U[i][1] = (a.y + b.y) + (c.y + d.y);
+                U[i][2] = (a.z + b.z) + (c.z + d.z); U[i][3] = (a.w + b.w) + (c.w + d.w);
+            }
+            // dg = G^T U G, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+            float t[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = U[0][j] + 0.5f * (U[1][j] + U[2][j]);
+                t[1][j] = 0.5f * (U[1][j] - U[2][j]);
+                t[2][j] = U[3][j] + 0.5f * (U[1][j] + U[2][j]);
+            }
+            const int cp = (int)(e % p.Cp), rp = (int)(e / p.Cp);
+            const int rl = wn_phys2log(rp, p.r_seg0, p.r_seg0p, p.R), cl = wn_phys2log(cp, p.c_seg0, p.c_seg0p, p.C);
+            if (rl >= 0 && cl >= 0) {
+                float* o = p.out + ((size_t)rl * p.C + cl) * 9;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    o[a * 3 + 0] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+                    o[a * 3 + 1] = 0.5f * (t[a][1] - t[a][2]);
+                    o[a * 3 + 2] = t[a][3] + 0.5f * (t[a][1] + t[a][2]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace clamd
+
+extern "C" {
+
+size_t clamd_wgrad_winograd_workspace_bytes(int Rp, int Cp) {
+    int nsplit = 256 / (((Rp + 63) / 64) * ((Cp + 63) / 64));
+    if (nsplit < 1) nsplit = 1;
+    return (size_t)nsplit * 16 * Rp * Cp * sizeof(float);
+}
+
+int clamd_wgrad_winograd(const float* gz, int gz_ldc, const float* x, int x_ldc, float* workspace, size_t ws_bytes, float* out,
+                         int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p,
+                         void* stream) {
+    using namespace clamd;
+    if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("wgrad_winograd: empty problem");
+    if ((H | W) & 1) return clamd_fail("wgrad_winograd: H and W must be even");
+    if (Rp % 32 || Cp % 32 || gz_ldc % 8 || x_ldc % 8) return clamd_fail("wgrad_winograd: channel counts/pitches must be padded");
+    if ((long long)H * W * gz_ldc * 4 >= (1ll << 30) || (long long)H * W * x_ldc * 4 >= (1ll << 30)) return clamd_fail("wgrad_winograd: one image exceeds 2^30 bytes");
+    const int rt = (Rp + 63) / 64, ct = (Cp + 63) / 64;
+    const int ntiles = ((W + 2 * WW_TX - 1) / (2 * WW_TX)) * ((H + 2 * WW_TY - 1) / (2 * WW_TY)) * B;
+    int nsplit = 256 / (rt * ct);
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > ntiles) nsplit = ntiles;
+    const int per = (ntiles + nsplit - 1) / nsplit;
+    nsplit = (ntiles + per - 1) / per;
+    if ((size_t)nsplit * 16 * Rp * Cp * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd: workspace too small");
+    WinoWgradParams p{gz, gz_ldc, x, x_ldc, workspace, B, H, W, Rp, Cp, nsplit, per};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(rt * ct * nsplit), dim3(256), 0, s, p);
+    if (int e = clamd_check_launch("wgrad_winograd")) return e;
+    WinoReduceParams rp{workspace, out, nsplit, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p};
+    long long g = ((long long)Rp * Cp + 15) / 16;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, rp);
+    return clamd_check_launch("wgrad_winograd_reduce");
+}
+
+}  // extern "C"

@@ -299,6 +299,8 @@ class _Engine:
         ws = 0
         for u in convs:
             ws = max(ws, lib.clamd_wgrad_workspace_bytes(_lib.WGRAD_CONV3, B, u.h, u.w_, u.cout_p, u.cin_p, self.dcode))
+            if u.wino:
+                ws = max(ws, lib.clamd_wgrad_winograd_workspace_bytes(u.cout_p, u.cin_p))
         for s in self.stages:
             t = s.get('tail')
             if t is not None:
@@ -482,9 +484,14 @@ class _Engine:
             call('clamd_wgrad', _lib.WGRAD_PW, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
                  g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, 9 * u.cin, u.cout, u.cout_p, 9 * u.cin, u.cin_p, dc, s)
             return
-        _timed('wgrad_conv3x3', flops,
-               'clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
-               g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, dc, s)
+        if u.wino:
+            _timed('wgrad_conv3x3', flops,
+                   'clamd_wgrad_winograd', ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
+                   g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, s)
+        else:
+            _timed('wgrad_conv3x3', flops,
+                   'clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
+                   g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, dc, s)
         if u.g_in is not None and u.wino:
             _timed('igemm_conv3x3', flops,
                    'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,

@@ -60,6 +60,12 @@ int clamd_sizeof_wino_pack_job(void);
 int clamd_wino_pack(const void* jobs_dev, int njobs, int total_blocks, void* stream);
 int clamd_conv3x3_winograd(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
                            float* stats, int B, int H, int W, int Cin_p, int Cout_p, int relu, void* stream);
+/* Weight gradient of the same convolution by Winograd (fp32, H and W even): out [R][C][3][3] = G^T (sum over tiles of
+ * (A dY A^T) x (B^T d B)) G; arguments as clamd_wgrad(CLAMD_WGRAD_CONV3, ...) (gz = d loss / d conv output, x = conv input). */
+size_t clamd_wgrad_winograd_workspace_bytes(int Rp, int Cp);
+int clamd_wgrad_winograd(const float* gz, int gz_ldc, const float* x, int x_ldc, float* workspace, size_t ws_bytes, float* out,
+                         int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p,
+                         void* stream);
 /* 1x1 convolution, NHWC output, same epilogue options as clamd_conv3x3 (bias, ReLU, BN statistics).  Used for the
  * data gradient of the head (unet.py:72) and, on an im2col'ed input (clamd_nchw_im2col3), for the first conv
  * enc1.0 (unet.py:50, Cin = 3).  w_packed [1][Cout_p][Cin_p]. */

@@ -361,6 +361,16 @@ def test_conv3x3_winograd_fp32(C, shape):
     assert rel_l2(got_gx[:, [p_ for p_, l in enumerate(pm) if l >= 0]], rgx) < TOL[0]
     pad = [p_ for p_, l in enumerate(pm) if l < 0]
     assert not pad or float(np.abs(got_gx[:, pad]).max()) == 0.0
+    # weight gradient by Winograd
+    wsb = lib.load().clamd_wgrad_winograd_workspace_bytes(cout_p, cin_p)
+    ws = torch.empty(wsb // 4 + 4, device='cuda')
+    gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
+    c_seg0, c_seg0p = (segs[0][0], segs[0][1]) if len(segs) == 2 else (cin, cin_p)
+    lib.call('clamd_wgrad_winograd', ptr(gzt), cout_p, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, cin_p, cout, cin,
+             cout, cout_p, c_seg0, c_seg0p, s)
+    sync()
+    rgw = O.conv3x3_bwd(x, w, gz)[1]
+    assert rel_l2(gw.cpu().numpy(), rgw) < 2e-5
 
 
 def _random_conv_shapes(n, seed):
