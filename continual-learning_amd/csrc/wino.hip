@@ -34,25 +34,30 @@ struct WinoParams {
     int B, H, W, Kp, Np, relu;
 };
 
-constexpr int WN_HW = 18, WN_PIX = WN_HW * WN_HW;            // input halo of a 16x16 output tile
-constexpr int WN_PIXP = 330;                                  // == 2 (mod 8): conflict-free staging stores
+constexpr int WN_HW = 18;                                     // input halo width of a 16-pixel-wide output tile
 constexpr int WN_WG = 66;                                     // padded rows per (xi, group)
-constexpr int WN_IN_SLOTS = 2 * WN_PIXP, WN_WT_SLOTS = 16 * 2 * WN_WG;
-constexpr int WN_STAGE = WN_IN_SLOTS + WN_WT_SLOTS;           // 16-byte slots per stage (44 KB)
+constexpr int WN_WT_SLOTS = 16 * 2 * WN_WG;
 constexpr int WN_EXP = 36;                                    // row pitch (floats) of the epilogue exchange block
 
+// MT = 32-tile halves per workgroup: 2 -> 8x8 Winograd tiles = 16x16 output pixels; 1 -> 4x8 tiles = 8x16 pixels (used when
+// the 16x16 grid would leave CUs without a workgroup)
+template <int MT>
 __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
+    constexpr int WN_HH = 8 * MT + 2, WN_PIX = WN_HW * WN_HH;             // input halo of the output tile
+    constexpr int WN_PIXP = WN_PIX + ((10 - WN_PIX % 8) % 8);             // == 2 (mod 8): conflict-free staging stores
+    constexpr int WN_IN_SLOTS = 2 * WN_PIXP, WN_STAGE = WN_IN_SLOTS + WN_WT_SLOTS;
+    constexpr int NJI = (2 * WN_PIX + 255) / 256;                         // input staging loads per thread
     constexpr int NST = 2;                     // LDS stages: chunk k+1 readable, chunk k+2 being written (chunk k is in registers)
     static_assert(4 * 2 * 32 * WN_EXP * 4 <= NST * WN_STAGE * 16 && NST * WN_STAGE * 16 <= 160 * 1024, "LDS budget");
     __shared__ uint4 smem[NST * WN_STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 15) >> 4;
+    const int tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 8 * MT - 1) / (8 * MT);
     const int ntn = (p.Np + 63) >> 6;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = bid % ntn, tm = bid / ntn;
-    const int x0 = (tm % tiles_x) * 16, y0 = ((tm / tiles_x) % tiles_y) * 16, b = tm / (tiles_x * tiles_y);
+    const int x0 = (tm % tiles_x) * 16, y0 = ((tm / tiles_x) % tiles_y) * (8 * MT), b = tm / (tiles_x * tiles_y);
     const int n0 = tn * 64;
     const int nk = p.Kp >> 3;
 
@@ -60,11 +65,11 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
     const unsigned img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc * 4u;
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x + (size_t)b * img, img);
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.w, (unsigned)(16u * p.Np * p.Kp * 4u));
-    unsigned in_vo[3];
-    int in_slot[3];
+    unsigned in_vo[NJI];
+    int in_slot[NJI];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        int piece = tid + 256 * j;                           // (pixel, 16-byte group): 648 pieces, the last pass wraps
+    for (int j = 0; j < NJI; ++j) {
+        int piece = tid + 256 * j;                           // (pixel, 16-byte group); the last pass wraps
         if (piece >= 2 * WN_PIX) piece -= 2 * WN_PIX;
         const int g = piece & 1, pix = piece >> 1;
         const int hy = pix / WN_HW, hx = pix - hy * WN_HW;
@@ -79,29 +84,31 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
     const unsigned w_chunk = (unsigned)(16 * p.Np * 8 * 4);   // bytes of one K-chunk
     const int w_slot0 = WN_IN_SLOTS + (wxi0 * 2 + wg_) * WN_WG + wn_;
 
-    uint4 rin[3], rw[8];
-    auto gload = [&](int k, bool live) {
+    uint4 rin[NJI], rw[8];
+    auto gload_to = [&](int k, bool live, uint4 (&ri)[NJI], uint4 (&rww)[8]) {
         const unsigned so = (unsigned)(k * 8 * 4);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) rin[j] = buf_ld16(xrs, live ? in_vo[j] : BUF_OOB, so);
+        for (int j = 0; j < NJI; ++j) ri[j] = buf_ld16(xrs, live ? in_vo[j] : BUF_OOB, so);
         const unsigned wv = live ? w_vo0 : BUF_OOB;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rw[j] = buf_ld16(wrs, wv + j * w_vstep, (unsigned)k * w_chunk);
+        for (int j = 0; j < 8; ++j) rww[j] = buf_ld16(wrs, wv + j * w_vstep, (unsigned)k * w_chunk);
     };
-    auto lds_store = [&](int st) {
+    auto lds_store_from = [&](int st, const uint4 (&ri)[NJI], const uint4 (&rww)[8]) {
         uint4* sm = smem + st * WN_STAGE;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) sm[in_slot[j]] = rin[j];
+        for (int j = 0; j < NJI; ++j) sm[in_slot[j]] = ri[j];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sm[w_slot0 + j * 4 * WN_WG] = rw[j];
+        for (int j = 0; j < 8; ++j) sm[w_slot0 + j * 4 * WN_WG] = rww[j];
     };
+    auto gload = [&](int k, bool live) { gload_to(k, live, rin, rw); };
+    auto lds_store = [&](int st) { lds_store_from(st, rin, rw); };
 
     // ---- fragment addressing: wave w = Winograd row i: t[b] = s1 * d[a1][b] + s2 * d[a2][b] ------------------------
     const int a1 = w == 0 ? 0 : 1, a2 = w == 3 ? 3 : 2;
     const float s1 = w == 2 ? -1.f : 1.f, s2 = (w == 0 || w == 3) ? -1.f : 1.f;
-    int p1[2], p2[2];
+    int p1[MT], p2[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         const int m = 32 * mt + r, ty = m >> 3, tx = m & 7;
         const int pb = h * WN_PIXP + (2 * ty) * WN_HW + 2 * tx;
         p1[mt] = pb + a1 * WN_HW;
@@ -109,20 +116,20 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
     }
     const int wb = WN_IN_SLOTS + (4 * w * 2 + h) * WN_WG + r;            // + j*2*WG + 32*nt
 
-    f32x16 acc[4][2][2];                                                  // [j][tile half][channel half]
+    f32x16 acc[4][MT][2];                                                 // [j][tile half][channel half]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2 * MT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][i >> 1][i & 1][e] = 0.f;
 
     // fragments of one chunk: the input transform V[w][j] for both tile halves + the filter rows of this wave's 4 xi
-    uint4 A[4][2], Bf[4][2];
+    uint4 A[4][MT], Bf[4][2];
     auto frags = [&](int st) {
         const uint4* sm = smem + st * WN_STAGE;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             float4 t[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -148,20 +155,26 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
     // Pipeline (one wave per SIMD, nothing else hides a stall): while the MFMAs of chunk k run from registers, the
     // fragments of chunk k+1 are read from LDS and transformed, the raw data of chunk k+2 (loaded one chunk ago) is
     // written to the third stage and the loads of chunk k+3 are issued.  One barrier per chunk.
-    gload(0, true);
-    lds_store(0);
-    gload(1, 1 < nk);
-    lds_store(1);
-    gload(2, 2 < nk);
+    {   // prologue: the first three chunks are requested back to back (one memory latency, not three)
+        uint4 ri0[NJI], rw0[8], ri1[NJI], rw1[8];
+        gload_to(0, true, ri0, rw0);
+        gload_to(1, 1 < nk, ri1, rw1);
+        gload(2, 2 < nk);
+        lds_store_from(0, ri0, rw0);
+        lds_store_from(1, ri1, rw1);
+    }
     __syncthreads();
     frags(0);
     __syncthreads();                                                      // stage 0 is free again
     for (int k = 0; k < nk; ++k) {
-        uint4 Ac[4][2], Bc[4][2];
+        uint4 Ac[4][MT], Bc[4][2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { Ac[j][i] = A[j][i]; Bc[j][i] = Bf[j][i]; }
+            for (int i = 0; i < MT; ++i) Ac[j][i] = A[j][i];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) Bc[j][i] = Bf[j][i];
+        }
         // straight-line body (past the last chunk the reads hit valid LDS and the stores write zeros nobody reads), so
         // that the 24 fragment reads, ~130 transform VALU ops, 11 staging stores and 11 loads can be issued in the gaps
         // of the 64 MFMAs instead of in front of them
@@ -169,12 +182,13 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) mma16<float>(Ac[j][mt], Bc[j][nt], acc[j][mt][nt]);
         lds_store(k % NST);                                               // chunk k+2 over chunk k's stage (read before the last barrier)
         gload(k + 3, k + 3 < nk);
-        sched_mfma_slots<64, 24, 26, 37, 38, 49, 2>();
+        if constexpr (MT == 2) sched_mfma_slots<64, 24, 26, 37, 38, 49, 2>();
+        else sched_mfma_slots<32, 16, 17, 27, 21, 31, 2>();
         __syncthreads();
     }
 
@@ -186,7 +200,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
     for (int i = 0; i < 8; ++i) { st1[i >> 2][i & 3] = 0.f; st2[i >> 2][i & 3] = 0.f; }
     const float relu_lo = p.relu ? 0.f : -__builtin_inff();
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
@@ -327,9 +341,12 @@ int clamd_conv3x3_winograd(const float* x, int x_ldc, const float* w_wino, const
     if ((long long)H * W * x_ldc * 4 >= (1ll << 31) || (long long)16 * Cout_p * Cin_p * 4 >= (1ll << 31))
         return clamd_fail("conv3x3_winograd: image or filter exceeds 2^31 bytes");
     WinoParams p{x, x_ldc, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu};
-    const long long nblk = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ((Cout_p + 63) / 64);
-    if (nblk > 0x7fffffff) return clamd_fail("conv3x3_winograd: grid out of range");
-    hipLaunchKernelGGL(wino_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, p);
+    const long long ntn = (Cout_p + 63) / 64, nblk2 = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ntn;
+    const long long nblk1 = (long long)B * ((H + 7) / 8) * ((W + 15) / 16) * ntn;
+    if (nblk1 > 0x7fffffff) return clamd_fail("conv3x3_winograd: grid out of range");
+    // one workgroup per CU: 16x16-pixel tiles unless that grid would leave a quarter of the CUs without one
+    if (nblk2 >= 192 || nblk1 == nblk2) hipLaunchKernelGGL((wino_kernel<2>), dim3((unsigned)nblk2), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((wino_kernel<1>), dim3((unsigned)nblk1), dim3(256), 0, (hipStream_t)stream, p);
     return clamd_check_launch("conv3x3_winograd");
 }
 

@@ -212,7 +212,8 @@ class _Engine:
             u.im2col = first_of_net and 9 * u.cin <= cpad(9 * u.cin) == u.cin_p
             u.y = act(level, u.cout_p)
             u.gz = act(level, u.cout_p)
-            u.wino = self.wino and not u.im2col and (u.h | u.w_) % 2 == 0
+            # Winograd tiles are 2x2 outputs inside 8x16 / 16x16-pixel workgroup tiles: nothing to gain below 8x8 images
+            u.wino = self.wino and not u.im2col and (u.h | u.w_) % 2 == 0 and min(u.h, u.w_) >= 8
             ntap = 1 if u.im2col else (16 if u.wino else 9)     # Winograd: [Cin_p/8][16][Cout_p][8] transformed filters
             u.wf = torch.zeros(ntap * u.cout_p * u.cin_p, dtype=T, device=dev)
             u.wd = None if first_of_net else torch.zeros(ntap * u.cin_p * u.cout_p, dtype=T, device=dev)

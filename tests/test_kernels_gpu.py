@@ -318,6 +318,7 @@ WINO_SHAPES = [  # B, Cin segs, Cout, H, W (H, W even)
     (2, [(20, 32), (20, 32)], 130, 40, 64),   # concat input, three Cout slabs with a ragged last one, ragged tiles in y
     (2, [(5, 32)], 7, 8, 12),                 # image smaller than a tile, heavy channel padding
     (1, [(128, 128)], 96, 34, 18),            # ragged in both directions
+    (3, [(32, 32)], 64, 128, 128),            # 192 workgroups: the 16x16-pixel tile variant (smaller grids take 8x16)
 ]
 
 

@@ -40,8 +40,14 @@ def maxrel(a, b):
 
 
 @pytest.mark.parametrize('fixture,nc,cd,size', [('unet_cd4_c2_32.npz', 2, 4, 32), ('unet_cd8_c21_64.npz', 21, 8, 64)])
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'bf16x3'])
-def test_train_steps_vs_reference_golden(C, golden, fixture, nc, cd, size, dtype):
+@pytest.mark.parametrize('dtype', ['fp32', 'fp32-direct', 'bf16', 'bf16x3'])
+def test_train_steps_vs_reference_golden(C, golden, fixture, nc, cd, size, dtype, monkeypatch):
+    # 'fp32' runs the Winograd kernels where the engine uses them, 'fp32-direct' the direct implicit-GEMM kernels
+    from continual_learning_amd import unet as U
+    direct = dtype == 'fp32-direct'
+    if direct:
+        monkeypatch.setattr(U, 'WINOGRAD', False)
+        dtype = 'fp32'
     g = golden(fixture)
     model = C.UNet(nc, 3, cd, compute_dtype=dtype)
     assert [n for n, _ in model.named_parameters()] == list(g['grad_names'])      # names AND order (Adam state is positional)
@@ -90,7 +96,11 @@ def test_train_steps_vs_reference_golden(C, golden, fixture, nc, cd, size, dtype
         opt.step()
         losses.append(float(loss))
     np.testing.assert_allclose(losses, g['losses'], rtol=2e-4 if dtype == 'fp32' else (2e-3 if fp32 else 6e-2))
-    if dtype == 'fp32' and 'w3/enc1.0.weight' in g.files:
+    # Weights after three Adam steps, element by element: only for the direct kernels.  These toy models (BatchNorm over
+    # as few as 8 values, Adam steps of +-lr whatever the gradient's size) amplify rounding-level differences into sign
+    # flips, so the check is tied to one summation order; the Winograd path is held to the losses, logits, gradient norms,
+    # statistics and metrics above, to the per-kernel tests and to the full-size golden test.
+    if dtype == 'fp32' and direct and 'w3/enc1.0.weight' in g.files:
         sd = model.state_dict()
         for k in g.files:
             if k.startswith('w3/'):
