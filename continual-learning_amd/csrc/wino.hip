@@ -367,6 +367,10 @@ namespace clamd {
 //   B side: t[b]  = sum_a B^T[w][a] d[a][b],     V[w][j]  = sum_b B^T[j][b] t[b]
 // and accumulates 4 (j) x 2 x 2 MFMA tiles = 256 accumulator registers.  Slabs are [split][i][r][c][j] (each wave stores
 // its own plane with contiguous 16-byte pieces); wino_wgrad_reduce_kernel sums the splits and applies G^T . G.
+#ifdef CLAMD_DIAG
+__device__ unsigned long long g_ww_diag[4];      // diagnostic build only
+#endif
+
 struct WinoWgradParams {
     const float* a; int a_ldc;       // gz  [B,H,W,a_ldc]
     const float* b; int b_ldc;       // x   [B,H,W,b_ldc]
@@ -457,41 +461,92 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const WinoWgradParam
     gload(t_begin, n > 0);
     if (n > 0) lds_store(0);
     __syncthreads();
+#ifdef CLAMD_DIAG
+    const unsigned long long dg0 = __builtin_amdgcn_s_memtime(), dr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int it = 0; it < n; ++it) {
+#ifndef WW_ABLATE_STAGING
         gload(t_begin + it + 1, it + 1 < n);                           // in flight under this tile's 256 MFMAs
         const char* sm = smem + (it & 1) * WW_STAGE;
-#pragma unroll
-        for (int s = 0; s < WW_TY * WW_TX / 2; ++s) {                  // one MFMA k-step = tiles 2s, 2s+1 (neighbours in x)
-            const int ty = s / (WW_TX / 2), tx2 = 2 * (s % (WW_TX / 2));      // this lane's tile = (ty, tx2 + kh)
-            const int apix = (2 * ty) * (2 * WW_TX) + 2 * tx2, bpix = (2 * ty) * WW_BW + 2 * tx2;
-            float Yt[4][2], V[4][2];
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const char* ap = sm + a_lane + apix * WW_PS + 128 * hf;
-                const float g00 = *reinterpret_cast<const float*>(ap), g01 = *reinterpret_cast<const float*>(ap + WW_PS);
-                const float g10 = *reinterpret_cast<const float*>(ap + 2 * WW_TX * WW_PS), g11 = *reinterpret_cast<const float*>(ap + (2 * WW_TX + 1) * WW_PS);
-                const float rc0 = fmaf(c1f, g10, c0f * g00), rc1 = fmaf(c1f, g11, c0f * g01);
-                Yt[0][hf] = rc0; Yt[1][hf] = rc0 + rc1; Yt[2][hf] = rc0 - rc1; Yt[3][hf] = -rc1;
-                const char* bp1 = sm + b_lane1 + bpix * WW_PS + 128 * hf;
-                const char* bp2 = sm + b_lane2 + bpix * WW_PS + 128 * hf;
-                float t[4];
-#pragma unroll
-                for (int bcol = 0; bcol < 4; ++bcol)
-                    t[bcol] = fmaf(s2, *reinterpret_cast<const float*>(bp2 + bcol * WW_PS), s1 * *reinterpret_cast<const float*>(bp1 + bcol * WW_PS));
-                V[0][hf] = t[0] - t[2]; V[1][hf] = t[1] + t[2]; V[2][hf] = t[2] - t[1]; V[3][hf] = t[1] - t[3];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int rh = 0; rh < 2; ++rh)
-#pragma unroll
-                    for (int ch = 0; ch < 2; ++ch)
-                        acc[j][rh][ch] = __builtin_amdgcn_mfma_f32_32x32x2f32(Yt[j][rh], V[j][ch], acc[j][rh][ch], 0, 0, 0);
-        }
+#else
+        const char* sm = smem;                                         // timing ablation: every tile multiplies stage 0
+#endif
+        // One MFMA k-step = tiles 2s, 2s+1 (neighbours in x); this lane's tile = (ty, tx2 + kh).  Software pipeline, one
+        // wave per SIMD: the 24 raw reads of step s+1 are issued before the 16 MFMAs of step s and transformed between its
+        // two halves, so no read is waited for with the matrix pipe empty (without this: 60 % MFMA utilisation).
+        float raw[2][2][6];                                            // [set][channel half][g00 g01 g10 g11 | .. see below]
+        float rawb[2][2][8];                                           // [set][channel half][row a1: 4 columns, row a2: 4 columns]
+        float Yt[2][4][2], V[2][4][2];
+#define WW_LOAD(s_, z_)                                                                                            \
+    do {                                                                                                           \
+        constexpr int ty_ = (s_) / (WW_TX / 2), tx2_ = 2 * ((s_) % (WW_TX / 2));                                   \
+        constexpr int apix_ = (2 * ty_) * (2 * WW_TX) + 2 * tx2_, bpix_ = (2 * ty_) * WW_BW + 2 * tx2_;            \
+        _Pragma("unroll") for (int hf_ = 0; hf_ < 2; ++hf_) {                                                      \
+            const char* ap_ = sm + a_lane + apix_ * WW_PS + 128 * hf_;                                             \
+            raw[z_][hf_][0] = *reinterpret_cast<const float*>(ap_);                                                \
+            raw[z_][hf_][1] = *reinterpret_cast<const float*>(ap_ + WW_PS);                                        \
+            raw[z_][hf_][2] = *reinterpret_cast<const float*>(ap_ + 2 * WW_TX * WW_PS);                            \
+            raw[z_][hf_][3] = *reinterpret_cast<const float*>(ap_ + (2 * WW_TX + 1) * WW_PS);                      \
+            const char* bp1_ = sm + b_lane1 + bpix_ * WW_PS + 128 * hf_;                                           \
+            const char* bp2_ = sm + b_lane2 + bpix_ * WW_PS + 128 * hf_;                                           \
+            _Pragma("unroll") for (int bc_ = 0; bc_ < 4; ++bc_) {                                                  \
+                rawb[z_][hf_][bc_] = *reinterpret_cast<const float*>(bp1_ + bc_ * WW_PS);                          \
+                rawb[z_][hf_][4 + bc_] = *reinterpret_cast<const float*>(bp2_ + bc_ * WW_PS);                      \
+            }                                                                                                      \
+        }                                                                                                          \
+    } while (0)
+#define WW_TRANSFORM(z_)                                                                                           \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int hf_ = 0; hf_ < 2; ++hf_) {                                                      \
+            const float rc0_ = fmaf(c1f, raw[z_][hf_][2], c0f * raw[z_][hf_][0]);                                  \
+            const float rc1_ = fmaf(c1f, raw[z_][hf_][3], c0f * raw[z_][hf_][1]);                                  \
+            Yt[z_][0][hf_] = rc0_; Yt[z_][1][hf_] = rc0_ + rc1_; Yt[z_][2][hf_] = rc0_ - rc1_; Yt[z_][3][hf_] = -rc1_; \
+            float t_[4];                                                                                           \
+            _Pragma("unroll") for (int bc_ = 0; bc_ < 4; ++bc_) t_[bc_] = fmaf(s2, rawb[z_][hf_][4 + bc_], s1 * rawb[z_][hf_][bc_]); \
+            V[z_][0][hf_] = t_[0] - t_[2]; V[z_][1][hf_] = t_[1] + t_[2]; V[z_][2][hf_] = t_[2] - t_[1]; V[z_][3][hf_] = t_[1] - t_[3]; \
+        }                                                                                                          \
+    } while (0)
+#define WW_MMA(z_, j0_, j1_)                                                                                       \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int j_ = (j0_); j_ < (j1_); ++j_)                                                   \
+            _Pragma("unroll") for (int rh_ = 0; rh_ < 2; ++rh_)                                                    \
+                _Pragma("unroll") for (int ch_ = 0; ch_ < 2; ++ch_)                                                \
+                    acc[j_][rh_][ch_] = __builtin_amdgcn_mfma_f32_32x32x2f32(Yt[z_][j_][rh_], V[z_][j_][ch_], acc[j_][rh_][ch_], 0, 0, 0); \
+    } while (0)
+#define WW_STEP(s_)                                                                                                \
+    do {                                                                                                           \
+        if constexpr ((s_) + 1 < WW_TY * WW_TX / 2) WW_LOAD((s_) + 1, ((s_) + 1) & 1);                             \
+        __builtin_amdgcn_sched_barrier(0);                 /* keep the reads in front of these 8 MFMAs ... */      \
+        WW_MMA((s_) & 1, 0, 2);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                 /* ... and their consumers behind them */               \
+        if constexpr ((s_) + 1 < WW_TY * WW_TX / 2) WW_TRANSFORM(((s_) + 1) & 1);                                  \
+        WW_MMA((s_) & 1, 2, 4);                                                                                    \
+        sched_mfma_slots<8, 0, 0, 0, 0, 0, 6>();           /* the ~42 transform VALU ops in the gaps of these 8 MFMAs */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    } while (0)
+        WW_LOAD(0, 0);
+        WW_TRANSFORM(0);
+        WW_STEP(0); WW_STEP(1); WW_STEP(2); WW_STEP(3); WW_STEP(4); WW_STEP(5); WW_STEP(6); WW_STEP(7);
+        WW_STEP(8); WW_STEP(9); WW_STEP(10); WW_STEP(11); WW_STEP(12); WW_STEP(13); WW_STEP(14); WW_STEP(15);
+        static_assert(WW_TY * WW_TX / 2 == 16, "16 k-steps per pixel tile");
+#undef WW_STEP
+#undef WW_MMA
+#undef WW_TRANSFORM
+#undef WW_LOAD
+#ifndef WW_ABLATE_STAGING
         if (it + 1 < n) lds_store((it + 1) & 1);                       // that stage was released by the last barrier
         __syncthreads();
+#endif
     }
 
+#ifdef CLAMD_DIAG
+    if (lane == 0 && w == 0) {      // [0] shader cycles, [1] 100-MHz ticks of the tile loop, [2] tiles, [3] workgroups
+        atomicAdd(&g_ww_diag[0], __builtin_amdgcn_s_memtime() - dg0);
+        atomicAdd(&g_ww_diag[1], __builtin_amdgcn_s_memrealtime() - dr0);
+        atomicAdd(&g_ww_diag[2], (unsigned long long)n);
+        atomicAdd(&g_ww_diag[3], 1ull);
+    }
+#endif
     // ---- slab: plane i = w, [r][c][j]: lane (col c = 32*ch + r, rows acc_row(e, kh) + 32*rh) stores 16 bytes (j = 0..3)
     float* const plane = p.partial + (((size_t)split * 4 + w) * p.Rp + r0) * (size_t)p.Cp * 4;
 #pragma unroll
@@ -565,6 +620,14 @@ __global__ void __launch_bounds__(256) wino_wgrad_reduce_kernel(const WinoReduce
 }  // namespace clamd
 
 extern "C" {
+
+#ifdef CLAMD_DIAG
+int clamd_debug_ww_diag(unsigned long long* out4, int reset) {
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(clamd::g_ww_diag), 32) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[4] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(clamd::g_ww_diag), z, 32) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 size_t clamd_wgrad_winograd_workspace_bytes(int Rp, int Cp) {
     int nsplit = 256 / (((Rp + 63) / 64) * ((Cp + 63) / 64));
