@@ -1,0 +1,119 @@
+"""Data-parallel train step on the GPU with real kernels: two ranks share the ONE card of the test box
+and exchange gradients over gloo (RCCL refuses two ranks on one device; the driver's multi-GPU bench is the RCCL run).
+What is checked is everything around the collective — side-stream ordering of the per-stage all-reduces against the
+weight-gradient kernels before them and the Adam kernel after them, bucket coverage, the 1/world factor:
+
+* identical shards on both ranks: the summed gradient is exactly 2x the local one and (g + g) * 0.5 == g, so the DDP
+  run must reproduce a single-process run (first-step gradients and the loss sequence; compared to float-atomics
+  noise, not bit for bit: the BatchNorm statistics are accumulated with atomics in launch order);
+* different shards: replicas stay BIT-identical to each other (same summed gradient, element-wise Adam) and the loss of
+  every rank is finite.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(num_classes=5, conv_dim=8, size=64, batch=2, steps=3)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _train(model_dtype, shard, ddp):
+    """K train steps (trainer.py:172-176 order) on shard `shard`; returns (losses, flat parameter vector)."""
+    import continual_learning_amd as C
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(7)
+    model = C.UNet(CFG['num_classes'], 3, CFG['conv_dim'], compute_dtype=model_dtype).to(dev).train()
+    opt = C.FusedAdam(model.parameters(), lr=1e-3, betas=[0.5, 0.99])
+    crit = C.CrossEntropyLoss()
+    if ddp:
+        C.ddp.broadcast_parameters(model)
+        C.ddp.GradSync(model, opt, min_bucket_bytes=16 << 10)      # small buckets: several collectives per backward
+    b, s = CFG['batch'], CFG['size']
+    x = torch.from_numpy(C.synth.images(99, b, 3, s, s, first_image=shard * b)).to(dev)
+    y = torch.from_numpy(C.synth.labels(99, b, s, s, CFG['num_classes'], first_image=shard * b)).to(dev)
+    losses, grad0 = [], None
+    for i in range(CFG['steps']):
+        out = model(x)
+        opt.zero_grad()
+        loss = crit(out, y)
+        loss.backward()
+        if i == 0:
+            if ddp:
+                model.grad_sync.wait()                             # the optimiser's pre-step hook; idempotent
+            grad0 = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu()
+        opt.step()
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+    return losses, flat, grad0
+
+
+def _worker(rank, world, port, dtype, same_shard, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        losses, flat, grad0 = _train(dtype, 0 if same_shard else rank, ddp=True)
+        q.put((rank, losses, flat.numpy(), grad0.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_world2(dtype, same_shard):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, dtype, same_shard, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_ddp_identical_shards_reproduce_single_process(dtype):
+    ref_losses, _, ref_grad = _train(dtype, 0, ddp=False)
+    tol_g, tol_l = (1e-5, 1e-3) if dtype == "fp32" else (2e-2, 5e-2)
+    for rank, losses, _, grad0 in _run_world2(dtype, same_shard=True):
+        g = torch.from_numpy(grad0)
+        err = float((g - 2 * ref_grad).norm() / (2 * ref_grad).norm())
+        assert err < tol_g, f'rank {rank}: summed gradient is not 2x the local gradient (rel {err:.2e})'
+        assert losses == pytest.approx(ref_losses, rel=tol_l), f'rank {rank}: {losses} vs {ref_losses}'
+
+
+def test_ddp_replicas_stay_identical():
+    (r0, l0, f0, g0), (r1, l1, f1, g1) = _run_world2('fp32', same_shard=False)
+    assert (g0 == g1).all(), 'summed gradients differ between ranks'
+    assert (f0 == f1).all(), 'replicas diverged'
+    assert all(map(lambda v: v == v and abs(v) < 1e3, l0 + l1))
+    assert l0 != l1                                             # different shards, different local losses
+
+
+def test_rccl_single_rank_process_group():
+    """The RCCL ("nccl") code path itself — communicator creation on the device, all-reduce launches on the side stream
+    between our kernels — with the one rank a 1-GPU box allows: a world-1 sum is the identity, so the run must match the
+    plain single-process run."""
+    ref_losses, _, ref_grad = _train('fp32', 0, ddp=False)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        losses, _, grad0 = _train('fp32', 0, ddp=True)
+    finally:
+        dist.destroy_process_group()
+    err = float((grad0 - ref_grad).norm() / ref_grad.norm())
+    assert err < 1e-5, f'rel {err:.2e}'
+    assert losses == pytest.approx(ref_losses, rel=1e-3)
