@@ -96,11 +96,12 @@ def run(args, dtype, rank, world, device, timing=True):
         torch.cuda.synchronize()
         U.KERNEL_TIMING = None
     kern = {}
-    for tag, flops, e0, e1 in events:
-        k = kern.setdefault(tag, [0.0, 0.0, 0])
+    for tag, flops, e0, e1, nbytes in events:
+        k = kern.setdefault(tag, [0.0, 0.0, 0, 0.0])
         k[0] += e0.elapsed_time(e1) * 1e-3
         k[1] += flops
         k[2] += 1
+        k[3] += nbytes
     return dt, float(loss.detach()), kern
 
 
@@ -114,8 +115,9 @@ def pmc_traffic(dtype):
         return None
     d = json.load(open(files[-1]))
     tot, n = 0.0, 0
+    names = ('wino_kernel<',) if dtype == 'fp32' else ('igemm_ws_kernel<', 'igemm_pws_kernel<')
     for k, v in d['kernels'].items():
-        if (k.startswith('igemm_kernel<') and k.replace(' ', '').split(',')[1:3] == ['0', '0']) or k.startswith(('igemm_ws_kernel<', 'igemm_pws_kernel<')):
+        if (dtype != 'fp32' and k.startswith('igemm_kernel<') and k.replace(' ', '').split(',')[1:3] == ['0', '0']) or k.startswith(names):
             tot += (v['hbm_read_bytes_per_launch'] + v['hbm_write_bytes_per_launch']) * v['launches']
             n += v['launches']
     return round(tot / n) if n else None
@@ -157,7 +159,7 @@ def main():
     }
     if kern:
         # dominant kernel = the 3x3 implicit-GEMM (forward + data-gradient launches share one kernel template)
-        sec, flops, n = kern.get('igemm_conv3x3', (0, 0, 0))
+        sec, flops, n, nbytes = kern.get('igemm_conv3x3', (0, 0, 0, 0))
         if sec > 0:
             ach = flops / sec / 1e12
             traffic = pmc_traffic(args.dtype)
@@ -168,6 +170,7 @@ def main():
                                           'conv3x3 implicit GEMM, fwd + dgrad launches: clamd::igemm_pws_kernel<T,TW> (persistent, <= 256 input '
                                           'channels) and clamd::igemm_ws_kernel<T,TW,MT> (> 256 input channels)'),
                                'launches': n, 'avg_launch_ms': round(sec / n * 1e3, 4),
+                               'algorithmic_bytes_per_launch': round(nbytes / n),
                                'ms_per_step': round(sec / 2 * 1e3, 3),
                                'timing': 'HIP events around every launch, 2 instrumented steps after the timed region'}
             if args.dtype == 'fp32':
@@ -176,7 +179,7 @@ def main():
                 out['roofline']['frac_executed'] = round(ach * 16.0 / 36.0 / PEAK[args.dtype], 4)
                 out['roofline']['note'] = ('Winograd F(2x2,3x3): 16 MFMA multiply-adds per 2x2 output tile and channel pair instead of 36; '
                                            'frac = algorithmic FLOP/s / MFMA peak may exceed 1, frac_executed = MFMA pipe utilisation')
-        sec, flops, n = kern.get('wgrad_conv3x3', (0, 0, 0))
+        sec, flops, n, _ = kern.get('wgrad_conv3x3', (0, 0, 0, 0))
         if sec > 0:
             ach = flops / sec / 1e12
             out['roofline_wgrad'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK[args.dtype],
@@ -191,11 +194,11 @@ def main():
         o = {'dtype': DTYPE_NAME[other], 'value': round(v2, 2), 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
              'step_frac_of_mfma_peak': round(v2 * flop_img / 1e12 / (PEAK[other] * world), 4),
              'final_loss': round(loss2, 5)}
-        sec, flops, n = k2.get('igemm_conv3x3', (0, 0, 0))
+        sec, flops, n, _ = k2.get('igemm_conv3x3', (0, 0, 0, 0))
         if sec > 0:
             o['conv3x3_igemm_tflops'] = round(flops / sec / 1e12, 1)
             o['conv3x3_igemm_frac_of_peak'] = round(flops / sec / 1e12 / PEAK[other], 4)
-        sec, flops, n = k2.get('wgrad_conv3x3', (0, 0, 0))
+        sec, flops, n, _ = k2.get('wgrad_conv3x3', (0, 0, 0, 0))
         if sec > 0:
             o['conv3x3_wgrad_tflops'] = round(flops / sec / 1e12, 1)
         out.setdefault('also', []).append(o)

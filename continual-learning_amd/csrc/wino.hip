@@ -32,6 +32,7 @@ struct WinoParams {
     float* y; int y_ldc;
     float* stats;                // [STAT_REPLICAS][2][Np] or null
     int B, H, W, Kp, Np, relu;
+    int band;                    // output-channel slabs per band of the block order (see clamd_conv3x3_winograd)
 };
 
 constexpr int WN_HW = 18;                                     // input halo width of a 16-pixel-wide output tile
@@ -56,7 +57,11 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
     const int tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 8 * MT - 1) / (8 * MT);
     const int ntn = (p.Np + 63) >> 6;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = bid % ntn, tm = bid / ntn;
+    // block order [band of p.band slabs][pixel tile][slab in band]: the 32 workgroups resident on one XCD (contiguous
+    // ids after xcd_remap) cover (32 / band) pixel tiles x band slabs and share those input tiles and filter slabs in L2
+    const int per_band = (gridDim.x / ntn) * p.band;
+    const int bnd = bid / per_band, rem = bid - bnd * per_band;
+    const int tn = bnd * p.band + rem % p.band, tm = rem / p.band;
     const int x0 = (tm % tiles_x) * 16, y0 = ((tm / tiles_x) % tiles_y) * (8 * MT), b = tm / (tiles_x * tiles_y);
     const int n0 = tn * 64;
     const int nk = p.Kp >> 3;
@@ -323,6 +328,24 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const WinoPackJob* __res
 
 using namespace clamd;
 
+namespace clamd { int g_wino_band = 0; }   // tuning knob "wino_band": 0 = choose per launch, else forced (rounded down to a divisor of the slab count)
+
+// HBM traffic model of one launch: an XCD holds 32 workgroups at a time = a pixel tiles x b slabs (a * b = 32); every
+// such group fetches its a input tiles and b filter slabs once, so bytes ~ X * (slabs / b) + F * (tiles / a).  Measured
+// with b = all slabs (slab-fastest order): 553 MB for 1024 -> 1024 @ 16^2, where activations + filters are 88 MB.
+static int wino_band(long long tiles, long long slabs, double x_elems, double f_elems) {
+    int best = 1;
+    double best_cost = 0;
+    for (int b = 1; b <= 32 && b <= slabs; b *= 2) {
+        if (slabs % b) break;
+        const double a = 32.0 / b < (double)tiles ? 32.0 / b : (double)tiles;
+        const double cost = x_elems * ((double)slabs / b) + f_elems * ((double)tiles / a);
+        if (b == 1 || cost < best_cost) { best = b; best_cost = cost; }
+    }
+    if (g_wino_band > 0) { best = 1; while (best * 2 <= g_wino_band && slabs % (best * 2) == 0) best *= 2; }
+    return best;
+}
+
 extern "C" {
 
 int clamd_sizeof_wino_pack_job(void) { return (int)sizeof(WinoPackJob); }
@@ -340,12 +363,14 @@ int clamd_conv3x3_winograd(const float* x, int x_ldc, const float* w_wino, const
     if (Cin_p % 32 || Cout_p % 32 || x_ldc % 8 || y_ldc % 8) return clamd_fail("conv3x3_winograd: channel counts/pitches must be padded");
     if ((long long)H * W * x_ldc * 4 >= (1ll << 31) || (long long)16 * Cout_p * Cin_p * 4 >= (1ll << 31))
         return clamd_fail("conv3x3_winograd: image or filter exceeds 2^31 bytes");
-    WinoParams p{x, x_ldc, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu};
+    WinoParams p{x, x_ldc, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 1};
     const long long ntn = (Cout_p + 63) / 64, nblk2 = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ntn;
     const long long nblk1 = (long long)B * ((H + 7) / 8) * ((W + 15) / 16) * ntn;
     if (nblk1 > 0x7fffffff) return clamd_fail("conv3x3_winograd: grid out of range");
     // one workgroup per CU: 16x16-pixel tiles unless that grid would leave a quarter of the CUs without one
-    if (nblk2 >= 192 || nblk1 == nblk2) hipLaunchKernelGGL((wino_kernel<2>), dim3((unsigned)nblk2), dim3(256), 0, (hipStream_t)stream, p);
+    const bool mt2 = nblk2 >= 192 || nblk1 == nblk2;
+    p.band = wino_band((mt2 ? nblk2 : nblk1) / ntn, ntn, (double)B * H * W * Cin_p, 16.0 * Cin_p * Cout_p);
+    if (mt2) hipLaunchKernelGGL((wino_kernel<2>), dim3((unsigned)nblk2), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((wino_kernel<1>), dim3((unsigned)nblk1), dim3(256), 0, (hipStream_t)stream, p);
     return clamd_check_launch("conv3x3_winograd");
 }

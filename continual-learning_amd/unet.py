@@ -28,11 +28,12 @@ FUSE_BN_SUMS = 'auto'
 WINOGRAD = True
 
 # bench.py sets this to a list to get per-launch HIP-event timings of the MFMA kernels:
-# entries (tag, algorithmic_flops, start_event, end_event), recorded on the stream the kernel is launched on.
+# entries (tag, algorithmic_flops, start_event, end_event, algorithmic_bytes), recorded on the stream the kernel is
+# launched on.  Algorithmic bytes of a 3x3 convolution launch = both activations once + the filters once.
 KERNEL_TIMING = None
 
 
-def _timed(tag, flops, name, *args):
+def _timed(tag, flops, nbytes, name, *args):
     kt = KERNEL_TIMING
     if kt is None:
         call(name, *args)
@@ -41,7 +42,7 @@ def _timed(tag, flops, name, *args):
     e0.record()
     call(name, *args)
     e1.record()
-    kt.append((tag, flops, e0, e1))
+    kt.append((tag, flops, e0, e1, nbytes))
 
 
 def stage_table(num_classes, in_dim=3, conv_dim=64):
@@ -158,7 +159,7 @@ class _Engine:
         self.R = lib.clamd_stat_replicas()
         self.NS = lib.clamd_bn_bwd_nsums()
         self.generation = 0
-        self.esize = 4 if self.dcode == _lib.F32 else 2
+        self.esize = 2 if self.dcode == _lib.BF16 else 4      # activation element size in HBM (bf16x3 stores fp32)
         K, d = model.num_classes, model.conv_dim
         self.K, self.Kp = K, cpad(K)
         T = self.tdtype
@@ -389,6 +390,11 @@ class _Engine:
             torch._foreach_add_(self.nbts, 1)
         return logits
 
+    def _conv_bytes(self, u):
+        """Algorithmic HBM bytes of one 3x3 launch on unit u (forward, data gradient or weight gradient alike): input and
+        output activation once each, filters (or their gradient) once."""
+        return self.esize * (self.B * u.h * u.w_ * (u.cin + u.cout) + 9 * u.cin * u.cout)
+
     def _conv_fwd(self, u, training, s):
         B, dc = self.B, self.dcode
         v = u.vec
@@ -396,11 +402,11 @@ class _Engine:
             call('clamd_conv1x1', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
                  ptr(u.stats) if training else None, None, None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
         elif u.wino:
-            _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout,
+            _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
                    'clamd_conv3x3_winograd', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
                    ptr(u.stats) if training else None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, s)
         else:
-            _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout,
+            _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
                    'clamd_conv3x3', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
                    ptr(u.stats) if training else None, None, None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, u.m_fastest, dc, s)
         call('clamd_bn_finalize', ptr(u.stats) if training else None, ptr(u.gamma), ptr(u.beta), ptr(u.rm), ptr(u.rv),
@@ -486,19 +492,19 @@ class _Engine:
                  g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, 9 * u.cin, u.cout, u.cout_p, 9 * u.cin, u.cin_p, dc, s)
             return
         if u.wino:
-            _timed('wgrad_conv3x3', flops,
+            _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
                    'clamd_wgrad_winograd', ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
                    g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, s)
         else:
-            _timed('wgrad_conv3x3', flops,
+            _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
                    'clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
                    g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, dc, s)
         if u.g_in is not None and u.wino:
-            _timed('igemm_conv3x3', flops,
+            _timed('igemm_conv3x3', flops, self._conv_bytes(u),
                    'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
                    B, u.h, u.w_, u.cout_p, u.cin_p, 0, s)
         elif u.g_in is not None:
-            _timed('igemm_conv3x3', flops,
+            _timed('igemm_conv3x3', flops, self._conv_bytes(u),
                    'clamd_conv3x3', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
                    ptr(u.consumer.y) if u.consumer is not None else None,
                    ptr(u.consumer.sums) if u.consumer is not None else None,

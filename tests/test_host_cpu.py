@@ -82,7 +82,13 @@ def test_engine_geometry_and_pack_table(C):
     enc1b = [u for u in e.convs if u.name == 'enc1.3'][0]
     assert enc1b.out is e.cat[0] and enc1b.pooled is e.pool[0] and enc1b.out_ldc == 64
     jobs = e.pack_table.jobs
-    assert len(jobs) == 18 * 3 - 1 + 5 * 3            # wf + wd + bias per conv (no wd for enc1.0), 3 per tail
+    # wf + wd + bias per conv (no wd for enc1.0), 3 per tail; on the fp32 path the filters of the Winograd units
+    # (3x3, even images of at least 8x8: every unit here except enc1.0 (im2col) and the two 4x4 centre convs) are
+    # transformed by the Winograd pack table instead
+    wino_units = [u for u in e.convs if u.wino]
+    assert len(wino_units) == 15 and all(min(u.h, u.w_) >= 8 for u in wino_units)
+    assert len(e.wino_table.jobs) == 2 * len(wino_units)
+    assert len(jobs) + len(e.wino_table.jobs) == 18 * 3 - 1 + 5 * 3
     assert e.pack_table.nblocks == sum(((j[3] + 31) // 32) * ((j[4] + 31) // 32) for j in jobs)
     assert C.cpad(3) == 32 and C.cpad(21) == 32 and C.cpad(1024) == 1024
 
