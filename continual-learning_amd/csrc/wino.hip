@@ -20,6 +20,7 @@
 //   * epilogue: R[q] = sum_j A^T[q][j] M[w][j] locally, the sum over the four waves' rows through LDS, then bias, ReLU,
 //     BatchNorm statistics and 16-byte stores.
 #include <string.h>
+#include <algorithm>
 #include "common.hip.h"
 #include "clamd_internal.h"
 
@@ -33,6 +34,7 @@ struct WinoParams {
     float* stats;                // [STAT_REPLICAS][2][Np] or null
     int B, H, W, Kp, Np, relu;
     int band;                    // output-channel slabs per band of the block order (see clamd_conv3x3_winograd)
+    int nblk;                    // (pixel tile, slab) pairs; the grid is min(nblk, CUs) persistent workgroups
 };
 
 constexpr int WN_HW = 18;                                     // input halo width of a 16-pixel-wide output tile
@@ -49,223 +51,263 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
     constexpr int WN_IN_SLOTS = 2 * WN_PIXP, WN_STAGE = WN_IN_SLOTS + WN_WT_SLOTS;
     constexpr int NJI = (2 * WN_PIX + 255) / 256;                         // input staging loads per thread
     constexpr int NST = 2;                     // LDS stages: chunk k+1 readable, chunk k+2 being written (chunk k is in registers)
-    static_assert(4 * 2 * 32 * WN_EXP * 4 <= NST * WN_STAGE * 16 && NST * WN_STAGE * 16 <= 160 * 1024, "LDS budget");
-    __shared__ uint4 smem[NST * WN_STAGE];
+    constexpr int WN_EXB = 4 * 2 * 32 * WN_EXP;                           // floats of one (mt, nt) exchange block
+    constexpr int WN_LDS = (NST * WN_STAGE * 16 > 2 * MT * WN_EXB * 4 ? NST * WN_STAGE * 16 : 2 * MT * WN_EXB * 4) / 16;
+    static_assert(WN_LDS * 16 <= 160 * 1024, "LDS budget");
+    __shared__ uint4 smem[WN_LDS];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 8 * MT - 1) / (8 * MT);
-    const int ntn = (p.Np + 63) >> 6;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    // block order [band of p.band slabs][pixel tile][slab in band]: the 32 workgroups resident on one XCD (contiguous
-    // ids after xcd_remap) cover (32 / band) pixel tiles x band slabs and share those input tiles and filter slabs in L2
-    const int per_band = (gridDim.x / ntn) * p.band;
-    const int bnd = bid / per_band, rem = bid - bnd * per_band;
-    const int tn = bnd * p.band + rem % p.band, tm = rem / p.band;
-    const int x0 = (tm % tiles_x) * 16, y0 = ((tm / tiles_x) % tiles_y) * (8 * MT), b = tm / (tiles_x * tiles_y);
-    const int n0 = tn * 64;
-    const int nk = p.Kp >> 3;
+    // Persistent: workgroup g walks the tiles g, g + grid, ... (same XCD every round).  The output stores and statistics
+    // atomics of a tile drain while the next tile is loaded and multiplied; a workgroup per tile instead waits for its
+    // last store to be acknowledged before the CU can start the next one (measured: 3 us of 30 per 64-channel tile).
+    for (int v = blockIdx.x; v < p.nblk; v += gridDim.x) {
+        // everything below is re-derived per tile from an opaque copy of the thread id: hoisted out of the tile loop the
+        // per-lane constants would stay live through the MFMA loop and spill (344 bytes per lane, measured)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, w = tid >> 6;
+        const int r = lane & 31, h = lane >> 5;
+        const int tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 8 * MT - 1) / (8 * MT);
+        const int ntn = (p.Np + 63) >> 6;
+        const int bid = xcd_remap(v, p.nblk);
+        // block order [band of p.band slabs][pixel tile][slab in band]: the 32 workgroups resident on one XCD (contiguous
+        // ids after xcd_remap) cover (32 / band) pixel tiles x band slabs and share those input tiles and filter slabs in L2
+        const int per_band = (p.nblk / ntn) * p.band;
+        const int bnd = bid / per_band, rem = bid - bnd * per_band;
+        const int tn = bnd * p.band + rem % p.band, tm = rem / p.band;
+        const int x0 = (tm % tiles_x) * 16, y0 = ((tm / tiles_x) % tiles_y) * (8 * MT), b = tm / (tiles_x * tiles_y);
+        const int n0 = tn * 64;
+        const int nk = p.Kp >> 3;
 
-    // ---- staging descriptors --------------------------------------------------------------------------------------
-    const unsigned img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc * 4u;
-    const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x + (size_t)b * img, img);
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.w, (unsigned)(16u * p.Np * p.Kp * 4u));
-    unsigned in_vo[NJI];
-    int in_slot[NJI];
-#pragma unroll
-    for (int j = 0; j < NJI; ++j) {
-        int piece = tid + 256 * j;                           // (pixel, 16-byte group); the last pass wraps
-        if (piece >= 2 * WN_PIX) piece -= 2 * WN_PIX;
-        const int g = piece & 1, pix = piece >> 1;
-        const int hy = pix / WN_HW, hx = pix - hy * WN_HW;
-        const int yy = y0 + hy - 1, xx = x0 + hx - 1;
-        in_vo[j] = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? (unsigned)(((yy * p.W + xx) * p.x_ldc + 4 * g) * 4) : BUF_OOB;
-        in_slot[j] = g * WN_PIXP + pix;
-    }
-    // filter slab of one K-chunk: 16 xi x 64 rows x 2 groups = 2048 pieces, piece = tid + 256*j: xi = (tid >> 7) + 2j
-    const int wg_ = tid & 1, wn_ = (tid >> 1) & 63, wxi0 = tid >> 7;
-    const unsigned w_vo0 = n0 + wn_ < p.Np ? (unsigned)(((wxi0 * p.Np + n0 + wn_) * 8 + 4 * wg_) * 4) : BUF_OOB;
-    const unsigned w_vstep = (unsigned)(2 * p.Np * 8 * 4);    // two xi further
-    const unsigned w_chunk = (unsigned)(16 * p.Np * 8 * 4);   // bytes of one K-chunk
-    const int w_slot0 = WN_IN_SLOTS + (wxi0 * 2 + wg_) * WN_WG + wn_;
+        // ---- staging descriptors --------------------------------------------------------------------------------------
+        const unsigned img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc * 4u;
+        const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x + (size_t)b * img, img);
+        const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.w, (unsigned)(16u * p.Np * p.Kp * 4u));
+        unsigned in_vo[NJI];
+        int in_slot[NJI];
+    #pragma unroll
+        for (int j = 0; j < NJI; ++j) {
+            int piece = tid + 256 * j;                           // (pixel, 16-byte group); the last pass wraps
+            if (piece >= 2 * WN_PIX) piece -= 2 * WN_PIX;
+            const int g = piece & 1, pix = piece >> 1;
+            const int hy = pix / WN_HW, hx = pix - hy * WN_HW;
+            const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+            in_vo[j] = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? (unsigned)(((yy * p.W + xx) * p.x_ldc + 4 * g) * 4) : BUF_OOB;
+            in_slot[j] = g * WN_PIXP + pix;
+        }
+        // filter slab of one K-chunk: 16 xi x 64 rows x 2 groups = 2048 pieces, piece = tid + 256*j: xi = (tid >> 7) + 2j
+        const int wg_ = tid & 1, wn_ = (tid >> 1) & 63, wxi0 = tid >> 7;
+        const unsigned w_vo0 = n0 + wn_ < p.Np ? (unsigned)(((wxi0 * p.Np + n0 + wn_) * 8 + 4 * wg_) * 4) : BUF_OOB;
+        const unsigned w_vstep = (unsigned)(2 * p.Np * 8 * 4);    // two xi further
+        const unsigned w_chunk = (unsigned)(16 * p.Np * 8 * 4);   // bytes of one K-chunk
+        const int w_slot0 = WN_IN_SLOTS + (wxi0 * 2 + wg_) * WN_WG + wn_;
 
-    uint4 rin[NJI], rw[8];
-    auto gload_to = [&](int k, bool live, uint4 (&ri)[NJI], uint4 (&rww)[8]) {
-        const unsigned so = (unsigned)(k * 8 * 4);
-#pragma unroll
-        for (int j = 0; j < NJI; ++j) ri[j] = buf_ld16(xrs, live ? in_vo[j] : BUF_OOB, so);
-        const unsigned wv = live ? w_vo0 : BUF_OOB;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rww[j] = buf_ld16(wrs, wv + j * w_vstep, (unsigned)k * w_chunk);
-    };
-    auto lds_store_from = [&](int st, const uint4 (&ri)[NJI], const uint4 (&rww)[8]) {
-        uint4* sm = smem + st * WN_STAGE;
-#pragma unroll
-        for (int j = 0; j < NJI; ++j) sm[in_slot[j]] = ri[j];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sm[w_slot0 + j * 4 * WN_WG] = rww[j];
-    };
-    auto gload = [&](int k, bool live) { gload_to(k, live, rin, rw); };
-    auto lds_store = [&](int st) { lds_store_from(st, rin, rw); };
+        uint4 rin[NJI], rw[8];
+        auto gload_to = [&](int k, bool live, uint4 (&ri)[NJI], uint4 (&rww)[8]) {
+            const unsigned so = (unsigned)(k * 8 * 4);
+    #pragma unroll
+            for (int j = 0; j < NJI; ++j) ri[j] = buf_ld16(xrs, live ? in_vo[j] : BUF_OOB, so);
+            const unsigned wv = live ? w_vo0 : BUF_OOB;
+    #pragma unroll
+            for (int j = 0; j < 8; ++j) rww[j] = buf_ld16(wrs, wv + j * w_vstep, (unsigned)k * w_chunk);
+        };
+        auto lds_store_from = [&](int st, const uint4 (&ri)[NJI], const uint4 (&rww)[8]) {
+            uint4* sm = smem + st * WN_STAGE;
+    #pragma unroll
+            for (int j = 0; j < NJI; ++j) sm[in_slot[j]] = ri[j];
+    #pragma unroll
+            for (int j = 0; j < 8; ++j) sm[w_slot0 + j * 4 * WN_WG] = rww[j];
+        };
+        auto gload = [&](int k, bool live) { gload_to(k, live, rin, rw); };
+        auto lds_store = [&](int st) { lds_store_from(st, rin, rw); };
 
-    // ---- fragment addressing: wave w = Winograd row i: t[b] = s1 * d[a1][b] + s2 * d[a2][b] ------------------------
-    const int a1 = w == 0 ? 0 : 1, a2 = w == 3 ? 3 : 2;
-    const float s1 = w == 2 ? -1.f : 1.f, s2 = (w == 0 || w == 3) ? -1.f : 1.f;
-    int p1[MT], p2[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = 32 * mt + r, ty = m >> 3, tx = m & 7;
-        const int pb = h * WN_PIXP + (2 * ty) * WN_HW + 2 * tx;
-        p1[mt] = pb + a1 * WN_HW;
-        p2[mt] = pb + a2 * WN_HW;
-    }
-    const int wb = WN_IN_SLOTS + (4 * w * 2 + h) * WN_WG + r;            // + j*2*WG + 32*nt
-
-    f32x16 acc[4][MT][2];                                                 // [j][tile half][channel half]
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 2 * MT; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][i >> 1][i & 1][e] = 0.f;
-
-    // fragments of one chunk: the input transform V[w][j] for both tile halves + the filter rows of this wave's 4 xi
-    uint4 A[4][MT], Bf[4][2];
-    auto frags = [&](int st) {
-        const uint4* sm = smem + st * WN_STAGE;
-#pragma unroll
+        // ---- fragment addressing: wave w = Winograd row i: t[b] = s1 * d[a1][b] + s2 * d[a2][b] ------------------------
+        const int a1 = w == 0 ? 0 : 1, a2 = w == 3 ? 3 : 2;
+        const float s1 = w == 2 ? -1.f : 1.f, s2 = (w == 0 || w == 3) ? -1.f : 1.f;
+        int p1[MT], p2[MT];
+    #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            float4 t[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint4 u1 = sm[p1[mt] + c], u2 = sm[p2[mt] + c];
-                t[c].x = fmaf(s2, __uint_as_float(u2.x), s1 * __uint_as_float(u1.x));
-                t[c].y = fmaf(s2, __uint_as_float(u2.y), s1 * __uint_as_float(u1.y));
-                t[c].z = fmaf(s2, __uint_as_float(u2.z), s1 * __uint_as_float(u1.z));
-                t[c].w = fmaf(s2, __uint_as_float(u2.w), s1 * __uint_as_float(u1.w));
-            }
-#define WN_PK(v_) make_uint4(__float_as_uint((v_).x), __float_as_uint((v_).y), __float_as_uint((v_).z), __float_as_uint((v_).w))
-            A[0][mt] = WN_PK(make_float4(t[0].x - t[2].x, t[0].y - t[2].y, t[0].z - t[2].z, t[0].w - t[2].w));
-            A[1][mt] = WN_PK(make_float4(t[1].x + t[2].x, t[1].y + t[2].y, t[1].z + t[2].z, t[1].w + t[2].w));
-            A[2][mt] = WN_PK(make_float4(t[2].x - t[1].x, t[2].y - t[1].y, t[2].z - t[1].z, t[2].w - t[1].w));
-            A[3][mt] = WN_PK(make_float4(t[1].x - t[3].x, t[1].y - t[3].y, t[1].z - t[3].z, t[1].w - t[3].w));
-#undef WN_PK
+            const int m = 32 * mt + r, ty = m >> 3, tx = m & 7;
+            const int pb = h * WN_PIXP + (2 * ty) * WN_HW + 2 * tx;
+            p1[mt] = pb + a1 * WN_HW;
+            p2[mt] = pb + a2 * WN_HW;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) Bf[j][nt] = sm[wb + j * 2 * WN_WG + 32 * nt];
-    };
+        const int wb = WN_IN_SLOTS + (4 * w * 2 + h) * WN_WG + r;            // + j*2*WG + 32*nt
 
-    // Pipeline (one wave per SIMD, nothing else hides a stall): while the MFMAs of chunk k run from registers, the
-    // fragments of chunk k+1 are read from LDS and transformed, the raw data of chunk k+2 (loaded one chunk ago) is
-    // written to the third stage and the loads of chunk k+3 are issued.  One barrier per chunk.
-    {   // prologue: the first three chunks are requested back to back (one memory latency, not three)
-        uint4 ri0[NJI], rw0[8], ri1[NJI], rw1[8];
-        gload_to(0, true, ri0, rw0);
-        gload_to(1, 1 < nk, ri1, rw1);
-        gload(2, 2 < nk);
-        lds_store_from(0, ri0, rw0);
-        lds_store_from(1, ri1, rw1);
-    }
-    __syncthreads();
-    frags(0);
-    __syncthreads();                                                      // stage 0 is free again
-    for (int k = 0; k < nk; ++k) {
-        uint4 Ac[4][MT], Bc[4][2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) Ac[j][i] = A[j][i];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) Bc[j][i] = Bf[j][i];
-        }
-        // straight-line body (past the last chunk the reads hit valid LDS and the stores write zeros nobody reads), so
-        // that the 24 fragment reads, ~130 transform VALU ops, 11 staging stores and 11 loads can be issued in the gaps
-        // of the 64 MFMAs instead of in front of them
-        frags((k + 1) % NST);                                             // visible since the last barrier
-#pragma unroll
+        f32x16 acc[4][MT][2];                                                 // [j][tile half][channel half]
+    #pragma unroll
         for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) mma16<float>(Ac[j][mt], Bc[j][nt], acc[j][mt][nt]);
-        lds_store(k % NST);                                               // chunk k+2 over chunk k's stage (read before the last barrier)
-        gload(k + 3, k + 3 < nk);
-        if constexpr (MT == 2) sched_mfma_slots<64, 24, 26, 37, 38, 49, 2>();
-        else sched_mfma_slots<32, 16, 17, 27, 21, 31, 2>();
+    #pragma unroll
+            for (int i = 0; i < 2 * MT; ++i)
+    #pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][i >> 1][i & 1][e] = 0.f;
+
+        // fragments of one chunk: the input transform V[w][j] for both tile halves + the filter rows of this wave's 4 xi
+        uint4 A[4][MT], Bf[4][2];
+        auto frags = [&](int st) {
+            const uint4* sm = smem + st * WN_STAGE;
+    #pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float4 t[4];
+    #pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint4 u1 = sm[p1[mt] + c], u2 = sm[p2[mt] + c];
+                    t[c].x = fmaf(s2, __uint_as_float(u2.x), s1 * __uint_as_float(u1.x));
+                    t[c].y = fmaf(s2, __uint_as_float(u2.y), s1 * __uint_as_float(u1.y));
+                    t[c].z = fmaf(s2, __uint_as_float(u2.z), s1 * __uint_as_float(u1.z));
+                    t[c].w = fmaf(s2, __uint_as_float(u2.w), s1 * __uint_as_float(u1.w));
+                }
+    #define WN_PK(v_) make_uint4(__float_as_uint((v_).x), __float_as_uint((v_).y), __float_as_uint((v_).z), __float_as_uint((v_).w))
+                A[0][mt] = WN_PK(make_float4(t[0].x - t[2].x, t[0].y - t[2].y, t[0].z - t[2].z, t[0].w - t[2].w));
+                A[1][mt] = WN_PK(make_float4(t[1].x + t[2].x, t[1].y + t[2].y, t[1].z + t[2].z, t[1].w + t[2].w));
+                A[2][mt] = WN_PK(make_float4(t[2].x - t[1].x, t[2].y - t[1].y, t[2].z - t[1].z, t[2].w - t[1].w));
+                A[3][mt] = WN_PK(make_float4(t[1].x - t[3].x, t[1].y - t[3].y, t[1].z - t[3].z, t[1].w - t[3].w));
+    #undef WN_PK
+            }
+    #pragma unroll
+            for (int j = 0; j < 4; ++j)
+    #pragma unroll
+                for (int nt = 0; nt < 2; ++nt) Bf[j][nt] = sm[wb + j * 2 * WN_WG + 32 * nt];
+        };
+
+        // Pipeline (one wave per SIMD, nothing else hides a stall): while the MFMAs of chunk k run from registers, the
+        // fragments of chunk k+1 are read from LDS and transformed, the raw data of chunk k+2 (loaded one chunk ago) is
+        // written to the third stage and the loads of chunk k+3 are issued.  One barrier per chunk.
+        {   // prologue: the first three chunks are requested back to back (one memory latency, not three)
+            uint4 ri0[NJI], rw0[8], ri1[NJI], rw1[8];
+            gload_to(0, true, ri0, rw0);
+            gload_to(1, 1 < nk, ri1, rw1);
+            gload(2, 2 < nk);
+            lds_store_from(0, ri0, rw0);
+            lds_store_from(1, ri1, rw1);
+        }
         __syncthreads();
-    }
-
-    // ---- epilogue: output transform Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]] -------------------------------------
-    float* const ex = reinterpret_cast<float*>(smem);                     // [wave][q][32 tiles][WN_EXP]
-    const int tl = tid >> 3, ng = tid & 7;                                // reader: tile inside the half, 4-channel group
-    float st1[2][4], st2[2][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { st1[i >> 2][i & 3] = 0.f; st2[i >> 2][i & 3] = 0.f; }
-    const float relu_lo = p.relu ? 0.f : -__builtin_inff();
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float m0 = acc[0][mt][nt][e], m1 = acc[1][mt][nt][e], m2 = acc[2][mt][nt][e], m3 = acc[3][mt][nt][e];
-                ex[((w * 2 + 0) * 32 + acc_row(e, h)) * WN_EXP + r] = m0 + m1 + m2;
-                ex[((w * 2 + 1) * 32 + acc_row(e, h)) * WN_EXP + r] = m1 - m2 - m3;
+        frags(0);
+        __syncthreads();                                                      // stage 0 is free again
+        for (int k = 0; k < nk; ++k) {
+            uint4 Ac[4][MT], Bc[4][2];
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+    #pragma unroll
+                for (int i = 0; i < MT; ++i) Ac[j][i] = A[j][i];
+    #pragma unroll
+                for (int i = 0; i < 2; ++i) Bc[j][i] = Bf[j][i];
             }
+            // straight-line body (past the last chunk the reads hit valid LDS and the stores write zeros nobody reads), so
+            // that the 24 fragment reads, ~130 transform VALU ops, 11 staging stores and 11 loads can be issued in the gaps
+            // of the 64 MFMAs instead of in front of them
+            frags((k + 1) % NST);                                             // visible since the last barrier
+    #pragma unroll
+            for (int j = 0; j < 4; ++j)
+    #pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+    #pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) mma16<float>(Ac[j][mt], Bc[j][nt], acc[j][mt][nt]);
+            lds_store(k % NST);                                               // chunk k+2 over chunk k's stage (read before the last barrier)
+            gload(k + 3, k + 3 < nk);
+            if constexpr (MT == 2) sched_mfma_slots<64, 24, 26, 37, 38, 49, 2>();
+            else sched_mfma_slots<32, 16, 17, 27, 21, 31, 2>();
             __syncthreads();
-            float4 R[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) R[i][q] = *reinterpret_cast<const float4*>(ex + ((i * 2 + q) * 32 + tl) * WN_EXP + 4 * ng);
-            const int m = 32 * mt + tl, ty = m >> 3, tx = m & 7;
-            const int n = n0 + 32 * nt + 4 * ng;
-            float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias && n < p.Np) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
-#pragma unroll
-            for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    float4 v;
-                    if (pp == 0) {
-                        v.x = R[0][q].x + R[1][q].x + R[2][q].x; v.y = R[0][q].y + R[1][q].y + R[2][q].y;
-                        v.z = R[0][q].z + R[1][q].z + R[2][q].z; v.w = R[0][q].w + R[1][q].w + R[2][q].w;
-                    } else {
-                        v.x = R[1][q].x - R[2][q].x - R[3][q].x; v.y = R[1][q].y - R[2][q].y - R[3][q].y;
-                        v.z = R[1][q].z - R[2][q].z - R[3][q].z; v.w = R[1][q].w - R[2][q].w - R[3][q].w;
+        }
+
+    #ifdef WN_ABLATE_EPI   // measurement only: no output transform / stores (keeps the accumulators alive)
+        {
+            float t = 0.f;
+    #pragma unroll
+            for (int j = 0; j < 4; ++j)
+    #pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+    #pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+    #pragma unroll
+                        for (int e = 0; e < 16; ++e) t += acc[j][mt][nt][e];
+            if (t == 12345.678f) p.y[0] = t;
+            return;
+        }
+    #endif
+        // ---- epilogue: output transform Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]] -------------------------------------
+        // All 2*MT (mt, nt) blocks are exchanged at once ([block][wave][q][32 tiles][WN_EXP], 144 KB for MT = 2): one
+        // barrier per tile instead of two per block, and the 128 scalar LDS writes of a lane go out back to back (the
+        // per-block version cost 21 % of the 64 -> 64 @ 256^2 launch, measured by ablation).
+        float* const ex = reinterpret_cast<float*>(smem);
+        const int tl = tid >> 3, ng = tid & 7;                                // reader: tile inside the half, 4-channel group
+        float st1[2][4], st2[2][4];
+    #pragma unroll
+        for (int i = 0; i < 8; ++i) { st1[i >> 2][i & 3] = 0.f; st2[i >> 2][i & 3] = 0.f; }
+        const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+    #pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+    #pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float* const exb = ex + (mt * 2 + nt) * WN_EXB;
+    #pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float m0 = acc[0][mt][nt][e], m1 = acc[1][mt][nt][e], m2 = acc[2][mt][nt][e], m3 = acc[3][mt][nt][e];
+                    exb[((w * 2 + 0) * 32 + acc_row(e, h)) * WN_EXP + r] = m0 + m1 + m2;
+                    exb[((w * 2 + 1) * 32 + acc_row(e, h)) * WN_EXP + r] = m1 - m2 - m3;
+                }
+            }
+        __syncthreads();
+    #pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+    #pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float* const exb = ex + (mt * 2 + nt) * WN_EXB;
+                float4 R[4][2];
+    #pragma unroll
+                for (int i = 0; i < 4; ++i)
+    #pragma unroll
+                    for (int q = 0; q < 2; ++q) R[i][q] = *reinterpret_cast<const float4*>(exb + ((i * 2 + q) * 32 + tl) * WN_EXP + 4 * ng);
+                const int m = 32 * mt + tl, ty = m >> 3, tx = m & 7;
+                const int n = n0 + 32 * nt + 4 * ng;
+                float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias && n < p.Np) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+    #pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+    #pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float4 v;
+                        if (pp == 0) {
+                            v.x = R[0][q].x + R[1][q].x + R[2][q].x; v.y = R[0][q].y + R[1][q].y + R[2][q].y;
+                            v.z = R[0][q].z + R[1][q].z + R[2][q].z; v.w = R[0][q].w + R[1][q].w + R[2][q].w;
+                        } else {
+                            v.x = R[1][q].x - R[2][q].x - R[3][q].x; v.y = R[1][q].y - R[2][q].y - R[3][q].y;
+                            v.z = R[1][q].z - R[2][q].z - R[3][q].z; v.w = R[1][q].w - R[2][q].w - R[3][q].w;
+                        }
+                        v.x = fmaxf(v.x + bias4.x, relu_lo); v.y = fmaxf(v.y + bias4.y, relu_lo);
+                        v.z = fmaxf(v.z + bias4.z, relu_lo); v.w = fmaxf(v.w + bias4.w, relu_lo);
+                        const int yy = y0 + 2 * ty + pp, xx = x0 + 2 * tx + q;
+                        if (yy < p.H && xx < p.W && n < p.Np) {
+    #ifndef WN_ABLATE_ST
+                            *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = v;
+    #endif
+                            st1[nt][0] += v.x; st1[nt][1] += v.y; st1[nt][2] += v.z; st1[nt][3] += v.w;
+                            st2[nt][0] = fmaf(v.x, v.x, st2[nt][0]); st2[nt][1] = fmaf(v.y, v.y, st2[nt][1]);
+                            st2[nt][2] = fmaf(v.z, v.z, st2[nt][2]); st2[nt][3] = fmaf(v.w, v.w, st2[nt][3]);
+                        }
                     }
-                    v.x = fmaxf(v.x + bias4.x, relu_lo); v.y = fmaxf(v.y + bias4.y, relu_lo);
-                    v.z = fmaxf(v.z + bias4.z, relu_lo); v.w = fmaxf(v.w + bias4.w, relu_lo);
-                    const int yy = y0 + 2 * ty + pp, xx = x0 + 2 * tx + q;
-                    if (yy < p.H && xx < p.W && n < p.Np) {
-                        *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = v;
-                        st1[nt][0] += v.x; st1[nt][1] += v.y; st1[nt][2] += v.z; st1[nt][3] += v.w;
-                        st2[nt][0] = fmaf(v.x, v.x, st2[nt][0]); st2[nt][1] = fmaf(v.y, v.y, st2[nt][1]);
-                        st2[nt][2] = fmaf(v.z, v.z, st2[nt][2]); st2[nt][3] = fmaf(v.w, v.w, st2[nt][3]);
-                    }
+            }
+        if (p.stats) {
+            // threads with equal (tid & 7) own the same channels: fold the 8 tiles of a wave (lane bits 3-5), then the 4 waves
+            __syncthreads();                                                   // every wave has read its exchange blocks
+            float* sb = ex;                                                    // [wave][2][64]
+    #pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+    #pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float a = st1[nt][c], q = st2[nt][c];
+                    a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+                    q += __shfl_xor(q, 8); q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+                    if (lane < 8) { sb[(w * 2 + 0) * 64 + 32 * nt + 4 * lane + c] = a; sb[(w * 2 + 1) * 64 + 32 * nt + 4 * lane + c] = q; }
                 }
             __syncthreads();
-        }
-    if (p.stats) {
-        // threads with equal (tid & 7) own the same channels: fold the 8 tiles of a wave (lane bits 3-5), then the 4 waves
-        float* sb = ex;                                                    // [wave][2][64]
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float a = st1[nt][c], q = st2[nt][c];
-                a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
-                q += __shfl_xor(q, 8); q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-                if (lane < 8) { sb[(w * 2 + 0) * 64 + 32 * nt + 4 * lane + c] = a; sb[(w * 2 + 1) * 64 + 32 * nt + 4 * lane + c] = q; }
+            if (tid < 128) {
+                const int k = tid >> 6, c = tid & 63;
+                const float t = sb[(0 * 2 + k) * 64 + c] + sb[(1 * 2 + k) * 64 + c] + sb[(2 * 2 + k) * 64 + c] + sb[(3 * 2 + k) * 64 + c];
+                if (n0 + c < p.Np) atomicAdd(p.stats + ((size_t)(v % STAT_REPLICAS) * 2 + k) * p.Np + n0 + c, t);
             }
-        __syncthreads();
-        if (tid < 128) {
-            const int k = tid >> 6, c = tid & 63;
-            const float t = sb[(0 * 2 + k) * 64 + c] + sb[(1 * 2 + k) * 64 + c] + sb[(2 * 2 + k) * 64 + c] + sb[(3 * 2 + k) * 64 + c];
-            if (n0 + c < p.Np) atomicAdd(p.stats + ((size_t)(blockIdx.x % STAT_REPLICAS) * 2 + k) * p.Np + n0 + c, t);
         }
+
+        __syncthreads();                                                   // exchange / statistics blocks are free again
     }
 }
 
@@ -328,7 +370,17 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const WinoPackJob* __res
 
 using namespace clamd;
 
-namespace clamd { int g_wino_band = 0; }   // tuning knob "wino_band": 0 = choose per launch, else forced (rounded down to a divisor of the slab count)
+namespace clamd { int g_wino_band = 0; int g_wino_persist = 1; }
+
+static int clamd_num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
+}   // tuning knob "wino_band": 0 = choose per launch, else forced (rounded down to a divisor of the slab count)
 
 // HBM traffic model of one launch: an XCD holds 32 workgroups at a time = a pixel tiles x b slabs (a * b = 32); every
 // such group fetches its a input tiles and b filter slabs once, so bytes ~ X * (slabs / b) + F * (tiles / a).  Measured
@@ -363,15 +415,17 @@ int clamd_conv3x3_winograd(const float* x, int x_ldc, const float* w_wino, const
     if (Cin_p % 32 || Cout_p % 32 || x_ldc % 8 || y_ldc % 8) return clamd_fail("conv3x3_winograd: channel counts/pitches must be padded");
     if ((long long)H * W * x_ldc * 4 >= (1ll << 31) || (long long)16 * Cout_p * Cin_p * 4 >= (1ll << 31))
         return clamd_fail("conv3x3_winograd: image or filter exceeds 2^31 bytes");
-    WinoParams p{x, x_ldc, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 1};
+    WinoParams p{x, x_ldc, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 1, 0};
     const long long ntn = (Cout_p + 63) / 64, nblk2 = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ntn;
     const long long nblk1 = (long long)B * ((H + 7) / 8) * ((W + 15) / 16) * ntn;
     if (nblk1 > 0x7fffffff) return clamd_fail("conv3x3_winograd: grid out of range");
     // one workgroup per CU: 16x16-pixel tiles unless that grid would leave a quarter of the CUs without one
     const bool mt2 = nblk2 >= 192 || nblk1 == nblk2;
     p.band = wino_band((mt2 ? nblk2 : nblk1) / ntn, ntn, (double)B * H * W * Cin_p, 16.0 * Cin_p * Cout_p);
-    if (mt2) hipLaunchKernelGGL((wino_kernel<2>), dim3((unsigned)nblk2), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((wino_kernel<1>), dim3((unsigned)nblk1), dim3(256), 0, (hipStream_t)stream, p);
+    p.nblk = (int)(mt2 ? nblk2 : nblk1);
+    const unsigned grid = g_wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_num_cus()) : (unsigned)p.nblk;
+    if (mt2) hipLaunchKernelGGL((wino_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((wino_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     return clamd_check_launch("conv3x3_winograd");
 }
 

@@ -11,6 +11,8 @@ layers = [(64, 64, 256), (128, 64, 256), (64, 128, 128), (128, 128, 128), (256, 
 if os.environ.get('CONV_LAYERS'):
     layers = [tuple(int(v) for v in l.split(',')) for l in os.environ['CONV_LAYERS'].split(';')]
 s = C._lib.stream_ptr()
+for kv in filter(None, os.environ.get('TUNING', '').split(',')):        # TUNING=wino_stagger=32,wino_band=0
+    k, v = kv.split('='); C._lib.load().clamd_set_tuning(k.encode(), int(v))
 tot = [0.0, 0.0, 0.0]
 for cin, cout, hw in layers:
     x = torch.randn(B, hw, hw, cin, device='cuda')
