@@ -420,6 +420,7 @@ extern int g_wgrad_ws;
 extern int g_wgrad_xcd;
 extern int g_wino_band;
 extern int g_wino_persist;
+extern int g_wino_mt;
 extern int g_wgrad_dma;
 static int g_igemm_variant = 0;
 static int g_igemm_pws = 1;        // persistent producer/consumer kernel: 1 = short-K layers (<= 256 input channels), 2 = every layer, 0 = never
@@ -492,6 +493,7 @@ int clamd_set_tuning(const char* key, int value) {
     if (!strcmp(key, "wgrad_xcd")) { g_wgrad_xcd = value; return 0; }
     if (!strcmp(key, "wino_band")) { g_wino_band = value; return 0; }
     if (!strcmp(key, "wino_persist")) { g_wino_persist = value; return 0; }
+    if (!strcmp(key, "wino_mt")) { g_wino_mt = value; return 0; }
     if (!strcmp(key, "wgrad_dma")) { g_wgrad_dma = value; return 0; }
     if (!strcmp(key, "wgrad_blocks")) { if (value < 1 || value > 512) return clamd_fail("wgrad_blocks: 1..512"); g_wgrad_target_blocks = value; return 0; }
     return clamd_fail("set_tuning: unknown key");

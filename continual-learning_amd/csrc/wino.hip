@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const WinoPackJob* __res
 
 using namespace clamd;
 
-namespace clamd { int g_wino_band = 0; int g_wino_persist = 1; }
+namespace clamd { int g_wino_band = 0; int g_wino_persist = 1; int g_wino_mt = 0; }
 
 static int clamd_num_cus() {
     static int cus = 0;
@@ -420,7 +420,7 @@ int clamd_conv3x3_winograd(const float* x, int x_ldc, const float* w_wino, const
     const long long nblk1 = (long long)B * ((H + 7) / 8) * ((W + 15) / 16) * ntn;
     if (nblk1 > 0x7fffffff) return clamd_fail("conv3x3_winograd: grid out of range");
     // one workgroup per CU: 16x16-pixel tiles unless that grid would leave a quarter of the CUs without one
-    const bool mt2 = nblk2 >= 192 || nblk1 == nblk2;
+    const bool mt2 = g_wino_mt ? g_wino_mt == 2 : (nblk2 >= 192 || nblk1 == nblk2);
     p.band = wino_band((mt2 ? nblk2 : nblk1) / ntn, ntn, (double)B * H * W * Cin_p, 16.0 * Cin_p * Cout_p);
     p.nblk = (int)(mt2 ? nblk2 : nblk1);
     const unsigned grid = g_wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_num_cus()) : (unsigned)p.nblk;
