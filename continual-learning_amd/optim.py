@@ -96,6 +96,22 @@ class FusedAdam(torch.optim.Optimizer):
         """lam * sum ||theta - theta_old||^2 as accumulated by the LAST step (device scalar)."""
         return self._l2acc * self._l2_lambda
 
+    def sync_hyper(self):
+        """Upload lr / betas / eps / gradient scale / L2 weight to device memory if they changed on the host (LambdaLR
+        writes param_groups[0]['lr']).  step() calls this; a replayed HIP graph of the step (graph.GraphedStep) calls it
+        before every replay, because the captured Adam kernel reads the values from that device buffer."""
+        group = self.param_groups[0]
+        hyper = (float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
+                 float(self.grad_scale), float(self._l2_lambda), 0.0, 0.0)
+        if hyper != self._hyper_host:
+            self._hyper.copy_(torch.tensor(hyper, dtype=torch.float32))
+            self._hyper_host = hyper
+
+    def note_replayed_step(self, n=1):
+        """Host-side mirror of the device step counter after a graph replay executed the Adam kernel (n = -1 after the
+        capture itself, which runs step() on the host without executing anything)."""
+        self._step_host += n
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
@@ -116,11 +132,7 @@ class FusedAdam(torch.optim.Optimizer):
             if not hasattr(self, '_m') or self._m.device != params[0].device:
                 self._init_state(params)
             self._build_table(params)
-        hyper = (float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),
-                 float(self.grad_scale), float(self._l2_lambda), 0.0, 0.0)
-        if hyper != self._hyper_host:
-            self._hyper.copy_(torch.tensor(hyper, dtype=torch.float32))
-            self._hyper_host = hyper
+        self.sync_hyper()
         if self._anchor is not None:
             self._l2acc.zero_()
         call('clamd_adam_step', ptr(self._tensors_dev), ptr(self._chunks_dev), self._nchunks, ptr(self._hyper),
