@@ -23,6 +23,11 @@ class GradSync:
         self._lo = None
         self._stream = None
         model.grad_sync = self
+        # RCCL's channel workgroups hold CUs for the duration of a collective, and our MFMA kernels need a whole CU per
+        # workgroup: a statically strided persistent grid sized to the CU count would then run two full rounds, while the
+        # hardware dispatcher spreads one-workgroup-per-tile grids over whatever CUs are free (persistent is worth 0.3 %).
+        from . import _lib
+        _lib.load().clamd_set_tuning(b'wino_persist', 0)
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
             optimizer.pre_step_hooks.append(self.wait)
