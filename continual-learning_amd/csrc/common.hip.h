@@ -192,15 +192,18 @@ __device__ inline void sched_mfma_reads() {
 // (sched_group_barrier masks: 0x008 MFMA, 0x002 VALU, 0x100 DS read, 0x200 DS write, 0x020 VMEM read.)
 // VALU groups start at slot V0: the VALU ops that consume an LDS read must not share its slot, or the wave waits out the
 // LDS latency with a single MFMA queued (measured: 5.6k instead of 4.1k cycles per 64-MFMA chunk).
-template <int NM, int R1, int W0, int W1, int L0, int L1, int NV, int V0 = 0, int I = 0>
+// RPS LDS reads per slot in slots [0, R1): with one read per slot and its consumers in the same slot the compiler has to
+// wait for the read it has just issued (lgkmcnt(0) behind every read: the whole LDS latency under ONE 64-cycle MFMA);
+// RPS = 2 and V0 > 0 put the reads a few slots ahead of the VALU ops that use them.
+template <int NM, int R1, int W0, int W1, int L0, int L1, int NV, int V0 = 0, int RPS = 1, int I = 0>
 __device__ inline void sched_mfma_slots() {
     if constexpr (I < NM) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if constexpr (I < R1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if constexpr (I < R1) __builtin_amdgcn_sched_group_barrier(0x100, RPS, 0);
         if constexpr (I >= W0 && I < W1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         if constexpr (I >= L0 && I < L1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         if constexpr (NV > 0 && I >= V0) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
-        sched_mfma_slots<NM, R1, W0, W1, L0, L1, NV, V0, I + 1>();
+        sched_mfma_slots<NM, R1, W0, W1, L0, L1, NV, V0, RPS, I + 1>();
     }
 }
 

@@ -24,6 +24,15 @@
 #include "common.hip.h"
 #include "clamd_internal.h"
 
+// K-loop issue pattern (sched_mfma_slots): RPS LDS reads per slot in slots [0, R1), NV VALU ops per slot from slot V0.
+// Measured alternatives (build with -DWN_RPS=.. etc.): reads two per slot and VALU from slot 12 (no s_waitcnt lgkmcnt(0)
+// behind the reads any more) 209 vs 217 TF/s aggregate; NV = 4: 203; V0 = 16: 201.
+#ifndef WN_RPS
+#define WN_RPS 1
+#define WN_R1 24
+#define WN_V0 0
+#define WN_NV 2
+#endif
 namespace clamd {
 
 struct WinoParams {
@@ -204,7 +213,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
                     for (int nt = 0; nt < 2; ++nt) mma16<float>(Ac[j][mt], Bc[j][nt], acc[j][mt][nt]);
             lds_store(k % NST);                                               // chunk k+2 over chunk k's stage (read before the last barrier)
             gload(k + 3, k + 3 < nk);
-            if constexpr (MT == 2) sched_mfma_slots<64, 24, 26, 37, 38, 49, 2>();
+            if constexpr (MT == 2) sched_mfma_slots<64, WN_R1, 26, 37, 38, 49, WN_NV, WN_V0, WN_RPS>();
             else sched_mfma_slots<32, 16, 17, 27, 21, 31, 2>();
             __syncthreads();
         }
