@@ -362,6 +362,18 @@ def test_conv3x3_winograd_fp32(C, shape):
     assert rel_l2(got_gx[:, [p_ for p_, l in enumerate(pm) if l >= 0]], rgx) < TOL[0]
     pad = [p_ for p_, l in enumerate(pm) if l < 0]
     assert not pad or float(np.abs(got_gx[:, pad]).max()) == 0.0
+    # block order, persistence and tile height are scheduling choices: bit-identical activations under every setting
+    try:
+        for key, val in ((b'wino_band', 1), (b'wino_band', 32), (b'wino_persist', 0), (b'wino_mt', 1), (b'wino_mt', 2)):
+            lib.load().clamd_set_tuning(key, val)
+            y2 = torch.full((B, H, W, cout_p), 7.0, device='cuda')
+            lib.call('clamd_conv3x3_winograd', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y2), cout_p, None, B, H, W, cin_p, cout_p, 1, s)
+            sync()
+            assert torch.equal(y, y2), (key, val)
+            lib.load().clamd_set_tuning(key, {b'wino_band': 0, b'wino_persist': 1, b'wino_mt': 0}[key])
+    finally:
+        for key, val in ((b'wino_band', 0), (b'wino_persist', 1), (b'wino_mt', 0)):
+            lib.load().clamd_set_tuning(key, val)
     # weight gradient by Winograd
     wsb = lib.load().clamd_wgrad_winograd_workspace_bytes(cout_p, cin_p)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
