@@ -118,3 +118,33 @@ def test_crop_origin_matches_pad_center_crop(C):
         vy, vx = (ys >= 0) & (ys < hs), (xs >= 0) & (xs < ws)
         got[np.ix_(vy, vx)] = a[np.ix_(ys[vy], xs[vx])][..., 0]
         assert np.array_equal(got, ref), (hs, ws, h, w)
+
+
+def test_abi_rejects_bad_arguments_before_any_launch(C):
+    """Error behaviour of the C ABI: argument validation happens on the host before anything is
+    enqueued, the entry point returns a negative status, clamd_last_error() names the problem and the Python side raises
+    RuntimeError — as the reference's failures surface as Python exceptions (unet.py:88-91).  No GPU needed: every call
+    below must fail validation (null pointers are never dereferenced)."""
+    lib = C._lib.load()
+    call = C._lib.call
+    cases = [
+        ('empty problem', 'clamd_conv3x3', (None, 32, None, None, None, 32, None, None, None, 0, 16, 16, 32, 32, 1, 0, 0, None)),
+        ('padded', 'clamd_conv3x3', (None, 32, None, None, None, 32, None, None, None, 1, 16, 16, 24, 32, 1, 0, 0, None)),
+        ('bad dtype', 'clamd_conv3x3', (None, 32, None, None, None, 32, None, None, None, 1, 16, 16, 32, 32, 1, 0, 9, None)),
+        ('empty problem', 'clamd_conv3x3_winograd', (None, 32, None, None, None, 32, None, 1, 0, 16, 32, 32, 1, None)),
+        ('must be even', 'clamd_conv3x3_winograd', (None, 32, None, None, None, 32, None, 1, 15, 16, 32, 32, 1, None)),
+        ('padded', 'clamd_conv3x3_winograd', (None, 32, None, None, None, 32, None, 1, 16, 16, 40, 32, 1, None)),
+        ('must be even', 'clamd_wgrad_winograd', (None, 32, None, 32, None, 0, None, 1, 16, 17, 32, 32, 32, 32, 32, 32, 32, 32, None)),
+        ('workspace too small', 'clamd_wgrad_winograd', (None, 32, None, 32, None, 0, None, 1, 16, 16, 32, 32, 32, 32, 32, 32, 32, 32, None)),
+        ('bad mode', 'clamd_wgrad', (7, None, 32, None, 32, None, 0, None, 1, 16, 16, 32, 32, 32, 32, 32, 32, 32, 32, 0, None)),
+        ('empty problem', 'clamd_wgrad', (0, None, 32, None, 32, None, 0, None, 0, 16, 16, 32, 32, 32, 32, 32, 32, 32, 32, 0, None)),
+        ('empty job table', 'clamd_wino_pack', (None, 0, 0, None)),
+    ]
+    for needle, name, args in cases:
+        with pytest.raises(RuntimeError) as e:
+            call(name, *args)
+        assert needle in str(e.value), (name, str(e.value))
+        assert needle in lib.clamd_last_error().decode()
+    assert lib.clamd_set_tuning(b'no_such_key', 1) < 0 and 'unknown key' in lib.clamd_last_error().decode()
+    assert lib.clamd_set_tuning(b'wgrad_blocks', 100000) < 0
+    assert lib.clamd_set_tuning(b'wino_band', 0) == 0
