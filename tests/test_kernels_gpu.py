@@ -5,6 +5,8 @@ Tolerances: fp32 path (exact-fp32 MFMA) differs from the oracle only by summatio
 bf16 path: the oracle is run on bf16-rounded inputs/weights, so what remains is accumulation order plus the bf16
 rounding of the stored output (2^-9 relative per element) -> rel L2 < 6e-3.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -322,7 +324,27 @@ WINO_SHAPES = [  # B, Cin segs, Cout, H, W (H, W even)
 ]
 
 
-@pytest.mark.parametrize('shape', WINO_SHAPES)
+def _random_wino_shapes(n, seed):
+    """Even, ragged image sizes, one- or two-segment (concat) inputs, any channel counts."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        B = int(rng.integers(1, 4))
+        H, W = 2 * int(rng.integers(4, 37)), 2 * int(rng.integers(4, 37))
+        cout = int(rng.integers(1, 200))
+        if rng.random() < 0.4:
+            c1, c2 = int(rng.integers(1, 80)), int(rng.integers(1, 80))
+            pp = max(32, 1 << (max(c1, c2) - 1).bit_length())                   # equal halves, as in the UNet's concat buffers
+            segs = [(c1, pp), (c2, pp)]
+        else:
+            c = int(rng.integers(1, 150))
+            segs = [(c, max(32, 1 << (c - 1).bit_length()))]
+        out.append((B, segs, cout, H, W))
+    return out
+
+
+@pytest.mark.parametrize('shape', WINO_SHAPES + _random_wino_shapes(int(os.environ.get('WINO_SWEEP', '8')), 99),
+                         ids=lambda sh: f'{sh[0]}x{"+".join(str(a) for a, _ in sh[1])}->{sh[2]}@{sh[3]}x{sh[4]}')
 def test_conv3x3_winograd_fp32(C, shape):
     """Winograd F(2x2,3x3) forward (+bias, ReLU, BN statistics) and data gradient, fp32, against the oracle's direct
     convolution at the SAME bound as the direct kernels (fp32 transforms add ~1e-7 relative error)."""
