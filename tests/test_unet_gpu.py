@@ -400,3 +400,49 @@ def test_training_curve_tracks_stock_torch(C, dtype):
     assert l_ours[:5] == pytest.approx(l_ref[:5], rel=5e-4)
     acc_ref = float((out.argmax(1) == y).float().mean()); acc_ours = float((out2.argmax(1) == y).float().mean())
     assert abs(acc_ref - acc_ours) < 0.02
+
+
+def _random_model_configs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append((int(rng.integers(2, 24)), int(rng.choice([3, 5, 8, 12, 16, 20, 24])), 16 * int(rng.integers(2, 9)),
+                    16 * int(rng.integers(2, 9)), int(rng.integers(1, 4))))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16x3'])
+@pytest.mark.parametrize('cfg', _random_model_configs(int(os.environ.get('MODEL_SWEEP', '5')), 5),
+                         ids=lambda c: f'nc{c[0]}-cd{c[1]}-{c[2]}x{c[3]}-b{c[4]}')
+def test_random_model_configs_vs_stock_torch(C, cfg, dtype):
+    """Whole forward + loss + backward on random (classes, conv_dim, H, W, batch) — odd conv_dims (channel padding at every
+    level), non-square images, Winograd and direct kernels mixed by size — against the stock torch counterpart on the
+    same GPU: logits, loss and every parameter gradient of one step."""
+    nc, cd, H, W, B = cfg
+    dev = torch.device('cuda', 0)
+    x = torch.from_numpy(C.synth.images(31, B, 3, H, W)).to(dev)
+    y = torch.from_numpy(C.synth.labels(31, B, H, W, nc)).to(dev)
+    torch.manual_seed(cd * 1000 + nc)
+    ref = TC.build_unet(nc, 3, cd).to(dev).train()
+    ours = C.UNet(nc, 3, cd, compute_dtype=dtype).to(dev).train()
+    ours.load_state_dict(ref.state_dict())
+    out_r = ref(x); l_r = torch.nn.CrossEntropyLoss()(out_r, y); l_r.backward()
+    out_o = ours(x); l_o = C.CrossEntropyLoss()(out_o, y); l_o.backward()
+    torch.cuda.synchronize()
+    tol = 2e-4 if dtype == 'fp32' else 1e-3
+    assert rel_l2(out_o.detach().cpu().numpy(), out_r.detach().cpu().numpy()) < tol
+    assert float(l_o.detach()) == pytest.approx(float(l_r.detach()), rel=tol)
+    gr = dict(ref.named_parameters())
+    # per tensor for the weights; the conv / convT biases in front of a BatchNorm have gradients that cancel to (almost)
+    # zero, so their relative error is noise -- they are covered by the norm over all gradients together
+    worst = max((rel_l2(p.grad.cpu().numpy(), gr[n].grad.cpu().numpy()), n) for n, p in ours.named_parameters() if p.dim() > 1)
+    # Gradients of small random nets are decided by ReLU / max-pool ties: against an fp64 run, stock torch fp32 (CPU and
+    # GPU) is itself 5e-3 .. 8e-3 off in the gradient norm on these configurations while its logits agree to 1e-6
+    # (probe: ours-direct 2e-6 .. 3e-3, ours-Winograd 2e-3 .. 8e-3, ours-bf16x3 1.2e-2 .. 2.2e-2).  The bounds admit such
+    # flips; logits and loss above are held tight.
+    gtol_t, gtol_all = (0.15, 3e-2) if dtype == 'fp32' else (0.2, 6e-2)
+    assert worst[0] < gtol_t, worst
+    ga = torch.cat([p.grad.reshape(-1) for _, p in ours.named_parameters()]).cpu().numpy()
+    gb = torch.cat([gr[n].grad.reshape(-1) for n, _ in ours.named_parameters()]).cpu().numpy()
+    assert rel_l2(ga, gb) < gtol_all
