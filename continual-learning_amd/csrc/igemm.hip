@@ -419,6 +419,7 @@ extern int g_wgrad_tw16;
 extern int g_wgrad_ws;
 extern int g_wgrad_xcd;
 extern int g_wino_band;
+extern int g_pws_wres;
 extern int g_wino_persist;
 extern int g_wino_mt;
 extern int g_wgrad_dma;
@@ -492,6 +493,7 @@ int clamd_set_tuning(const char* key, int value) {
     if (!strcmp(key, "wgrad_ws")) { g_wgrad_ws = value; return 0; }
     if (!strcmp(key, "wgrad_xcd")) { g_wgrad_xcd = value; return 0; }
     if (!strcmp(key, "wino_band")) { g_wino_band = value; return 0; }
+    if (!strcmp(key, "pws_wres")) { g_pws_wres = value; return 0; }
     if (!strcmp(key, "wino_persist")) { g_wino_persist = value; return 0; }
     if (!strcmp(key, "wino_mt")) { g_wino_mt = value; return 0; }
     if (!strcmp(key, "wgrad_dma")) { g_wgrad_dma = value; return 0; }

@@ -28,7 +28,7 @@ __device__ unsigned long long g_pws_diag[8];
 #endif
 
 template <typename T, int TW>
-__global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, const int gm) {
+__global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, const int gm, const int w_resident) {
     constexpr int MT = 2;
     using G = WsGeo<TW, MT>;
     constexpr int TH = G::TH, NT = G::NT, HW_ = G::HW_, NPIX = G::NPIX, NPIXP = G::NPIXP, NJ = G::NJ;
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
         _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                            \
             rw[t] = buf_ld16(wrs, w_vo, (unsigned)((ks_) * NT + t) * w_slab);                                     \
     } while (0)
-#define PWS_STORE(st_, RIN)                                                                                       \
+#define PWS_STORE_IN(st_, RIN)                                                                                       \
     do {                                                                                                          \
         uint4* sm_ = smem + (st_) * STAGE;                                                                        \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                          \
@@ -123,8 +123,14 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                 *reinterpret_cast<uint2*>(b_ + 2 * NPIXP * 16) = lo_;                                             \
             }                                                                                                     \
         }                                                                                                         \
+    } while (0)
+
+#define PWS_STORE_W(st_)                                                                                          \
+    do {                                                                                                          \
+        uint4* sm_ = smem + (st_) * STAGE;                                                                        \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) sm_[G::IN_SLOTS + (t * 4 + g4) * G::WG + wco] = rw[t];     \
     } while (0)
+#define PWS_STORE(st_, RIN) do { PWS_STORE_IN(st_, RIN); PWS_STORE_W(st_); } while (0)
 
         int l_tile = 0, l_pair = 0;                // load cursor: tile index of this workgroup, K-step pair inside it
         const int npair = nk >> 1;
@@ -134,28 +140,45 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
         PWS_STORE(0, rinA);
         PWS_GLOAD_W(1);
         __syncthreads();                                   // step 0 is staged
-        int ks2 = 2 == nk ? 0 : 2;                         // K-step index (inside its tile) of flattened step 2q + 2
-        for (int q = 0; q < (S >> 1); ++q) {
-            const bool more = 2 * q + 2 < S;               // wave-uniform; false only in the last iteration
-            // consumers are on step 2q (stage 0): stage step 2q + 1, then fetch steps 2q + 2 / 2q + 3
-            PWS_STORE(1, rinB);
-            if (more) {
-                PWS_GLOAD_W(ks2);
-                if (++l_pair == npair) { l_pair = 0; ++l_tile; set_tile(mg + l_tile * gm); }
-                PWS_GLOAD_IN2(l_pair);
+        if (nk == 2 && w_resident) {
+            // Two K-steps per tile (64 input channels in bf16): stage parity == K-step, so the two stages already hold the
+            // WHOLE filter slab of this output slab after the first tile -- only the input halos are staged from then on
+            // (58 -> 22 KB per K-step).
+            for (int q = 0; q < (S >> 1); ++q) {
+                const bool more = 2 * q + 2 < S;
+                PWS_STORE_IN(1, rinB);
+                if (q == 0) PWS_STORE_W(1);                // the slab of K-step 1, fetched by the prologue
+                if (more) { ++l_tile; set_tile(mg + l_tile * gm); PWS_GLOAD_IN2(0); }
+                __syncthreads();
+                if (more) PWS_STORE_IN(0, rinA);
+                __syncthreads();
             }
-            __syncthreads();
-            // consumers are on step 2q + 1 (stage 1): stage step 2q + 2, fetch the filter slab of step 2q + 3
-            if (more) {
-                PWS_STORE(0, rinA);
-                PWS_GLOAD_W(ks2 + 1);
+        } else {
+            int ks2 = 2 == nk ? 0 : 2;                         // K-step index (inside its tile) of flattened step 2q + 2
+            for (int q = 0; q < (S >> 1); ++q) {
+                const bool more = 2 * q + 2 < S;               // wave-uniform; false only in the last iteration
+                // consumers are on step 2q (stage 0): stage step 2q + 1, then fetch steps 2q + 2 / 2q + 3
+                PWS_STORE(1, rinB);
+                if (more) {
+                    PWS_GLOAD_W(ks2);
+                    if (++l_pair == npair) { l_pair = 0; ++l_tile; set_tile(mg + l_tile * gm); }
+                    PWS_GLOAD_IN2(l_pair);
+                }
+                __syncthreads();
+                // consumers are on step 2q + 1 (stage 1): stage step 2q + 2, fetch the filter slab of step 2q + 3
+                if (more) {
+                    PWS_STORE(0, rinA);
+                    PWS_GLOAD_W(ks2 + 1);
+                }
+                __syncthreads();
+                ks2 = ks2 + 2 == nk ? 0 : ks2 + 2;
             }
-            __syncthreads();
-            ks2 = ks2 + 2 == nk ? 0 : ks2 + 2;
         }
 #undef PWS_GLOAD_IN2
 #undef PWS_GLOAD_W
 #undef PWS_STORE
+#undef PWS_STORE_IN
+#undef PWS_STORE_W
     } else {
         // ------------------------------------------------------------------ consumers: LDS fragments -> MFMA -> epilogue
         int apix[MT];
@@ -414,6 +437,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
 }
 
 static int g_num_cus = 0;
+int g_pws_wres = 1;             // tuning knob "pws_wres": keep the filter slab resident in LDS when a tile has two K-steps
 
 }  // namespace clamd
 #ifdef CLAMD_DIAG
@@ -444,8 +468,8 @@ static int launch_pws_t(const IgemmParams& p, hipStream_t s) {
     if (gm > ntm) gm = ntm;
     const long long nblk = gm * ntn;
     if (ntm > 0x7fffffff) return clamd_fail("igemm_pws: grid out of range");
-    if (wide) hipLaunchKernelGGL((igemm_pws_kernel<T, 32>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm);
-    else hipLaunchKernelGGL((igemm_pws_kernel<T, 16>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm);
+    if (wide) hipLaunchKernelGGL((igemm_pws_kernel<T, 32>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm, g_pws_wres);
+    else hipLaunchKernelGGL((igemm_pws_kernel<T, 16>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm, g_pws_wres);
     return clamd_check_launch("igemm_pws");
 }
 

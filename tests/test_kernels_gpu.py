@@ -247,9 +247,11 @@ VARIANT_SHAPES = [  # B, Cin, Cout, H, W
     (2, 64, 64, 40, 64),      # short K, ragged tile rows
     (1, 256, 96, 16, 16),     # long K, 16-wide tiles, ragged Cout tile
     (3, 128, 130, 24, 40),    # 3 Cout slabs (persistent kernel: several workgroups per slab), ragged in x and y
+    (5, 64, 40, 128, 160),    # 400 tiles > CUs: persistent workgroups walk several tiles (resident filter slab in bf16)
 ]
 CONV_VARIANTS = [('igemm_pws', 0, 'igemm_ws', 0), ('igemm_pws', 0, 'igemm_ws', 1), ('igemm_pws', 0, 'igemm_ws', 3),
-                 ('igemm_pws', 0, 'igemm_ws', 4), ('igemm_pws', 2, 'igemm_ws', 2), ('igemm_pws', 1, 'igemm_ws', 2)]
+                 ('igemm_pws', 0, 'igemm_ws', 4), ('igemm_pws', 2, 'igemm_ws', 2), ('igemm_pws', 2, 'pws_wres', 0),
+                 ('igemm_pws', 1, 'pws_wres', 1)]
 
 
 @pytest.mark.parametrize('name,dcode', DT)
@@ -285,6 +287,7 @@ def test_conv3x3_kernel_structures_agree(C, name, dcode, shape):
     finally:
         lib.load().clamd_set_tuning(b'igemm_pws', 1)
         lib.load().clamd_set_tuning(b'igemm_ws', 2)
+        lib.load().clamd_set_tuning(b'pws_wres', 1)
 
 
 @pytest.mark.parametrize('name,dcode', DT)
