@@ -420,6 +420,8 @@ extern int g_wgrad_ws;
 extern int g_wgrad_xcd;
 extern int g_wino_band;
 extern int g_pws_wres;
+extern int g_bn_reduce_blocks;
+extern int g_chsum_blocks;
 extern int g_wino_persist;
 extern int g_wino_mt;
 extern int g_wgrad_dma;
@@ -494,6 +496,8 @@ int clamd_set_tuning(const char* key, int value) {
     if (!strcmp(key, "wgrad_xcd")) { g_wgrad_xcd = value; return 0; }
     if (!strcmp(key, "wino_band")) { g_wino_band = value; return 0; }
     if (!strcmp(key, "pws_wres")) { g_pws_wres = value; return 0; }
+    if (!strcmp(key, "bn_reduce_blocks")) { if (value < 0 || value > 65535) return clamd_fail("bn_reduce_blocks: 0..65535"); g_bn_reduce_blocks = value; return 0; }
+    if (!strcmp(key, "chsum_blocks")) { if (value < 0 || value > 65535) return clamd_fail("chsum_blocks: 0..65535"); g_chsum_blocks = value; return 0; }
     if (!strcmp(key, "wino_persist")) { g_wino_persist = value; return 0; }
     if (!strcmp(key, "wino_mt")) { g_wino_mt = value; return 0; }
     if (!strcmp(key, "wgrad_dma")) { g_wgrad_dma = value; return 0; }

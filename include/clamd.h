@@ -157,7 +157,8 @@ int clamd_fill_f32(float* p, long long n, double v, void* stream);
  * "igemm_ws" 0|1|2|3|4 (producer/consumer kernel: never | 256-px | heuristic | 512-px | 128-px tiles),
  * "igemm_variant" 0|1|2 (baseline kernel prefetch variants), "wgrad_ws" 0|1, "wgrad_dma" 0|1|2 (LDS-DMA staging: never | heuristic | always), "wgrad_xcd" 0|1, "wgrad_blocks" 1..512,
  * "wgrad_tw16" 0|1, "wino_band" 0 (per-launch choice) | 1..32 (output-channel slabs per band of the Winograd block
- * order), "pws_wres" 0|1 (persistent kernel: filter slab kept in LDS across tiles when a tile has two K-steps),
+ * order), "bn_reduce_blocks" / "chsum_blocks" 0 (per-launch choice) | n (grid cap of the per-channel reductions),
+ * "pws_wres" 0|1 (persistent kernel: filter slab kept in LDS across tiles when a tile has two K-steps),
  * "wino_persist" 0|1 (one workgroup per tile | persistent tile loop), "wino_mt" 0|1|2 (tile height: per-launch
  * choice | 8 | 16 pixels).  Process-wide, not thread-safe: set before launching. */
 int clamd_set_tuning(const char* key, int value);

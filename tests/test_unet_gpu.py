@@ -361,16 +361,19 @@ def test_graphed_step_matches_eager(C):
     m2, o2, s2, c2 = make()
     step = C.GraphedStep(m2, o2, c2, x, y, warmup=3)     # 3 eager steps, then the capture (not executed)
     got = [float(l) for l in step.eager_losses]
+    flat = lambda m: torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
+    moved = []
     for i in range(3, 6):
+        w_before = flat(m2)
         got.append(float(step(x, y)))
+        moved.append(float((flat(m2) - w_before).abs().mean()))
         if i == 3:
             s2.step()
     assert got == pytest.approx(ref, rel=2e-3)
     assert float(o2.state[next(iter(m2.parameters()))]['step']) == 6.0
-    w1 = torch.cat([p.detach().reshape(-1) for p in m1.parameters()])
-    w2 = torch.cat([p.detach().reshape(-1) for p in m2.parameters()])
-    # after the lr change the updates are 0.5e-3 per step: a replay that still used lr = 1e-3 would be off by ~5e-4 per weight
-    assert float((w1 - w2).abs().mean()) < 1e-4
+    # Adam moves every weight by about lr per step: after the scheduler halved lr, the replayed (captured) Adam kernel
+    # must move the weights half as far -- it reads lr from device memory, which sync_hyper() refreshed before the replay
+    assert 0.25 < moved[2] / moved[0] < 0.7, moved
 
 
 @pytest.mark.gpu
