@@ -296,25 +296,27 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const T* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // Layout conversion at the drop-in boundary (visible tensors are NCHW fp32).
-// NCHW f32 [B,C,H,W] -> NHWC T [B,H,W,ldc] with channels >= C zero-filled up to Cp.  One thread per (pixel, 8ch).
+// NCHW f32 [B,C,H,W] -> NHWC T [B,H,W,ldc] with channels >= C zero-filled up to Cp.  One thread per pixel.
+// One thread per PIXEL, the channel groups in turn: for every channel the 64 lanes read 64 consecutive pixels of one NCHW
+// plane (256 contiguous bytes) and a lane writes its pixel's channel vector back to back, so a wave completes each
+// 128-byte line of the NHWC tensor at once.  Measured per launch of an fp32 step (nchw_to_nhwc / nchw_im2col3): one
+// thread per (pixel, 8 channels) 92 / 117 us; this 67 / 79 us; an LDS-tiled variant with fully contiguous stores 70 / 95 us.
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* dst, int ldc, int B, int C, int H, int W,
-                                    int Cp, float mul) {
+                                         int Cp, float mul) {
     const int G = Cp >> 3;
-    const long long hw = (long long)H * W, nitem = (long long)B * hw * G;
-    // lanes along pixels (coalesced NCHW reads); each lane writes 16/32 contiguous bytes
-    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < nitem;
-         it += (long long)gridDim.x * blockDim.x) {
-        const long long pixb = it % (B * hw);
-        const int cg = (int)(it / (B * hw));
+    const long long hw = (long long)H * W, npix = (long long)B * hw;
+    for (long long pixb = (long long)blockIdx.x * blockDim.x + threadIdx.x; pixb < npix; pixb += (long long)gridDim.x * blockDim.x) {
         const long long b = pixb / hw, p = pixb % hw;
-        float v[8];
+        for (int cg = 0; cg < G; ++cg) {
+            float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = cg * 8 + j;
-            v[j] = c < C ? src[(b * C + c) * hw + p] * mul : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                const int c = cg * 8 + j;
+                v[j] = c < C ? src[(b * C + c) * hw + p] * mul : 0.f;
+            }
+            Vec8<T>::store(dst + pixb * ldc + cg * 8, v);
         }
-        Vec8<T>::store(dst + pixb * ldc + cg * 8, v);
     }
 }
 
@@ -325,21 +327,20 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* dst, int l
 template <typename T>
 __global__ void nchw_im2col3_kernel(const float* __restrict__ src, T* dst, int ldc, int B, int C, int H, int W, int Cp) {
     const int G = Cp >> 3;
-    const long long hw = (long long)H * W, nitem = (long long)B * hw * G;
-    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < nitem;
-         it += (long long)gridDim.x * blockDim.x) {
-        const long long pixb = it % (B * hw);
-        const int cg = (int)(it / (B * hw));
+    const long long hw = (long long)H * W, npix = (long long)B * hw;
+    for (long long pixb = (long long)blockIdx.x * blockDim.x + threadIdx.x; pixb < npix; pixb += (long long)gridDim.x * blockDim.x) {
         const long long b = pixb / hw, p = pixb % hw;
         const int y = (int)(p / W), x = (int)(p % W);
-        float v[8];
+        for (int cg = 0; cg < G; ++cg) {
+            float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = cg * 8 + j, c = k / 9, t = k - c * 9;
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            v[j] = (c < C && yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[(b * C + c) * hw + (long long)yy * W + xx] : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                const int k = cg * 8 + j, c = k / 9, t = k - c * 9;
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                v[j] = (c < C && yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[(b * C + c) * hw + (long long)yy * W + xx] : 0.f;
+            }
+            Vec8<T>::store(dst + pixb * ldc + cg * 8, v);
         }
-        Vec8<T>::store(dst + pixb * ldc + cg * 8, v);
     }
 }
 
@@ -465,25 +466,27 @@ int clamd_channel_sum(const void* g, int ldc, float* out, long long npix, int Cp
 int clamd_nchw_to_nhwc(const float* src, void* dst, int ldc, int B, int C, int H, int W, int Cp, double mul,
                        int dtype, void* stream) {
     if (Cp % 8 || C > Cp) return clamd_fail("nchw_to_nhwc: bad channel counts");
-    const long long nitem = (long long)B * H * W * (Cp / 8);
+    const long long nitem = (long long)B * H * W;
     dim3 g(ew_grid(nitem, 8192)), b(256);
-    if (dtype == CLAMD_BF16)
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, src, (bf16_t*)dst, ldc, B, C, H, W, Cp, (float)mul);
-    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT)
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, g, b, 0, (hipStream_t)stream, src, (float*)dst, ldc, B, C, H, W, Cp, (float)mul);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T) hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, g, b, 0, s, src, (T*)dst, ldc, B, C, H, W, Cp, (float)mul)
+    if (dtype == CLAMD_BF16) LAUNCH(bf16_t);
+    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT) LAUNCH(float);
     else return clamd_fail("nchw_to_nhwc: bad dtype");
+#undef LAUNCH
     return clamd_check_launch("nchw_to_nhwc");
 }
 
 int clamd_nchw_im2col3(const float* src, void* dst, int ldc, int B, int C, int H, int W, int Cp, int dtype, void* stream) {
     if (Cp % 8 || 9 * C > Cp) return clamd_fail("nchw_im2col3: needs 9*C <= Cp, Cp % 8 == 0");
-    const long long nitem = (long long)B * H * W * (Cp / 8);
+    const long long nitem = (long long)B * H * W;
     dim3 g(ew_grid(nitem, 8192)), b(256);
-    if (dtype == CLAMD_BF16)
-        hipLaunchKernelGGL(nchw_im2col3_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, src, (bf16_t*)dst, ldc, B, C, H, W, Cp);
-    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT)
-        hipLaunchKernelGGL(nchw_im2col3_kernel<float>, g, b, 0, (hipStream_t)stream, src, (float*)dst, ldc, B, C, H, W, Cp);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T) hipLaunchKernelGGL(nchw_im2col3_kernel<T>, g, b, 0, s, src, (T*)dst, ldc, B, C, H, W, Cp)
+    if (dtype == CLAMD_BF16) LAUNCH(bf16_t);
+    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT) LAUNCH(float);
     else return clamd_fail("nchw_im2col3: bad dtype");
+#undef LAUNCH
     return clamd_check_launch("nchw_im2col3");
 }
 
