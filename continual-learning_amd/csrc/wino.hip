@@ -89,7 +89,11 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
 
         // ---- staging descriptors --------------------------------------------------------------------------------------
         const unsigned img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc * 4u;
+#ifdef WN_ABLATE_SAMETILE   // measurement only: every workgroup stages the same input tile (all loads hit the caches)
+        const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x, img);
+#else
         const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x + (size_t)b * img, img);
+#endif
         const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.w, (unsigned)(16u * p.Np * p.Kp * 4u));
         unsigned in_vo[NJI];
         int in_slot[NJI];
@@ -99,7 +103,11 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
             if (piece >= 2 * WN_PIX) piece -= 2 * WN_PIX;
             const int g = piece & 1, pix = piece >> 1;
             const int hy = pix / WN_HW, hx = pix - hy * WN_HW;
+#ifdef WN_ABLATE_SAMETILE
+            const int yy = hy - 1 + 16, xx = hx - 1 + 16;
+#else
             const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+#endif
             in_vo[j] = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? (unsigned)(((yy * p.W + xx) * p.x_ldc + 4 * g) * 4) : BUF_OOB;
             in_slot[j] = g * WN_PIXP + pix;
         }
