@@ -133,10 +133,18 @@ def main():
             sys.exit('launch with torch.distributed.run for --gpus > 1')
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    # Rehearsal switch for 1-GPU boxes (tests/test_bench_ddp_gpu.py): CLAMD_BENCH_BACKEND=gloo lets N ranks share one
+    # card (RCCL refuses two ranks on one device).  The driver's multi-GPU runs never set it.
+    backend = os.environ.get('CLAMD_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=device)       # "nccl" IS RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)   # "nccl" IS RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     dt, loss, kern = run(args, args.dtype, rank, world, device, timing=not args.no_kernel_timing)
     images = args.batch * world * args.steps
