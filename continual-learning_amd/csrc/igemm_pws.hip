@@ -209,8 +209,8 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                 if constexpr (BN) bn_vo[mt][ps] = n < p.Np ? (unsigned)(((m / TW) * p.W + m % TW) * p.Np + n) * (unsigned)sizeof(T) : BUF_OOB;
             }
 
-        unsigned long long d0 = PWD_T(), d1, d2, dk = 0, db = 0, de = 0;
-        (void)d1; (void)d2; (void)dk; (void)db; (void)de;
+        unsigned long long d0 = PWD_T(), d1, d2, dk = 0, db = 0, de = 0, dea = 0, deb = 0, dec_ = 0;
+        (void)d1; (void)d2; (void)dk; (void)db; (void)de; (void)dea; (void)deb; (void)dec_;
         __syncthreads();                                   // step 0 is staged
         PWD_ADD(0, PWD_T() - d0);                          // [0] wait for the first stage
         for (int ti = 0; ti < T_; ++ti) {
@@ -323,6 +323,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             const bool full = y0 + TH <= p.H && x0 + TW <= p.W;            // wave-uniform
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+                const unsigned long long e0 = PWD_T(); (void)e0;
                 if (full) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
@@ -346,6 +347,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                             wbuf[acc_row(e, h) * 68 + 32 * nt + r] = v;
                         }
                 }
+                const unsigned long long e1 = PWD_T(); (void)e1;
                 float4 lo[4], hi[4];                       // all four row pieces first: one LDS round trip, not four
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
@@ -353,6 +355,10 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                     lo[ps] = *reinterpret_cast<const float4*>(wbuf + row * 68 + cgp * 8);
                     hi[ps] = *reinterpret_cast<const float4*>(wbuf + row * 68 + cgp * 8 + 4);
                 }
+#ifdef CLAMD_DIAG
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // attribute the LDS round trip to phase [5]
+#endif
+                const unsigned long long e2 = PWD_T(); (void)e2;
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
                     const float v[8] = {lo[ps].x, lo[ps].y, lo[ps].z, lo[ps].w, hi[ps].x, hi[ps].y, hi[ps].z, hi[ps].w};
@@ -381,10 +387,12 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                         }
                     }
                 }
+                dea += e1 - e0; deb += e2 - e1; dec_ += PWD_T() - e2;
             }
             de += PWD_T() - d2;
         }
         PWD_ADD(1, dk); PWD_ADD(2, db); PWD_ADD(3, de);    // [1] MFMA loops [2] at the K-step barriers [3] epilogues
+        PWD_ADD(4, dea); PWD_ADD(5, deb); PWD_ADD(6, dec_); // epilogue: [4] bias/ReLU/stats + LDS writes [5] LDS round trip [6] pack + stores
         if (wave == 0) PWD_ADD(7, 1);                      // [7] workgroups
     }
 

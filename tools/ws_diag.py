@@ -29,7 +29,8 @@ for cin, cout, hw in [(64, 64, 256), (128, 64, 256), (128, 128, 128), (256, 256,
     torch.cuda.synchronize(); diag(out, 1)
     v = list(out); nb = max(v[7], 1)
     if pws:
-        print(f'{cin}->{cout}@{hw}: workgroups {nb}; consumer cycles per wave per workgroup: ' + ', '.join(f'{n} {v[i] / (nb * 4):.0f}' for i, n in enumerate(['wait first stage', 'MFMA loops', 'at K-step barriers', 'epilogues'])))
+        print(f'{cin}->{cout}@{hw}: workgroups {nb}; consumer cycles per wave per workgroup: ' + ', '.join(f'{n} {v[i] / (nb * 4):.0f}' for i, n in enumerate(['wait first stage', 'MFMA loops', 'at K-step barriers', 'epilogues'])) +
+              '  | epilogue phases: ' + ', '.join(f'{n} {v[i] / (nb * 4):.0f}' for i, n in [(4, 'bias/ReLU/stats + LDS writes'), (5, 'LDS round trip'), (6, 'pack + stores (+BN sums)')]))
         continue
     names = ['prod prologue', 'prod load-wait+store+issue', 'prod at barrier', 'cons wait stage0 + PROD vmcnt wait', 'cons MFMA loop', 'cons at barrier', 'epilogue + PROD wait+store']
     print(f'{cin}->{cout}@{hw}: blocks {nb}; per-wave cycles per block: ' + ', '.join(f'{n} {v[i] / (nb * 4):.0f}' for i, n in enumerate(names)))
