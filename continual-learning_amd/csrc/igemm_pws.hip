@@ -15,6 +15,9 @@
 #include "igemm_common.hip.h"
 #include "clamd_internal.h"
 
+#ifndef PWS_EPW
+#define PWS_EPW 68
+#endif
 namespace clamd {
 
 #ifdef CLAMD_DIAG
@@ -35,7 +38,11 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
     constexpr int KC = DT<T>::KC, VEC = DT<T>::VEC;
     constexpr bool SPLIT = __is_same(T, split_t);
     constexpr int STAGE = G::IN_SLOTS + G::WT_SLOTS;
-    constexpr int EPI_SLOTS = (4 * 32 * 68 + 8 * 64) / 4;        // 4 waves x [32][68] fp32 + statistics hand-over
+    // Row pitch of the wave-private transposition block.  68 floats: the two half-waves of a 32x32 accumulator tile share
+    // 16 banks when they write; 72 (conflict-free writes) was measured no faster in the write phase (it is VALU-issue
+    // bound: 34.7k cycles either way) and slower in the read-back (6.0k -> 8.9k cycles), -DPWS_EPW=72 to reproduce.
+    constexpr int EPW = PWS_EPW;
+    constexpr int EPI_SLOTS = (4 * 32 * EPW + 8 * 64) / 4;       // 4 waves x [32][EPW] fp32 + statistics hand-over
     static_assert((2 * STAGE + EPI_SLOTS) * 16 <= 160 * 1024, "two LDS stages + the epilogue region must fit one CU");
     __shared__ uint4 smem[2 * STAGE + EPI_SLOTS];
 
@@ -193,7 +200,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             const int n = n0 + 32 * nt + r;
             bcol[nt] = (p.bias && n < p.Np) ? p.bias[n] : 0.f;
         }
-        float* const wbuf = reinterpret_cast<float*>(smem + 2 * STAGE) + cw * 32 * 68;   // this wave's transposition block
+        float* const wbuf = reinterpret_cast<float*>(smem + 2 * STAGE) + cw * 32 * EPW;   // this wave's transposition block
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();
         const unsigned y_img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.y_ldc * (unsigned)sizeof(T);
         const unsigned bn_img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.Np * (unsigned)sizeof(T);   // bn_y: dense pitch Np
@@ -332,7 +339,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                             const float v = fmaxf(acc[mt][nt][e] + bcol[nt], relu_lo);
                             st1[nt] += v;
                             st2[nt] = fmaf(v, v, st2[nt]);
-                            wbuf[acc_row(e, h) * 68 + 32 * nt + r] = v;
+                            wbuf[acc_row(e, h) * EPW + 32 * nt + r] = v;
                         }
                 } else {
 #pragma unroll
@@ -344,7 +351,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                             const float vs = (y0 + m / TW < p.H && x0 + m % TW < p.W) ? v : 0.f;
                             st1[nt] += vs;
                             st2[nt] = fmaf(vs, vs, st2[nt]);
-                            wbuf[acc_row(e, h) * 68 + 32 * nt + r] = v;
+                            wbuf[acc_row(e, h) * EPW + 32 * nt + r] = v;
                         }
                 }
                 const unsigned long long e1 = PWD_T(); (void)e1;
@@ -352,8 +359,8 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
                     const int row = ps * 8 + (lane >> 3), cgp = lane & 7;
-                    lo[ps] = *reinterpret_cast<const float4*>(wbuf + row * 68 + cgp * 8);
-                    hi[ps] = *reinterpret_cast<const float4*>(wbuf + row * 68 + cgp * 8 + 4);
+                    lo[ps] = *reinterpret_cast<const float4*>(wbuf + row * EPW + cgp * 8);
+                    hi[ps] = *reinterpret_cast<const float4*>(wbuf + row * EPW + cgp * 8 + 4);
                 }
 #ifdef CLAMD_DIAG
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // attribute the LDS round trip to phase [5]
@@ -398,7 +405,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
 
     // ---------------------------------------------------------------------- statistics: one flush per workgroup
     if (p.stats) {
-        float* sbuf = reinterpret_cast<float*>(smem + 2 * STAGE) + 4 * 32 * 68;
+        float* sbuf = reinterpret_cast<float*>(smem + 2 * STAGE) + 4 * 32 * EPW;
         if (!producer) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
@@ -431,13 +438,13 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                     for (int j = 0; j < 8; ++j) {
                         float t = bs[k][j];
                         t += __shfl_xor(t, 8); t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
-                        if (lane < 8) ebuf[cw * 32 * 68 + k * 64 + lane * 8 + j] = t;
+                        if (lane < 8) ebuf[cw * 32 * EPW + k * 64 + lane * 8 + j] = t;
                     }
             }
             __syncthreads();
             for (int i = tid; i < 5 * 64; i += 512) {
                 const int k = i >> 6, c = i & 63;
-                const float t = ebuf[0 * 32 * 68 + i] + ebuf[1 * 32 * 68 + i] + ebuf[2 * 32 * 68 + i] + ebuf[3 * 32 * 68 + i];
+                const float t = ebuf[0 * 32 * EPW + i] + ebuf[1 * 32 * EPW + i] + ebuf[2 * 32 * EPW + i] + ebuf[3 * 32 * EPW + i];
                 if (n0 + c < p.Np) atomicAdd(p.bn_sums + ((size_t)(blockIdx.x % STAT_REPLICAS) * 5 + k) * p.Np + n0 + c, t);
             }
         }
