@@ -137,9 +137,12 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
         auto gload = [&](int k, bool live) { gload_to(k, live, rin, rw); };
         auto lds_store = [&](int st) { lds_store_from(st, rin, rw); };
 
-        // ---- fragment addressing: wave w = Winograd row i: t[b] = s1 * d[a1][b] + s2 * d[a2][b] ------------------------
+        // ---- fragment addressing: wave w = Winograd row i: t[b] = d[a1][b] + s2 * d[a2][b] -----------------------------
         const int a1 = w == 0 ? 0 : 1, a2 = w == 3 ? 3 : 2;
-        const float s1 = w == 2 ? -1.f : 1.f, s2 = (w == 0 || w == 3) ? -1.f : 1.f;
+        // B^T rows: d0 - d2 | d1 + d2 | d2 - d1 | d1 - d3.  Row 2 is formed as d1 - d2 = -(d2 - d1): its sign is folded into
+        // the transformed filters (wino_pack_kernel negates U[2][j]), so every row is d[a1] + s2 * d[a2] -- one fma per
+        // component with a wave-uniform coefficient instead of a multiply and an fma (32 of 134 VALU ops per chunk).
+        const float s2 = w == 1 ? 1.f : -1.f;
         int p1[MT], p2[MT];
     #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -168,10 +171,10 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
     #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const uint4 u1 = sm[p1[mt] + c], u2 = sm[p2[mt] + c];
-                    t[c].x = fmaf(s2, __uint_as_float(u2.x), s1 * __uint_as_float(u1.x));
-                    t[c].y = fmaf(s2, __uint_as_float(u2.y), s1 * __uint_as_float(u1.y));
-                    t[c].z = fmaf(s2, __uint_as_float(u2.z), s1 * __uint_as_float(u1.z));
-                    t[c].w = fmaf(s2, __uint_as_float(u2.w), s1 * __uint_as_float(u1.w));
+                    t[c].x = fmaf(s2, __uint_as_float(u2.x), __uint_as_float(u1.x));   // ONE op per component: row 2's
+                    t[c].y = fmaf(s2, __uint_as_float(u2.y), __uint_as_float(u1.y));   // overall sign lives in the
+                    t[c].z = fmaf(s2, __uint_as_float(u2.z), __uint_as_float(u1.z));   // packed filters (see below)
+                    t[c].w = fmaf(s2, __uint_as_float(u2.w), __uint_as_float(u1.w));
                 }
     #define WN_PK(v_) make_uint4(__float_as_uint((v_).x), __float_as_uint((v_).y), __float_as_uint((v_).z), __float_as_uint((v_).w))
                 A[0][mt] = WN_PK(make_float4(t[0].x - t[2].x, t[0].y - t[2].y, t[0].z - t[2].z, t[0].w - t[2].w));
@@ -375,7 +378,8 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const WinoPackJob* __res
     float* d = J.dst + ((size_t)kc * 16 * J.Np + n) * 8 + k8;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]), u3 = t[i][2];
+        const float sg = i == 2 ? -0.5f : 0.5f;          // row 2 carries the sign of the kernel's input transform (see wino_kernel)
+        const float u0 = 2.f * sg * t[i][0], u1 = sg * (t[i][0] + t[i][1] + t[i][2]), u2 = sg * (t[i][0] - t[i][1] + t[i][2]), u3 = 2.f * sg * t[i][2];
         d[(size_t)(4 * i + 0) * J.Np * 8] = u0;
         d[(size_t)(4 * i + 1) * J.Np * 8] = u1;
         d[(size_t)(4 * i + 2) * J.Np * 8] = u2;
@@ -541,7 +545,9 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const WinoWgradParam
     // wave row i = w: coefficients of the two transforms
     const float c0f = w == 3 ? 0.f : 1.f, c1f = w == 0 ? 0.f : (w == 1 ? 1.f : -1.f);          // A[w] = (c0, c1)
     const int a1 = w == 0 ? 0 : 1, a2 = w == 3 ? 3 : 2;                                          // B^T[w]: rows a1, a2
-    const float s1 = w == 2 ? -1.f : 1.f, s2 = (w == 0 || w == 3) ? -1.f : 1.f;
+    // as in wino_kernel: every B^T row is d[a1] + s2 * d[a2]; row 2 comes out negated and wino_wgrad_reduce_kernel flips
+    // plane 2 back (one fma per element instead of a multiply and an fma)
+    const float s2 = w == 1 ? 1.f : -1.f;
     // lane part of every fragment address: tile parity kh -> 2 pixels to the right, channel r (+32 for the second half)
     const int a_lane = (2 * kh) * WW_PS + r * 4;
     const int b_lane1 = WW_ABYTES + (a1 * WW_BW + 2 * kh) * WW_PS + r * 4, b_lane2 = WW_ABYTES + (a2 * WW_BW + 2 * kh) * WW_PS + r * 4;
@@ -598,7 +604,7 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const WinoWgradParam
             const float rc1_ = fmaf(c1f, raw[z_][hf_][3], c0f * raw[z_][hf_][1]);                                  \
             Yt[z_][0][hf_] = rc0_; Yt[z_][1][hf_] = rc0_ + rc1_; Yt[z_][2][hf_] = rc0_ - rc1_; Yt[z_][3][hf_] = -rc1_; \
             float t_[4];                                                                                           \
-            _Pragma("unroll") for (int bc_ = 0; bc_ < 4; ++bc_) t_[bc_] = fmaf(s2, rawb[z_][hf_][4 + bc_], s1 * rawb[z_][hf_][bc_]); \
+            _Pragma("unroll") for (int bc_ = 0; bc_ < 4; ++bc_) t_[bc_] = fmaf(s2, rawb[z_][hf_][4 + bc_], rawb[z_][hf_][bc_]); \
             V[z_][0][hf_] = t_[0] - t_[2]; V[z_][1][hf_] = t_[1] + t_[2]; V[z_][2][hf_] = t_[2] - t_[1]; V[z_][3][hf_] = t_[1] - t_[3]; \
         }                                                                                                          \
     } while (0)
@@ -689,6 +695,8 @@ __global__ void __launch_bounds__(256) wino_wgrad_reduce_kernel(const WinoReduce
                 U[i][0] = (a.x + b.x) + (c.x + d.x); U[i][1] = (a.y + b.y) + (c.y + d.y);
                 U[i][2] = (a.z + b.z) + (c.z + d.z); U[i][3] = (a.w + b.w) + (c.w + d.w);
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) U[2][j] = -U[2][j];             // plane 2 is accumulated with the opposite sign (see wino_wgrad_kernel)
             // dg = G^T U G, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
             float t[3][4];
 #pragma unroll
