@@ -543,7 +543,10 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const WinoWgradParam
     };
 
     // wave row i = w: coefficients of the two transforms
-    const float c0f = w == 3 ? 0.f : 1.f, c1f = w == 0 ? 0.f : (w == 1 ? 1.f : -1.f);          // A[w] = (c0, c1)
+    // A rows (1,0), (1,1), (1,-1), (0,-1): rc[q] = gA[q] + c1f * g1[q] with gA = g0 (rows 0-2) or g1 (row 3, c1f = 0: the
+    // row comes out as +g1 and the reduce flips plane 3), one fma per element with a per-wave LDS row instead of mul + fma
+    const float c1f = w == 1 ? 1.f : (w == 2 ? -1.f : 0.f);
+    const int a_rowA = w == 3 ? 2 * WW_TX * WW_PS : 0;                  // byte offset of the row that supplies gA
     const int a1 = w == 0 ? 0 : 1, a2 = w == 3 ? 3 : 2;                                          // B^T[w]: rows a1, a2
     // as in wino_kernel: every B^T row is d[a1] + s2 * d[a2]; row 2 comes out negated and wino_wgrad_reduce_kernel flips
     // plane 2 back (one fma per element instead of a multiply and an fma)
@@ -585,8 +588,8 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const WinoWgradParam
         constexpr int apix_ = (2 * ty_) * (2 * WW_TX) + 2 * tx2_, bpix_ = (2 * ty_) * WW_BW + 2 * tx2_;            \
         _Pragma("unroll") for (int hf_ = 0; hf_ < 2; ++hf_) {                                                      \
             const char* ap_ = sm + a_lane + apix_ * WW_PS + 128 * hf_;                                             \
-            raw[z_][hf_][0] = *reinterpret_cast<const float*>(ap_);                                                \
-            raw[z_][hf_][1] = *reinterpret_cast<const float*>(ap_ + WW_PS);                                        \
+            raw[z_][hf_][0] = *reinterpret_cast<const float*>(ap_ + a_rowA);                                       \
+            raw[z_][hf_][1] = *reinterpret_cast<const float*>(ap_ + a_rowA + WW_PS);                               \
             raw[z_][hf_][2] = *reinterpret_cast<const float*>(ap_ + 2 * WW_TX * WW_PS);                            \
             raw[z_][hf_][3] = *reinterpret_cast<const float*>(ap_ + (2 * WW_TX + 1) * WW_PS);                      \
             const char* bp1_ = sm + b_lane1 + bpix_ * WW_PS + 128 * hf_;                                           \
@@ -600,9 +603,9 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const WinoWgradParam
 #define WW_TRANSFORM(z_)                                                                                           \
     do {                                                                                                           \
         _Pragma("unroll") for (int hf_ = 0; hf_ < 2; ++hf_) {                                                      \
-            const float rc0_ = fmaf(c1f, raw[z_][hf_][2], c0f * raw[z_][hf_][0]);                                  \
-            const float rc1_ = fmaf(c1f, raw[z_][hf_][3], c0f * raw[z_][hf_][1]);                                  \
-            Yt[z_][0][hf_] = rc0_; Yt[z_][1][hf_] = rc0_ + rc1_; Yt[z_][2][hf_] = rc0_ - rc1_; Yt[z_][3][hf_] = -rc1_; \
+            const float rc0_ = fmaf(c1f, raw[z_][hf_][2], raw[z_][hf_][0]);                                        \
+            const float rc1_ = fmaf(c1f, raw[z_][hf_][3], raw[z_][hf_][1]);                                        \
+            Yt[z_][0][hf_] = rc0_; Yt[z_][1][hf_] = rc0_ + rc1_; Yt[z_][2][hf_] = rc0_ - rc1_; Yt[z_][3][hf_] = rc1_;  /* column 3: sign in the reduce */ \
             float t_[4];                                                                                           \
             _Pragma("unroll") for (int bc_ = 0; bc_ < 4; ++bc_) t_[bc_] = fmaf(s2, rawb[z_][hf_][4 + bc_], rawb[z_][hf_][bc_]); \
             V[z_][0][hf_] = t_[0] - t_[2]; V[z_][1][hf_] = t_[1] + t_[2]; V[z_][2][hf_] = t_[2] - t_[1]; V[z_][3][hf_] = t_[1] - t_[3]; \
@@ -696,7 +699,12 @@ __global__ void __launch_bounds__(256) wino_wgrad_reduce_kernel(const WinoReduce
                 U[i][2] = (a.z + b.z) + (c.z + d.z); U[i][3] = (a.w + b.w) + (c.w + d.w);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) U[2][j] = -U[2][j];             // plane 2 is accumulated with the opposite sign (see wino_wgrad_kernel)
+            for (int j = 0; j < 4; ++j) {       // signs left out of wino_wgrad_kernel's transforms: planes 2, 3 and column 3
+                U[2][j] = -U[2][j];
+                U[3][j] = -U[3][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) U[i][3] = -U[i][3];
             // dg = G^T U G, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
             float t[3][4];
 #pragma unroll
