@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
             for (int j = 0; j < NJI; ++j) ri[j] = buf_ld16(xrs, live ? in_vo[j] : BUF_OOB, so);
             const unsigned wv = live ? w_vo0 : BUF_OOB;
     #pragma unroll
-            for (int j = 0; j < 8; ++j) rww[j] = buf_ld16(wrs, wv + j * w_vstep, (unsigned)k * w_chunk);
+            for (int j = 0; j < 8; ++j) rww[j] = buf_ld16(wrs, wv, (unsigned)k * w_chunk + j * w_vstep);   // j-step in the SCALAR offset: no VALU add per load
         };
         auto lds_store_from = [&](int st, const uint4 (&ri)[NJI], const uint4 (&rww)[8]) {
             uint4* sm = smem + st * WN_STAGE;
