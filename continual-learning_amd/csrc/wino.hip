@@ -485,6 +485,10 @@ constexpr int WW_PS = 256;                                            // bytes p
 constexpr int WW_ABYTES = WW_APIX * WW_PS, WW_STAGE = (WW_APIX + WW_BPIX) * WW_PS;   // 32 KB + 45 KB
 constexpr int WW_NJA = WW_APIX * 16 / 256, WW_NJB = (WW_BPIX * 16 + 255) / 256;      // 8 + 12 staging loads per thread
 
+// RAGGED = false (H % 8 == 0 and W % 16 == 0: every pixel tile lies inside the image): the 20 per-lane staging offsets
+// are computed ONCE; per tile only the image-border lanes of the halo are switched off (four per-lane bit masks x four
+// wave-uniform tile flags) -- address and edge arithmetic was ~170 of the ~550 VALU instructions per tile.
+template <bool RAGGED>
 __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const WinoWgradParams p) {
     static_assert(2 * WW_STAGE <= 160 * 1024, "two stages must fit one CU");
     __shared__ __attribute__((aligned(16))) char smem[2 * WW_STAGE];
@@ -506,11 +510,43 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(const WinoWgradParam
     const unsigned a_img = (unsigned)p.H * p.W * p.a_ldc * 4u, b_img = (unsigned)p.H * p.W * p.b_ldc * 4u;
     const unsigned b_shift = (unsigned)(p.W + 1) * p.b_ldc * 4u;      // descriptor base sits one row + one pixel early
     uint4 ra[WW_NJA], rb[WW_NJB];
+    // tile-invariant staging offsets (used when !RAGGED) and the border masks of the halo pieces: bit j of mT / mB / mL /
+    // mR = piece j of this lane is in the first / last halo row / column
+    unsigned a_vo[RAGGED ? 1 : WW_NJA], b_vo[RAGGED ? 1 : WW_NJB];
+    unsigned mT = 0, mB = 0, mL = 0, mR = 0;
+    if constexpr (!RAGGED) {
+        const int g = tid & 15;
+#pragma unroll
+        for (int j = 0; j < WW_NJA; ++j) {
+            const int pix = (tid >> 4) + 16 * j, py = pix / (2 * WW_TX), px = pix % (2 * WW_TX);
+            a_vo[j] = r0 + 4 * g < p.Rp ? (unsigned)(((py * p.W + px) * p.a_ldc + r0 + 4 * g) * 4) : BUF_OOB;
+        }
+#pragma unroll
+        for (int j = 0; j < WW_NJB; ++j) {
+            int pix = (tid >> 4) + 16 * j;
+            if (pix >= WW_BPIX) pix -= WW_BPIX;
+            const int hy = pix / WW_BW, hx = pix % WW_BW;
+            b_vo[j] = c0 + 4 * g < p.Cp ? (unsigned)(((hy * p.W + hx) * p.b_ldc + c0 + 4 * g) * 4) : BUF_OOB;
+            mT |= (hy == 0 ? 1u : 0u) << j; mB |= (hy == WW_BH - 1 ? 1u : 0u) << j;
+            mL |= (hx == 0 ? 1u : 0u) << j; mR |= (hx == WW_BW - 1 ? 1u : 0u) << j;
+        }
+    }
     auto gload = [&](int tile, bool live) {                            // piece = tid + 256*j: 16 lanes = the 256 bytes of one pixel
         const int x0 = (tile % tiles_x) * (2 * WW_TX), y0 = ((tile / tiles_x) % tiles_y) * (2 * WW_TY), b = live ? tile / (tiles_x * tiles_y) : 0;
         const __amdgpu_buffer_rsrc_t ars = make_rsrc((const char*)p.a + (size_t)b * a_img, a_img);
         const __amdgpu_buffer_rsrc_t brs = make_rsrc((const char*)p.b + (size_t)b * b_img - b_shift, b_img + b_shift);
         const unsigned a_so = (unsigned)((y0 * p.W + x0) * p.a_ldc) * 4u, b_so = (unsigned)((y0 * p.W + x0) * p.b_ldc) * 4u;
+        if constexpr (!RAGGED) {
+            // a dead load (past the last tile of this split) gets an EMPTY descriptor: every lane out of range, no traffic
+            const __amdgpu_buffer_rsrc_t ars2 = make_rsrc((const char*)p.a + (size_t)b * a_img, live ? a_img : 0u);
+            const __amdgpu_buffer_rsrc_t brs2 = make_rsrc((const char*)p.b + (size_t)b * b_img - b_shift, live ? b_img + b_shift : 0u);
+            const unsigned em = (y0 == 0 ? mT : 0u) | (y0 + 2 * WW_TY == p.H ? mB : 0u) | (x0 == 0 ? mL : 0u) | (x0 + 2 * WW_TX == p.W ? mR : 0u);
+#pragma unroll
+            for (int j = 0; j < WW_NJA; ++j) ra[j] = buf_ld16(ars2, a_vo[j], a_so);
+#pragma unroll
+            for (int j = 0; j < WW_NJB; ++j) rb[j] = buf_ld16(brs2, (em >> j) & 1u ? BUF_OOB : b_vo[j], b_so);
+            return;
+        }
         const int g = tid & 15;
 #pragma unroll
         for (int j = 0; j < WW_NJA; ++j) {
@@ -765,7 +801,8 @@ int clamd_wgrad_winograd(const float* gz, int gz_ldc, const float* x, int x_ldc,
     if ((size_t)nsplit * 16 * Rp * Cp * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd: workspace too small");
     WinoWgradParams p{gz, gz_ldc, x, x_ldc, workspace, B, H, W, Rp, Cp, nsplit, per};
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(rt * ct * nsplit), dim3(256), 0, s, p);
+    if (H % (2 * WW_TY) || W % (2 * WW_TX)) hipLaunchKernelGGL(wino_wgrad_kernel<true>, dim3(rt * ct * nsplit), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(wino_wgrad_kernel<false>, dim3(rt * ct * nsplit), dim3(256), 0, s, p);
     if (int e = clamd_check_launch("wgrad_winograd")) return e;
     WinoReduceParams rp{workspace, out, nsplit, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p};
     long long g = ((long long)Rp * Cp + 15) / 16;
