@@ -53,7 +53,9 @@ constexpr int WN_EXP = 36;                                    // row pitch (floa
 
 // MT = 32-tile halves per workgroup: 2 -> 8x8 Winograd tiles = 16x16 output pixels; 1 -> 4x8 tiles = 8x16 pixels (used when
 // the 16x16 grid would leave CUs without a workgroup)
-template <int MT>
+// RAGGED = false: H, W multiples of the tile and Cout_p a multiple of 64 -- the 16 output stores of a tile and their
+// statistics need no range predicate.
+template <int MT, bool RAGGED>
 __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
     constexpr int WN_HH = 8 * MT + 2, WN_PIX = WN_HW * WN_HH;             // input halo of the output tile
     constexpr int WN_PIXP = WN_PIX + ((10 - WN_PIX % 8) % 8);             // == 2 (mod 8): conflict-free staging stores
@@ -445,8 +447,11 @@ int clamd_conv3x3_winograd(const float* x, int x_ldc, const float* w_wino, const
     p.band = wino_band((mt2 ? nblk2 : nblk1) / ntn, ntn, (double)B * H * W * Cin_p, 16.0 * Cin_p * Cout_p);
     p.nblk = (int)(mt2 ? nblk2 : nblk1);
     const unsigned grid = g_wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_num_cus()) : (unsigned)p.nblk;
-    if (mt2) hipLaunchKernelGGL((wino_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((wino_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    const bool ragged = (H % (mt2 ? 16 : 8)) != 0 || (W % 16) != 0 || (Cout_p % 64) != 0;
+#define WN_LAUNCH(MT_, RG_) hipLaunchKernelGGL((wino_kernel<MT_, RG_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p)
+    if (mt2) { if (ragged) WN_LAUNCH(2, true); else WN_LAUNCH(2, false); }
+    else { if (ragged) WN_LAUNCH(1, true); else WN_LAUNCH(1, false); }
+#undef WN_LAUNCH
     return clamd_check_launch("conv3x3_winograd");
 }
 
