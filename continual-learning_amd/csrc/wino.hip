@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
         const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x + (size_t)b * img, img);
 #endif
         const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.w, (unsigned)(16u * p.Np * p.Kp * 4u));
+        const __amdgpu_buffer_rsrc_t xrs_dead = make_rsrc(p.x, 0u), wrs_dead = make_rsrc(p.w, 0u);
         unsigned in_vo[NJI];
         int in_slot[NJI];
     #pragma unroll
@@ -123,11 +124,13 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
         uint4 rin[NJI], rw[8];
         auto gload_to = [&](int k, bool live, uint4 (&ri)[NJI], uint4 (&rww)[8]) {
             const unsigned so = (unsigned)(k * 8 * 4);
+            // loads past the last chunk use EMPTY descriptors (every lane out of range, no traffic): a scalar select
+            // instead of a per-lane one on each offset
+            const __amdgpu_buffer_rsrc_t xr = live ? xrs : xrs_dead, wr = live ? wrs : wrs_dead;
     #pragma unroll
-            for (int j = 0; j < NJI; ++j) ri[j] = buf_ld16(xrs, live ? in_vo[j] : BUF_OOB, so);
-            const unsigned wv = live ? w_vo0 : BUF_OOB;
+            for (int j = 0; j < NJI; ++j) ri[j] = buf_ld16(xr, in_vo[j], so);
     #pragma unroll
-            for (int j = 0; j < 8; ++j) rww[j] = buf_ld16(wrs, wv, (unsigned)k * w_chunk + j * w_vstep);   // j-step in the SCALAR offset: no VALU add per load
+            for (int j = 0; j < 8; ++j) rww[j] = buf_ld16(wr, w_vo0, (unsigned)k * w_chunk + j * w_vstep);   // j-step in the SCALAR offset: no VALU add per load
         };
         auto lds_store_from = [&](int st, const uint4 (&ri)[NJI], const uint4 (&rww)[8]) {
             uint4* sm = smem + st * WN_STAGE;
