@@ -14,8 +14,37 @@ F32, BF16, SPLIT = 0, 1, 2      # SPLIT = 'bf16x3': fp32 storage, 3-term split-b
 WGRAD_CONV3, WGRAD_PW, WGRAD_UP2 = 0, 1, 2
 
 _P, _I, _D, _LL, _SZ = c_void_p, c_int, c_double, c_longlong, c_size_t
+OP_CONV3X3, OP_CONV3X3_WINOGRAD, OP_CONV1X1, OP_CONVT2X2_DGRAD, OP_BN_BWD_REDUCE = range(5)
 
-# name -> (restype, argtypes); must list EVERY symbol of include/clamd.h (tests/test_abi.py checks the header).
+
+class Tuning(ctypes.Structure):
+    """Mirror of `clamd_tuning` (include/clamd.h): per-call kernel-structure selection.  The library keeps no process
+    state; an engine owns one of these and passes it to every launch (None = library defaults)."""
+    _fields_ = [(n, c_int) for n in ('igemm_pws', 'igemm_ws', 'igemm_variant', 'pws_wres', 'wgrad_ws', 'wgrad_dma',
+                                     'wgrad_xcd', 'wgrad_blocks', 'wgrad_tw16', 'wino_band', 'wino_persist', 'wino_mt',
+                                     'bn_reduce_blocks', 'chsum_blocks', 'cu_reserve')] + [('reserved', c_int * 9)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        load().clamd_tuning_init(ctypes.byref(self))
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise KeyError(f'unknown tuning field {k!r}')
+            setattr(self, k, int(v))
+
+    def ref(self):
+        return ctypes.addressof(self)
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != 'reserved'}
+
+
+def tune_ptr(t):
+    """`const clamd_tuning*` argument for a Tuning object (None -> NULL = library defaults)."""
+    return None if t is None else t.ref()
+
+
+# name -> (restype, argtypes); must list EVERY symbol of include/clamd.h (tests/test_host_cpu.py checks the header).
 SIGNATURES = {
     'clamd_last_error': (c_char_p, []),
     'clamd_version': (_I, []),
@@ -23,21 +52,24 @@ SIGNATURES = {
     'clamd_sizeof_adam_tensor': (_I, []),
     'clamd_adam_chunk_elems': (_I, []),
     'clamd_pack_tile': (_I, []),
-    'clamd_stat_replicas': (_I, []),
     'clamd_bn_bwd_nsums': (_I, []),
-    'clamd_conv3x3': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    'clamd_conv1x1': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_sizeof_tuning': (_I, []),
+    'clamd_tuning_init': (None, [_P]),
+    'clamd_stat_rows': (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_conv3x3': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'clamd_conv1x1': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_conv1x1_logits': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_convT2x2_fwd': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    'clamd_convT2x2_dgrad': (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_convT2x2_dgrad': (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_wgrad_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
-    'clamd_wgrad': (_I, [_I, _P, _I, _P, _I, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    'clamd_bn_finalize': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _P]),
+    'clamd_wgrad': (_I, [_I, _P, _I, _P, _I, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'clamd_bn_finalize': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _P]),
     'clamd_bn_apply': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
-    'clamd_bn_bwd_reduce': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    'clamd_bn_bwd_finalize': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _P]),
+    'clamd_bn_bwd_reduce': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'clamd_bn_bwd_finalize': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _P]),
     'clamd_bn_bwd_apply': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    'clamd_channel_sum': (_I, [_P, _I, _P, _LL, _I, _I, _I, _P]),
+    'clamd_channel_sum_workspace_bytes': (_SZ, [_I]),
+    'clamd_channel_sum': (_I, [_P, _I, _P, _LL, _I, _I, _I, _P, _SZ, _P, _P]),
     'clamd_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _D, _I, _P]),
     'clamd_nhwc_to_nchw': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'clamd_nchw_im2col3': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -45,8 +77,8 @@ SIGNATURES = {
     'clamd_sizeof_wino_pack_job': (_I, []),
     'clamd_wino_pack': (_I, [_P, _I, _I, _P]),
     'clamd_wgrad_winograd_workspace_bytes': (_SZ, [_I, _I]),
-    'clamd_wgrad_winograd': (_I, [_P, _I, _P, _I, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    'clamd_conv3x3_winograd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_wgrad_winograd': (_I, [_P, _I, _P, _I, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'clamd_conv3x3_winograd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_ce_workspace_bytes': (_SZ, []),
     'clamd_ce_fwd_bwd': (_I, [_P, _P, _P, _I, _I, _D, _D, _P, _P, _P, _SZ, _I, _I, _I, _I, _LL, _D, _P]),
     'clamd_adam_step': (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
@@ -54,7 +86,6 @@ SIGNATURES = {
     'clamd_voc_prepare': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_label_to_rgb': (_I, [_P, _P, _LL, _LL, _P]),
     'clamd_fill_f32': (_I, [_P, _LL, _D, _P]),
-    'clamd_set_tuning': (_I, [c_char_p, _I]),
 }
 
 _lib = None
@@ -86,6 +117,14 @@ def check(rc, what=''):
 def call(name, *args):
     """Invoke a status-returning entry point and raise on error."""
     check(getattr(load(), name)(*args), name)
+
+
+def stat_rows(op, B, H, W, cin_p, cout_p, dcode, fused_bn=False, tuning=None):
+    """Partial-statistics rows a launch of `op` writes (clamd_stat_rows); raises on error."""
+    n = load().clamd_stat_rows(op, B, H, W, cin_p, cout_p, dcode, 1 if fused_bn else 0, tune_ptr(tuning))
+    if n <= 0:
+        check(n, 'clamd_stat_rows')
+    return n
 
 
 def ptr(t):

@@ -207,6 +207,4 @@ __device__ inline void sched_mfma_slots() {
     }
 }
 
-constexpr int STAT_REPLICAS = 16;   // per-channel atomic accumulators are replicated to spread contention
-
 }  // namespace clamd

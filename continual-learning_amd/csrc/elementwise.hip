@@ -9,39 +9,66 @@
 namespace clamd {
 
 // ------------------------------------------------------------------------------------------------
-// BN finalise: replicas of (sum, sumsq) -> mean / invstd / scale / shift, running-stat update.
+// Fixed-order sum of partial rows [row][NK][Cp] for the 8 channels c0..c0+7 of this block (256 threads): thread
+// (row lane, column) adds its rows in ascending order into four interleaved fp64 chains, the row lanes are then added in
+// ascending order.  The result depends only on (nrows, data): two runs are bit-identical (no float atomics anywhere).
+template <int NK>
+__device__ inline void sum_partial_rows(const float* __restrict__ rows, int nrows, int Cp, int c0, double* red, double* out) {
+    constexpr int COLS = NK * 8, RL = 256 / COLS;
+    const int t = threadIdx.x, col = t % COLS, rl = t / COLS;
+    if (rl < RL) {
+        const float* p = rows + (size_t)(col >> 3) * Cp + c0 + (col & 7);
+        const size_t rs = (size_t)NK * Cp;
+        double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+        int r = rl;
+        for (; r + 3 * RL < nrows; r += 4 * RL) {
+            a0 += (double)p[(size_t)r * rs]; a1 += (double)p[(size_t)(r + RL) * rs];
+            a2 += (double)p[(size_t)(r + 2 * RL) * rs]; a3 += (double)p[(size_t)(r + 3 * RL) * rs];
+        }
+        for (; r < nrows; r += RL) a0 += (double)p[(size_t)r * rs];
+        red[rl * COLS + col] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if (t < COLS) {
+        double v = 0.;
+        for (int q = 0; q < RL; ++q) v += red[q * COLS + t];
+        out[t] = v;
+    }
+    __syncthreads();
+}
+
+// BN finalise: partial rows of (sum, sumsq) -> mean / invstd / scale / shift, running-stat update.  One block per 8 channels.
 // Reference: nn.BatchNorm2d train mode, models/unet.py:15 (momentum 0.1, eps 1e-5, unbiased running var).
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
+// Mean and variance are formed in fp64 from the fp64 row sums (E[x^2] - mean^2 cancels in fp32 on low-variance channels).
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ stats, int nrows, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    float* scale, float* shift, float* save_mean, float* save_istd,
-                                   int Cp, int C, float count, float momentum, float eps) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cp) return;
-    float mean, var;
+                                   int Cp, int C, double count, double momentum, double eps) {
+    __shared__ double red[256], tot[16];
+    const int c0 = blockIdx.x * 8;
+    if (stats) sum_partial_rows<2>(stats, nrows, Cp, c0, red, tot);
+    if (threadIdx.x >= 8) return;
+    const int c = c0 + threadIdx.x;
+    double mean, var;
     if (stats) {
-        float s = 0.f, q = 0.f;
-        for (int r = 0; r < STAT_REPLICAS; ++r) {
-            s += stats[(r * 2 + 0) * Cp + c];
-            q += stats[(r * 2 + 1) * Cp + c];
-        }
-        mean = s / count;
-        var = fmaxf(q / count - mean * mean, 0.f);
+        mean = tot[threadIdx.x] / count;
+        var = tot[8 + threadIdx.x] / count - mean * mean;
+        var = var > 0. ? var : 0.;
     } else {   // eval mode (trainer.py:271): normalise with the running statistics, update nothing
-        mean = c < C ? running_mean[c] : 0.f;
-        var = c < C ? running_var[c] : 1.f;
+        mean = c < C ? (double)running_mean[c] : 0.;
+        var = c < C ? (double)running_var[c] : 1.;
     }
-    float istd = rsqrtf(var + eps);
-    istd = istd * (1.5f - 0.5f * (var + eps) * istd * istd);   // one Newton step: rsqrtf is approximate
-    float g = c < C ? gamma[c] : 0.f, b = c < C ? beta[c] : 0.f;
-    float sc = g * istd;
+    const double istd = 1.0 / sqrt(var + eps);
+    const double g = c < C ? (double)gamma[c] : 0., b = c < C ? (double)beta[c] : 0.;
+    const float sc = (float)(g * istd);
     scale[c] = sc;
-    shift[c] = b - mean * sc;
-    save_mean[c] = mean;
-    save_istd[c] = istd;
+    shift[c] = (float)(b - mean * (g * istd));
+    save_mean[c] = (float)mean;
+    save_istd[c] = (float)istd;
     if (c < C && running_mean && stats) {
-        float unb = count > 1.f ? var * (count / (count - 1.f)) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+        const double unb = count > 1. ? var * (count / (count - 1.)) : var;
+        running_mean[c] = (float)((1. - momentum) * (double)running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1. - momentum) * (double)running_var[c] + momentum * unb);
     }
 }
 
@@ -179,8 +206,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
             }
         }
     }
-    // block reduction over the threads that share a channel group, one sum kind at a time
-    float* dst = sums + (size_t)(blockIdx.x % STAT_REPLICAS) * NSUM * Cp;
+    // block reduction over the threads that share a channel group, one sum kind at a time; this block's partial row
+    float* dst = sums + (size_t)blockIdx.x * NSUM * Cp;
 #pragma unroll
     for (int s = 0; s < NSUM; ++s) {
         __syncthreads();
@@ -192,37 +219,37 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
             const int g8 = c >> 3, j = c & 7;
             float t = 0.f;
             for (int r = 0; r < rows; ++r) t += red[(r * G + g8) * 8 + j];
-            atomicAdd(dst + s * Cp + c, t);
+            dst[s * Cp + c] = t;
         }
     }
 }
 
-// sums (replicated) -> k0,k1,k2 per channel, and the parameter gradients d_gamma, d_beta, d_convbias.
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+// partial rows of the five sums -> k0,k1,k2 per channel, and the parameter gradients d_gamma, d_beta, d_convbias.
+// One block per 8 channels; fixed-order fp64 row sums (sum_partial_rows), coefficients formed in fp64.
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ sums, int nrows, const float* __restrict__ gamma,
                                        const float* __restrict__ save_mean, const float* __restrict__ save_istd,
                                        float* k012, float* dgamma, float* dbeta, float* dbias, int Cp, int C,
-                                       float count) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Cp) return;
-    float s[NSUM];
+                                       double count) {
+    __shared__ double red[256], tot[NSUM * 8];
+    const int c0 = blockIdx.x * 8;
+    sum_partial_rows<NSUM>(sums, nrows, Cp, c0, red, tot);
+    if (threadIdx.x >= 8) return;
+    const int c = c0 + threadIdx.x;
+    double s[NSUM];
 #pragma unroll
-    for (int k = 0; k < NSUM; ++k) {
-        float t = 0.f;
-        for (int r = 0; r < STAT_REPLICAS; ++r) t += sums[((size_t)r * NSUM + k) * Cp + c];
-        s[k] = t;
-    }
-    const float mu = save_mean[c], istd = save_istd[c];
-    const float g = c < C ? gamma[c] : 0.f;
-    const float inv_n = 1.f / count;
-    const float k0 = g * istd;
-    const float c2 = istd * istd * (s[1] * inv_n - mu * s[0] * inv_n);
-    const float k1 = -k0 * c2;
-    const float k2 = k0 * (mu * c2 - s[0] * inv_n);
-    k012[c] = k0; k012[Cp + c] = k1; k012[2 * Cp + c] = k2;
+    for (int k = 0; k < NSUM; ++k) s[k] = tot[k * 8 + threadIdx.x];
+    const double mu = save_mean[c], istd = save_istd[c];
+    const double g = c < C ? (double)gamma[c] : 0.;
+    const double inv_n = 1. / count;
+    const double k0 = g * istd;
+    const double c2 = istd * istd * (s[1] * inv_n - mu * s[0] * inv_n);
+    const double k1 = -k0 * c2;
+    const double k2 = k0 * (mu * c2 - s[0] * inv_n);
+    k012[c] = (float)k0; k012[Cp + c] = (float)k1; k012[2 * Cp + c] = (float)k2;
     if (c < C) {
-        dgamma[c] = istd * (s[1] - mu * s[0]);
-        dbeta[c] = s[0];
-        dbias[c] = k0 * s[2] + k1 * s[4] + k2 * s[3];
+        dgamma[c] = (float)(istd * (s[1] - mu * s[0]));
+        dbeta[c] = (float)s[0];
+        dbias[c] = (float)(k0 * s[2] + k1 * s[4] + k2 * s[3]);
     }
 }
 
@@ -292,11 +319,11 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ ga, int ga_ldc, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Per-channel sum of an NHWC tensor (bias gradients of convT / head): out[c] += sum_p g[p,c] (atomic, out
-// must be zeroed by the caller).
+// Per-channel sum of an NHWC tensor (bias gradients of convT / head): every block writes its partial row [Cp] into the
+// workspace, channel_sum_final_kernel adds the rows in a fixed order (fp64) and OVERWRITES out[c].
 template <typename T>
-__global__ void __launch_bounds__(256) channel_sum_kernel(const T* __restrict__ g, int ldc, float* out,
-                                                          long long npix, int Cp, int C) {
+__global__ void __launch_bounds__(256) channel_sum_kernel(const T* __restrict__ g, int ldc, float* partial,
+                                                          long long npix, int Cp) {
     __shared__ float red[256 * 8];
     const int G = Cp >> 3, tid = threadIdx.x;
     const int cg = tid % G, rows = 256 / G, prow = tid / G;
@@ -314,8 +341,15 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const T* __restrict__ 
         const int g8 = c >> 3, j = c & 7;
         float t = 0.f;
         for (int r = 0; r < rows; ++r) t += red[(r * G + g8) * 8 + j];
-        if (c < C) atomicAdd(out + c, t);
+        partial[(size_t)blockIdx.x * Cp + c] = t;
     }
+}
+
+__global__ void __launch_bounds__(256) channel_sum_final_kernel(const float* __restrict__ partial, int nrows, float* out, int Cp, int C) {
+    __shared__ double red[256], tot[8];
+    const int c0 = blockIdx.x * 8;
+    sum_partial_rows<1>(partial, nrows, Cp, c0, red, tot);
+    if (threadIdx.x < 8 && c0 + threadIdx.x < C) out[c0 + threadIdx.x] = (float)tot[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -380,11 +414,9 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int ldc, float* d
     }
 }
 
-// Grid caps of the two per-channel reductions (0 = per-launch choice): every block ends with one atomic per channel
-// and sum kind, so with many channels the tail, not the streaming part, sets the time (1024 channels at 16x16:
-// 39.5 us with 2048 blocks, 8.8 us with 256).
-int g_bn_reduce_blocks = 0;       // tuning knob "bn_reduce_blocks"
-int g_chsum_blocks = 0;           // tuning knob "chsum_blocks"
+// Grid caps of the two per-channel reductions (clamd_tuning::bn_reduce_blocks / chsum_blocks, 0 = per-launch choice):
+// every block ends with one partial row per sum kind that the finalize kernel has to add, so with many channels the tail,
+// not the streaming part, sets the time (1024 channels at 16x16: 39.5 us with 2048 blocks, 8.8 us with 256).
 static inline long long reduce_grid_cap(int forced, int Cp, int lo, int hi, int budget) {
     if (forced > 0) return forced;
     long long c = budget / Cp;
@@ -401,15 +433,24 @@ static inline int ew_grid(long long nitem, int cap = 4096) {
 }
 static bool pow2_channels(int Cp) { return Cp >= 32 && Cp <= 2048 && (Cp & (Cp - 1)) == 0; }
 
+long long clamd_bn_bwd_reduce_rows(int B, int H, int W, int Cp, bool pooled, const clamd_tuning& tn) {
+    const int rows = 256 / (Cp / 8) > 0 ? 256 / (Cp / 8) : 1;
+    const long long npix = pooled ? (long long)B * (H / 2) * (W / 2) : (long long)B * H * W;
+    const long long gb = (npix + rows - 1) / rows;
+    const long long cap = reduce_grid_cap(tn.bn_reduce_blocks, Cp, 256, 1024, 131072);
+    return gb > cap ? cap : (gb < 1 ? 1 : gb);
+}
+constexpr int CHSUM_MAX_BLOCKS = 1024;
+
 extern "C" {
 
-int clamd_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
+int clamd_bn_finalize(const float* stats, int stat_rows, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float* scale, float* shift, float* save_mean, float* save_istd,
                       int Cp, int C, double count, double momentum, double eps, void* stream) {
-    if (Cp <= 0 || C > Cp) return clamd_fail("bn_finalize: bad channel counts");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((Cp + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, gamma,
-                       beta, running_mean, running_var, scale, shift, save_mean, save_istd, Cp, C, (float)count,
-                       (float)momentum, (float)eps);
+    if (Cp <= 0 || Cp % 8 || C > Cp) return clamd_fail("bn_finalize: bad channel counts");
+    if (stats && stat_rows <= 0) return clamd_fail("bn_finalize: stat_rows must be the row count the producing launch wrote");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(Cp / 8), dim3(256), 0, (hipStream_t)stream, stats, stat_rows, gamma,
+                       beta, running_mean, running_var, scale, shift, save_mean, save_istd, Cp, C, count, momentum, eps);
     return clamd_check_launch("bn_finalize");
 }
 
@@ -430,15 +471,14 @@ int clamd_bn_apply(const void* y, int y_ldc, const float* scale, const float* sh
 }
 
 int clamd_bn_bwd_reduce(const void* ga, int ga_ldc, const void* gp, int gp_ldc, const void* y, int y_ldc,
-                        const float* scale, const float* shift, float* sums, int B, int H, int W, int Cp,
-                        int dtype, void* stream) {
+                        const float* scale, const float* shift, float* sums, int sum_rows, int B, int H, int W, int Cp,
+                        int dtype, const clamd_tuning* tune, void* stream) {
     if (!pow2_channels(Cp)) return clamd_fail("bn_bwd_reduce: physical channels must be a power of two in [32,2048]");
     if (!gp && !ga) return clamd_fail("bn_bwd_reduce: no gradient source");
-    const int rows = 256 / (Cp / 8) > 0 ? 256 / (Cp / 8) : 1;
-    const long long npix = gp ? (long long)B * (H / 2) * (W / 2) : (long long)B * H * W;
-    long long gb = (npix + rows - 1) / rows;
-    const long long cap = reduce_grid_cap(g_bn_reduce_blocks, Cp, 256, 1024, 131072);
-    dim3 g((unsigned)(gb > cap ? cap : gb)), b(256);
+    if (int e = clamd_check_tuning(tune)) return e;
+    const long long nrows = clamd_bn_bwd_reduce_rows(B, H, W, Cp, gp != nullptr, clamd_tune(tune));
+    if (sum_rows != nrows) return clamd_fail("bn_bwd_reduce: sum_rows does not match clamd_stat_rows(CLAMD_OP_BN_BWD_REDUCE, ...)");
+    dim3 g((unsigned)nrows), b(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(T, P) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, P>), g, b, 0, s, (const T*)ga, ga_ldc, \
                                         (const T*)gp, gp_ldc, (const T*)y, y_ldc, scale, shift, sums, B, H, W, Cp)
@@ -449,11 +489,13 @@ int clamd_bn_bwd_reduce(const void* ga, int ga_ldc, const void* gp, int gp_ldc, 
     return clamd_check_launch("bn_bwd_reduce");
 }
 
-int clamd_bn_bwd_finalize(const float* sums, const float* gamma, const float* save_mean, const float* save_istd,
+int clamd_bn_bwd_finalize(const float* sums, int sum_rows, const float* gamma, const float* save_mean, const float* save_istd,
                           float* k012, float* dgamma, float* dbeta, float* dbias, int Cp, int C, double count,
                           void* stream) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Cp + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums,
-                       gamma, save_mean, save_istd, k012, dgamma, dbeta, dbias, Cp, C, (float)count);
+    if (Cp <= 0 || Cp % 8 || C > Cp) return clamd_fail("bn_bwd_finalize: bad channel counts");
+    if (sum_rows <= 0) return clamd_fail("bn_bwd_finalize: sum_rows must be the row count the producing launch wrote");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(Cp / 8), dim3(256), 0, (hipStream_t)stream, sums, sum_rows,
+                       gamma, save_mean, save_istd, k012, dgamma, dbeta, dbias, Cp, C, count);
     return clamd_check_launch("bn_bwd_finalize");
 }
 
@@ -473,17 +515,26 @@ int clamd_bn_bwd_apply(const void* ga, int ga_ldc, const void* gp, int gp_ldc, c
     return clamd_check_launch("bn_bwd_apply");
 }
 
-int clamd_channel_sum(const void* g, int ldc, float* out, long long npix, int Cp, int C, int dtype, void* stream) {
+size_t clamd_channel_sum_workspace_bytes(int Cp) { return (size_t)CHSUM_MAX_BLOCKS * (Cp > 0 ? Cp : 0) * sizeof(float); }
+
+int clamd_channel_sum(const void* g, int ldc, float* out, long long npix, int Cp, int C, int dtype, float* workspace,
+                      size_t ws_bytes, const clamd_tuning* tune, void* stream) {
     if (!pow2_channels(Cp)) return clamd_fail("channel_sum: physical channels must be a power of two in [32,2048]");
+    if (C > Cp || npix <= 0) return clamd_fail("channel_sum: bad sizes");
+    if (int e = clamd_check_tuning(tune)) return e;
     const int rows = 256 / (Cp / 8) > 0 ? 256 / (Cp / 8) : 1;
     long long gb = (npix + rows - 1) / rows;
-    const long long cap = reduce_grid_cap(g_chsum_blocks, Cp, 128, 256, 65536);     // one atomic per channel and block, NO replicas
-    dim3 gr((unsigned)(gb > cap ? cap : gb)), b(256);
+    const long long cap = reduce_grid_cap(clamd_tune(tune).chsum_blocks, Cp, 128, 256, 65536);
+    if (gb > cap) gb = cap;
+    if (!workspace || (size_t)gb * Cp * sizeof(float) > ws_bytes) return clamd_fail("channel_sum: workspace too small (clamd_channel_sum_workspace_bytes)");
+    dim3 gr((unsigned)gb), b(256);
+    hipStream_t s = (hipStream_t)stream;
     if (dtype == CLAMD_BF16)
-        hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, gr, b, 0, (hipStream_t)stream, (const bf16_t*)g, ldc, out, npix, Cp, C);
+        hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, gr, b, 0, s, (const bf16_t*)g, ldc, workspace, npix, Cp);
     else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT)
-        hipLaunchKernelGGL(channel_sum_kernel<float>, gr, b, 0, (hipStream_t)stream, (const float*)g, ldc, out, npix, Cp, C);
+        hipLaunchKernelGGL(channel_sum_kernel<float>, gr, b, 0, s, (const float*)g, ldc, workspace, npix, Cp);
     else return clamd_fail("channel_sum: bad dtype");
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(Cp / 8), b, 0, s, workspace, (int)gb, out, Cp, C);
     return clamd_check_launch("channel_sum");
 }
 

@@ -19,6 +19,7 @@
 //                   UP2   (ConvTranspose2d forward: column n = (dy,dx,co) is scattered to pixel (2y+dy,2x+dx)),
 //                   NCHW  (logits head: fp32 NCHW, only the logical classes).
 #include <string.h>
+#include <stdio.h>
 #include "common.hip.h"
 #include "igemm_common.hip.h"
 #include "clamd_internal.h"
@@ -322,7 +323,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
                     const float t = sbuf[(0 * 2 + k) * 64 + c] + sbuf[(1 * 2 + k) * 64 + c] +
                                     sbuf[(2 * 2 + k) * 64 + c] + sbuf[(3 * 2 + k) * 64 + c];
                     if (n0 + c < p.Np)
-                        atomicAdd(p.stats + ((size_t)(blockIdx.x % STAT_REPLICAS) * 2 + k) * p.Np + n0 + c, t);
+                        p.stats[((size_t)tm * 2 + k) * p.Np + n0 + c] = t;          // partial row of this pixel tile
                 }
             }
         }
@@ -401,7 +402,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
                     const float t = ebuf[(0 * 5 + k) * 64 + c] + ebuf[(1 * 5 + k) * 64 + c] + ebuf[(2 * 5 + k) * 64 + c] +
                                     ebuf[(3 * 5 + k) * 64 + c];
                     if (n0 + c < p.Np)
-                        atomicAdd(p.bn_sums + ((size_t)(blockIdx.x % STAT_REPLICAS) * 5 + k) * p.Np + n0 + c, t);
+                        p.bn_sums[((size_t)tm * 5 + k) * p.Np + n0 + c] = t;
                 }
             }
         }
@@ -414,31 +415,20 @@ static_assert(Geo<MODE_CONV3, 16>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4,
 static_assert(Geo<MODE_PW, 32>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4, "LDS too small for epilogue");
 static_assert(Geo<MODE_PW, 16>::SLOTS * 16 >= (4 * 32 * 68 + 4 * 2 * 64) * 4, "LDS too small for epilogue");
 
-extern int g_wgrad_target_blocks;
-extern int g_wgrad_tw16;
-extern int g_wgrad_ws;
-extern int g_wgrad_xcd;
-extern int g_wino_band;
-extern int g_pws_wres;
-extern int g_bn_reduce_blocks;
-extern int g_chsum_blocks;
-extern int g_wino_persist;
-extern int g_wino_mt;
-extern int g_wgrad_dma;
-static int g_igemm_variant = 0;
-static int g_igemm_pws = 1;        // persistent producer/consumer kernel: 1 = short-K layers (<= 256 input channels), 2 = every layer, 0 = never
-static int g_igemm_ws = 2;         // producer/consumer kernel: 0 never, 1 / 3 / 4 always with 256- / 512- / 128-pixel tiles, 2 = heuristic:
-                                   // layers the persistent kernel does not take (> 256 input channels), with the largest tile
-                                   // that still gives every CU a workgroup (interleaved A/B: tools/conv_ab.py)
+// pixel tiles of the baseline kernel (256 pixels each) = its partial statistics rows
+static long long igemm_tiles(const IgemmParams& p) {
+    const int TW = p.W >= 32 ? 32 : 16, TH = 256 / TW;
+    return (long long)((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.B;
+}
 
 template <typename T, int MODE, int EPI>
-static int launch_tw(const IgemmParams& p, hipStream_t s) {
+static int launch_tw(const IgemmParams& p, hipStream_t s, int variant) {
     const bool wide = p.W >= 32;
     const int TW = wide ? 32 : 16, TH = 256 / TW;
     const long long tiles = (long long)((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.B;
     const long long nblk = tiles * ((p.Np + 63) / 64);
     if (nblk <= 0 || nblk > 0x7fffffff) return clamd_fail("igemm: grid out of range");
-    const int var = (MODE == MODE_CONV3 && EPI == EPI_NHWC && !__is_same(T, split_t)) ? g_igemm_variant : 0;
+    const int var = (MODE == MODE_CONV3 && EPI == EPI_NHWC && !__is_same(T, split_t)) ? variant : 0;
 #define IGEMM_LAUNCH(TW_, V_) hipLaunchKernelGGL((igemm_kernel<T, MODE, EPI, TW_, V_>), dim3((unsigned)nblk), dim3(256), 0, s, p)
     if constexpr (MODE == MODE_CONV3 && EPI == EPI_NHWC && !__is_same(T, split_t)) {
         if (wide) { if (var == 1) IGEMM_LAUNCH(32, 1); else if (var == 2) IGEMM_LAUNCH(32, 2);
@@ -457,11 +447,33 @@ static int launch_tw(const IgemmParams& p, hipStream_t s) {
 }
 
 template <int MODE, int EPI>
-static int launch(const IgemmParams& p, int dtype, hipStream_t s) {
-    if (dtype == CLAMD_BF16) return launch_tw<bf16_t, MODE, EPI>(p, s);
-    if (dtype == CLAMD_F32) return launch_tw<float, MODE, EPI>(p, s);
-    if (dtype == CLAMD_SPLIT) return launch_tw<split_t, MODE, EPI>(p, s);
+static int launch(const IgemmParams& p, int dtype, hipStream_t s, int variant = 0) {
+    if (dtype == CLAMD_BF16) return launch_tw<bf16_t, MODE, EPI>(p, s, variant);
+    if (dtype == CLAMD_F32) return launch_tw<float, MODE, EPI>(p, s, variant);
+    if (dtype == CLAMD_SPLIT) return launch_tw<split_t, MODE, EPI>(p, s, variant);
     return clamd_fail("igemm: bad dtype");
+}
+
+// Which structure runs a 3x3 launch (measured choices, tools/conv_ab.py) and how many partial statistics rows it writes.
+struct Conv3Plan { int kind; int mt; int rows; };      // kind 0 = baseline, 1 = producer/consumer, 2 = persistent
+static Conv3Plan plan_conv3x3(const IgemmParams& p, int dtype, const clamd_tuning& tn) {
+    if (tn.igemm_pws == 2 || (tn.igemm_pws == 1 && p.Kp <= 256)) {    // measured: faster up to 256 input channels
+        const int gm = pws_rows(p, dtype, tn);
+        if (gm > 0) return {2, 2, gm};                                  // -1: shape not supported there, fall through
+    }
+    int mt = 0;
+    if (tn.igemm_ws == 1 || tn.igemm_ws == 3 || tn.igemm_ws == 4)      // forced: 256- / 512- / 128-pixel tiles
+        mt = tn.igemm_ws == 1 ? 2 : tn.igemm_ws == 3 ? 4 : 1;
+    else if (tn.igemm_ws == 2 && p.Kp >= 256) {                        // (exactly 256 only when the persistent kernel declined)
+        // one workgroup per CU: take the 512-pixel tile only if it still gives every CU a workgroup
+        const long long ntn = (p.Np + 63) / 64;
+        const long long blocks4 = (long long)p.B * ((p.H + 15) / 16) * ((p.W + 31) / 32) * ntn;
+        const long long blocks2 = (long long)p.B * (p.W >= 32 ? ((p.H + 7) / 8) * ((p.W + 31) / 32) : ((p.H + 15) / 16) * ((p.W + 15) / 16)) * ntn;
+        mt = (p.W >= 32 && blocks4 >= 224) ? 4 : blocks2 >= 224 ? 2 : 1;
+    }
+    if (mt) return {1, mt, ws_rows(p, mt)};
+    const long long t = igemm_tiles(p);
+    return {0, 2, t > 0x7fffffff ? -1 : (int)t};
 }
 
 static int check_common(const IgemmParams& p, const char* who) {
@@ -482,55 +494,61 @@ using namespace clamd;
 
 extern "C" {
 
-int clamd_set_tuning(const char* key, int value) {
-    if (!strcmp(key, "igemm_variant")) {
-#ifndef CLAMD_DIAG
-        if (value < 0 || value > 2) return clamd_fail("igemm_variant: 0..2 (3..6 are timing ablations of the diagnostic build)");
-#endif
-        g_igemm_variant = value; return 0;
+int clamd_sizeof_tuning(void) { return (int)sizeof(clamd_tuning); }
+void clamd_tuning_init(clamd_tuning* t) { if (t) *t = clamd_default_tuning(); }
+
+int clamd_stat_rows(int op, int B, int H, int W, int Cin_p, int Cout_p, int dtype, int fused_bn, const clamd_tuning* tune) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cout_p <= 0) return clamd_fail("stat_rows: empty problem");
+    if (int e = clamd_check_tuning(tune)) return e;
+    const clamd_tuning& tn = clamd_tune(tune);
+    IgemmParams p{};
+    p.B = B; p.H = H; p.W = W; p.Kp = Cin_p; p.Np = Cout_p;
+    p.bn_y = fused_bn ? (const void*)&p : nullptr;          // only tested against null by the planners
+    long long rows = -1;
+    switch (op) {
+    case CLAMD_OP_CONV3X3: rows = plan_conv3x3(p, dtype, tn).rows; break;
+    case CLAMD_OP_CONV3X3_WINOGRAD: rows = clamd_winograd_stat_rows(B, H, W, Cout_p, tn); break;
+    case CLAMD_OP_CONV1X1:
+    case CLAMD_OP_CONVT2X2_DGRAD: rows = igemm_tiles(p); break;
+    case CLAMD_OP_BN_BWD_REDUCE: rows = clamd_bn_bwd_reduce_rows(B, H, W, Cout_p, Cin_p != 0, tn); break;
+    default: return clamd_fail("stat_rows: unknown op");
     }
-    if (!strcmp(key, "igemm_ws")) { g_igemm_ws = value; return 0; }
-    if (!strcmp(key, "igemm_pws")) { g_igemm_pws = value; return 0; }
-    if (!strcmp(key, "wgrad_tw16")) { g_wgrad_tw16 = value; return 0; }
-    if (!strcmp(key, "wgrad_ws")) { g_wgrad_ws = value; return 0; }
-    if (!strcmp(key, "wgrad_xcd")) { g_wgrad_xcd = value; return 0; }
-    if (!strcmp(key, "wino_band")) { g_wino_band = value; return 0; }
-    if (!strcmp(key, "pws_wres")) { g_pws_wres = value; return 0; }
-    if (!strcmp(key, "bn_reduce_blocks")) { if (value < 0 || value > 65535) return clamd_fail("bn_reduce_blocks: 0..65535"); g_bn_reduce_blocks = value; return 0; }
-    if (!strcmp(key, "chsum_blocks")) { if (value < 0 || value > 65535) return clamd_fail("chsum_blocks: 0..65535"); g_chsum_blocks = value; return 0; }
-    if (!strcmp(key, "wino_persist")) { g_wino_persist = value; return 0; }
-    if (!strcmp(key, "wino_mt")) { g_wino_mt = value; return 0; }
-    if (!strcmp(key, "wgrad_dma")) { g_wgrad_dma = value; return 0; }
-    if (!strcmp(key, "wgrad_blocks")) { if (value < 1 || value > 512) return clamd_fail("wgrad_blocks: 1..512"); g_wgrad_target_blocks = value; return 0; }
-    return clamd_fail("set_tuning: unknown key");
+    if (rows <= 0 || rows > 0x7fffffff) return clamd_fail("stat_rows: out of range");
+    return (int)rows;
+}
+
+static int check_rows(const IgemmParams& p, int have, int need, const char* who) {
+    if ((p.stats || p.bn_sums) && have != need) {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "%s: stat_rows = %d but this launch writes %d partial rows (size the buffer with clamd_stat_rows)", who, have, need);
+        return clamd_fail(msg);
+    }
+    return 0;
 }
 
 int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
-                  float* stats, const void* bn_y, float* bn_sums, int B, int H, int W, int Cin_p, int Cout_p, int relu,
-                  int m_fastest, int dtype, void* stream) {
+                  float* stats, const void* bn_y, float* bn_sums, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p,
+                  int relu, int m_fastest, int dtype, const clamd_tuning* tune, void* stream) {
     IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, m_fastest, bn_y, bn_sums};
     if (int e = check_common(p, "conv3x3")) return e;
-    if (g_igemm_pws == 2 || (g_igemm_pws == 1 && Cin_p <= 256)) {     // measured: faster up to 256 input channels (tools/conv_ab.py)
-        const int e = launch_igemm_pws(p, dtype, (hipStream_t)stream);
-        if (e != -1) return e;                                       // -1: shape not supported there, fall through
-    }
-    if (g_igemm_ws == 1 || g_igemm_ws == 3 || g_igemm_ws == 4)      // forced: 256- / 512- / 128-pixel tiles
-        return launch_igemm_ws(p, dtype, (hipStream_t)stream, g_igemm_ws == 1 ? 2 : g_igemm_ws == 3 ? 4 : 1);
-    if (g_igemm_ws == 2 && Cin_p >= 256) {                           // (exactly 256 only when the persistent kernel declined)
-        // one workgroup per CU: take the 512-pixel tile only if it still gives every CU a workgroup
-        const long long ntn = (Cout_p + 63) / 64;
-        const long long blocks4 = (long long)B * ((H + 15) / 16) * ((W + 31) / 32) * ntn;
-        const long long blocks2 = (long long)B * (W >= 32 ? ((H + 7) / 8) * ((W + 31) / 32) : ((H + 15) / 16) * ((W + 15) / 16)) * ntn;
-        return launch_igemm_ws(p, dtype, (hipStream_t)stream, (W >= 32 && blocks4 >= 224) ? 4 : blocks2 >= 224 ? 2 : 1);
-    }
-    return launch<MODE_CONV3, EPI_NHWC>(p, dtype, (hipStream_t)stream);
+    if (int e = clamd_check_tuning(tune)) return e;
+    if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("conv3x3: bn_y and bn_sums go together");
+    const clamd_tuning& tn = clamd_tune(tune);
+    const Conv3Plan pl = plan_conv3x3(p, dtype, tn);
+    if (pl.rows <= 0) return clamd_fail("conv3x3: grid out of range");
+    if (int e = check_rows(p, stat_rows, pl.rows, "conv3x3")) return e;
+    if (pl.kind == 2) return launch_igemm_pws(p, dtype, (hipStream_t)stream, tn);
+    if (pl.kind == 1) return launch_igemm_ws(p, dtype, (hipStream_t)stream, pl.mt);
+    return launch<MODE_CONV3, EPI_NHWC>(p, dtype, (hipStream_t)stream, tn.igemm_variant);
 }
 
 int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
-                  float* stats, const void* bn_y, float* bn_sums, int B, int H, int W, int Cin_p, int Cout_p, int relu,
-                  int dtype, void* stream) {
+                  float* stats, const void* bn_y, float* bn_sums, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p,
+                  int relu, int dtype, void* stream) {
     IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, 0, bn_y, bn_sums};
     if (int e = check_common(p, "conv1x1")) return e;
+    if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("conv1x1: bn_y and bn_sums go together");
+    if (int e = check_rows(p, stat_rows, (int)igemm_tiles(p), "conv1x1")) return e;
     return launch<MODE_PW, EPI_NHWC>(p, dtype, (hipStream_t)stream);
 }
 
@@ -550,9 +568,11 @@ int clamd_convT2x2_fwd(const void* x, int x_ldc, const void* w_packed, const flo
 }
 
 int clamd_convT2x2_dgrad(const void* gy, int gy_ldc, const void* w_packed, void* gx, int gx_ldc, const void* bn_y,
-                         float* bn_sums, int B, int h, int w, int Cin_p, int Cout_p, int dtype, void* stream) {
+                         float* bn_sums, int stat_rows, int B, int h, int w, int Cin_p, int Cout_p, int dtype, void* stream) {
     IgemmParams p{gy, gy_ldc, w_packed, nullptr, gx, gx_ldc, nullptr, B, h, w, 4 * Cout_p, Cin_p, 0, Cout_p, 0, bn_y, bn_sums};
     if (int e = check_common(p, "up2_dgrad")) return e;
+    if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("convT2x2_dgrad: bn_y and bn_sums go together");
+    if (int e = check_rows(p, stat_rows, (int)igemm_tiles(p), "convT2x2_dgrad")) return e;
     return launch<MODE_UP2, EPI_NHWC>(p, dtype, (hipStream_t)stream);
 }
 

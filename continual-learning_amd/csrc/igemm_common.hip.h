@@ -2,6 +2,7 @@
 // wave-specialised structure for the 3x3 convolutions).
 #pragma once
 #include "common.hip.h"
+#include "clamd_internal.h"
 
 namespace clamd {
 
@@ -13,7 +14,7 @@ struct IgemmParams {
     const void* w;          // packed [taps][Np][Kp], K innermost
     const float* bias;      // indexed by n (NHWC/NCHW) or by n % aux (UP2 epilogue); may be null
     void* y; int y_ldc;
-    float* stats;           // [STAT_REPLICAS][2][Np] or null
+    float* stats;           // partial rows [row][2][Np] (one row per pixel tile or per workgroup, plain stores) or null
     int B, H, W;            // pixel grid of the GEMM rows
     int Kp, Np;
     int relu;
@@ -21,7 +22,7 @@ struct IgemmParams {
     int m_fastest;
     // EPI_NHWC only: when this launch produces the gradient g w.r.t. a BatchNorm output, accumulate the five
     // per-channel sums of the fused ReLU/BN backward (see bn_bwd_reduce_kernel) right here in the epilogue:
-    // bn_y = that unit's saved post-ReLU activation [B,H,W,Np] (dense pitch Np), bn_sums = [STAT_REPLICAS][5][Np].
+    // bn_y = that unit's saved post-ReLU activation [B,H,W,Np] (dense pitch Np), bn_sums = partial rows [row][5][Np].
     const void* bn_y;
     float* bn_sums;
 };
@@ -57,10 +58,12 @@ template <int TW, int MT> struct WsGeo {
 };
 
 // igemm_ws.hip: producer/consumer variant of the CONV3/NHWC kernel (same results)
-int launch_igemm_ws(const IgemmParams& p, int dtype, hipStream_t s, int mt);   // mt: 32-pixel row tiles per consumer wave (2 or 4)
+int launch_igemm_ws(const IgemmParams& p, int dtype, hipStream_t s, int mt);   // mt: 32-pixel row tiles per consumer wave (1, 2 or 4)
+int ws_rows(const IgemmParams& p, int mt);                                     // pixel tiles = partial statistics rows of that launch
 
-// igemm_pws.hip: persistent producer/consumer variant for short-K layers (same results up to the order of the
-// per-channel statistics atomics); returns -1 without launching when the shape is not supported
-int launch_igemm_pws(const IgemmParams& p, int dtype, hipStream_t s);
+// igemm_pws.hip: persistent producer/consumer variant for short-K layers (same activations; statistics rows are per
+// workgroup instead of per tile); returns -1 without launching when the shape is not supported
+int launch_igemm_pws(const IgemmParams& p, int dtype, hipStream_t s, const ::clamd_tuning& tn);
+int pws_rows(const IgemmParams& p, int dtype, const ::clamd_tuning& tn);
 
 }  // namespace clamd

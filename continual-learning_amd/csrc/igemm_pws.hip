@@ -9,7 +9,8 @@
 //   * waves 0-3 (consumers) do MFMAs, then an epilogue without workgroup barriers: every wave transposes its own
 //     32x64 accumulator block through a private LDS region outside the two stages;
 //   * the per-channel Sigma / Sigma^2 of the fused BatchNorm statistics stay in registers across tiles and are flushed
-//     with one set of atomics per workgroup instead of one per tile.
+//     once per workgroup as ONE partial row (plain stores, row = index of the workgroup inside its slab): the tile ->
+//     workgroup map is static, so the rows and their fixed-order sum (bn_finalize) are bit-reproducible.
 // Tile (256 pixels x 64 channels), LDS image, fragment maps and per-element results are those of igemm_ws.hip (MT = 2).
 #include "common.hip.h"
 #include "igemm_common.hip.h"
@@ -428,7 +429,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             const int k = tid >> 6, c = tid & 63;
             const float t = sbuf[(0 * 2 + k) * 64 + c] + sbuf[(1 * 2 + k) * 64 + c] + sbuf[(2 * 2 + k) * 64 + c] +
                             sbuf[(3 * 2 + k) * 64 + c];
-            if (n0 + c < p.Np) atomicAdd(p.stats + ((size_t)(blockIdx.x % STAT_REPLICAS) * 2 + k) * p.Np + n0 + c, t);
+            if (n0 + c < p.Np) p.stats[((size_t)mg * 2 + k) * p.Np + n0 + c] = t;
         }
     }
     if constexpr (BN) {
@@ -448,14 +449,11 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             for (int i = tid; i < 5 * 64; i += 512) {
                 const int k = i >> 6, c = i & 63;
                 const float t = ebuf[0 * 32 * EPW + i] + ebuf[1 * 32 * EPW + i] + ebuf[2 * 32 * EPW + i] + ebuf[3 * 32 * EPW + i];
-                if (n0 + c < p.Np) atomicAdd(p.bn_sums + ((size_t)(blockIdx.x % STAT_REPLICAS) * 5 + k) * p.Np + n0 + c, t);
+                if (n0 + c < p.Np) p.bn_sums[((size_t)mg * 5 + k) * p.Np + n0 + c] = t;
             }
         }
     }
 }
-
-static int g_num_cus = 0;
-int g_pws_wres = 1;             // tuning knob "pws_wres": keep the filter slab resident in LDS when a tile has two K-steps
 
 }  // namespace clamd
 #ifdef CLAMD_DIAG
@@ -468,36 +466,42 @@ extern "C" int clamd_debug_pws_diag(unsigned long long* out8, int reset) {
 namespace clamd {
 
 
+// Workgroups per 64-channel output slab (= partial statistics rows of a launch), or -1 when this kernel declines the shape.
+int pws_rows(const IgemmParams& p, int dtype, const clamd_tuning& tn) {
+    const int esz = dtype == CLAMD_BF16 ? 2 : 4, kc = dtype == CLAMD_BF16 ? 32 : 16;
+    if (p.bn_y && esz != 2) return -1;                       // fused BN-backward sums here: bf16 only (register budget)
+    if (p.Kp % (2 * kc)) return -1;                          // K-steps are staged in pairs
+    const int TW = p.W >= 32 ? 32 : 16, TH = 256 / TW;
+    const long long ntm = (long long)((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.B;
+    const int ntn = (p.Np + 63) / 64;
+    long long gm = clamd_usable_cus(tn) / ntn;
+    if (gm < 1) gm = 1;
+    if (gm > ntm) gm = ntm;
+    return (int)gm;
+}
+
 template <typename T>
-static int launch_pws_t(const IgemmParams& p, hipStream_t s) {
-    if (p.bn_y && sizeof(T) != 2) return -1;                 // fused BN-backward sums here: bf16 only (register budget)
-    if (p.Kp % (2 * DT<T>::KC)) return -1;                   // K-steps are staged in pairs
-    if (!g_num_cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        g_num_cus = n;
-    }
+static int launch_pws_t(const IgemmParams& p, hipStream_t s, int dtype, const clamd_tuning& tn) {
+    const long long gm = pws_rows(p, dtype, tn);
+    if (gm < 0) return -1;
     const bool wide = p.W >= 32;
     const int TW = wide ? 32 : 16, TH = 256 / TW;
     const long long ntm = (long long)((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.B;
     const int ntn = (p.Np + 63) / 64;
-    long long gm = g_num_cus / ntn;
-    if (gm < 1) gm = 1;
-    if (gm > ntm) gm = ntm;
     const long long nblk = gm * ntn;
     if (ntm > 0x7fffffff) return clamd_fail("igemm_pws: grid out of range");
     const bool ragged = (p.H % TH) != 0 || (p.W % TW) != 0;
-#define PWS_LAUNCH(TW_, RG_) hipLaunchKernelGGL((igemm_pws_kernel<T, TW_, RG_>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm, g_pws_wres)
+#define PWS_LAUNCH(TW_, RG_) hipLaunchKernelGGL((igemm_pws_kernel<T, TW_, RG_>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm, tn.pws_wres)
     if (wide) { if (ragged) PWS_LAUNCH(32, true); else PWS_LAUNCH(32, false); }
     else { if (ragged) PWS_LAUNCH(16, true); else PWS_LAUNCH(16, false); }
 #undef PWS_LAUNCH
     return clamd_check_launch("igemm_pws");
 }
 
-int launch_igemm_pws(const IgemmParams& p, int dtype, hipStream_t s) {
-    if (dtype == CLAMD_BF16) return launch_pws_t<bf16_t>(p, s);
-    if (dtype == CLAMD_F32) return launch_pws_t<float>(p, s);
-    if (dtype == CLAMD_SPLIT) return launch_pws_t<split_t>(p, s);
+int launch_igemm_pws(const IgemmParams& p, int dtype, hipStream_t s, const clamd_tuning& tn) {
+    if (dtype == CLAMD_BF16) return launch_pws_t<bf16_t>(p, s, dtype, tn);
+    if (dtype == CLAMD_F32) return launch_pws_t<float>(p, s, dtype, tn);
+    if (dtype == CLAMD_SPLIT) return launch_pws_t<split_t>(p, s, dtype, tn);
     return clamd_fail("igemm_pws: bad dtype");
 }
 

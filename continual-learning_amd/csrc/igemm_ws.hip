@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
             const int k = tid >> 6, c = tid & 63;
             const float t = sbuf[(0 * 2 + k) * 64 + c] + sbuf[(1 * 2 + k) * 64 + c] + sbuf[(2 * 2 + k) * 64 + c] +
                             sbuf[(3 * 2 + k) * 64 + c];
-            if (n0 + c < p.Np) atomicAdd(p.stats + ((size_t)(blockIdx.x % STAT_REPLICAS) * 2 + k) * p.Np + n0 + c, t);
+            if (n0 + c < p.Np) p.stats[((size_t)tm * 2 + k) * p.Np + n0 + c] = t;      // partial row of this pixel tile
         }
     }
     T* out = (T*)p.y;
@@ -396,11 +396,19 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
             const int k = i >> 6, c = i & 63;
             const float t = ebuf[(0 * 5 + k) * 64 + c] + ebuf[(1 * 5 + k) * 64 + c] + ebuf[(2 * 5 + k) * 64 + c] +
                             ebuf[(3 * 5 + k) * 64 + c];
-            if (n0 + c < p.Np) atomicAdd(p.bn_sums + ((size_t)(blockIdx.x % STAT_REPLICAS) * 5 + k) * p.Np + n0 + c, t);
+            if (n0 + c < p.Np) p.bn_sums[((size_t)tm * 5 + k) * p.Np + n0 + c] = t;
         }
     }
     if (wave == 0) DIAG_ADD(6, DIAG_T() - e0);             // [6] epilogue (one wave per workgroup)
     if (wave == 0) DIAG_ADD(7, 1);                         // [7] workgroups
+}
+
+int ws_rows(const IgemmParams& p, int mt) {
+    const bool wide = p.W >= 32;
+    if (!wide && mt > 2) mt = 2;
+    const int TW = wide ? 32 : 16, TH = 128 * mt / TW;
+    const long long tiles = (long long)((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.B;
+    return tiles > 0x7fffffff ? -1 : (int)tiles;
 }
 
 template <typename T>

@@ -20,6 +20,23 @@ int clamd_check_launch(const char* what) {
     return -2;
 }
 
+int clamd_check_tuning(const clamd_tuning* t) {
+    if (!t) return 0;
+    if (t->igemm_pws < 0 || t->igemm_pws > 2) return clamd_fail("tuning: igemm_pws 0..2");
+    if (t->igemm_ws < 0 || t->igemm_ws > 4) return clamd_fail("tuning: igemm_ws 0..4");
+#ifndef CLAMD_DIAG
+    if (t->igemm_variant < 0 || t->igemm_variant > 2) return clamd_fail("tuning: igemm_variant 0..2 (3..6 are timing ablations of the diagnostic build)");
+#endif
+    if (t->wgrad_dma < 0 || t->wgrad_dma > 2) return clamd_fail("tuning: wgrad_dma 0..2");
+    if (t->wgrad_blocks < 1 || t->wgrad_blocks > 512) return clamd_fail("tuning: wgrad_blocks 1..512");
+    if (t->wino_band < 0 || t->wino_band > 32) return clamd_fail("tuning: wino_band 0..32");
+    if (t->wino_mt < 0 || t->wino_mt > 2) return clamd_fail("tuning: wino_mt 0..2");
+    if (t->bn_reduce_blocks < 0 || t->bn_reduce_blocks > 65535) return clamd_fail("tuning: bn_reduce_blocks 0..65535");
+    if (t->chsum_blocks < 0 || t->chsum_blocks > 1024) return clamd_fail("tuning: chsum_blocks 0..1024");
+    if (t->cu_reserve < 0 || t->cu_reserve > 128) return clamd_fail("tuning: cu_reserve 0..128");
+    return 0;
+}
+
 namespace clamd {
 
 // ------------------------------------------------------------------------------------------------ pack
@@ -372,7 +389,6 @@ int clamd_sizeof_pack_job(void) { return (int)sizeof(PackJob); }
 int clamd_sizeof_adam_tensor(void) { return (int)sizeof(AdamTensor); }
 int clamd_adam_chunk_elems(void) { return ADAM_CHUNK; }
 int clamd_pack_tile(void) { return PACK_TILE; }
-int clamd_stat_replicas(void) { return STAT_REPLICAS; }
 int clamd_bn_bwd_nsums(void) { return 5; }
 
 int clamd_pack(const void* jobs_dev, int njobs, int total_blocks, int dtype, void* stream) {

@@ -478,20 +478,15 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const ReduceParams p)
 
 // Pixel-tile width.  The split (bf16x3) 3x3 variant always takes the 16-wide tile: its 6x18 halo needs 7 staging
 // registers-quads instead of 9 and the kernel stays spill-free (the 32-wide variant spilled 36-100 bytes per lane).
-int g_wgrad_tw16 = 0;               // tuning knob: 1 = 16-wide tiles everywhere
-static inline int wgrad_tw(int W, int mode, bool split) { return (W >= 32 && !(split && mode == WG_CONV3) && !g_wgrad_tw16) ? 32 : 16; }
-
-int g_wgrad_target_blocks = 512;   // tuning knob (clamd_set_tuning "wgrad_blocks"): split-K until about this many workgroups
-int g_wgrad_dma = 1;               // tuning knob "wgrad_dma": bf16 3x3 kernel with LDS-DMA staging (wgrad_dma.hip)
-int g_wgrad_xcd = 1;
-int g_wgrad_ws = 1;                // tuning knob "wgrad_ws": producer/consumer kernel (one 512-thread workgroup per CU) for the 3x3 convs
+// (clamd_tuning::wgrad_tw16 = 1: 16-wide tiles everywhere)
+static inline int wgrad_tw(int W, int mode, bool split, int tw16) { return (W >= 32 && !(split && mode == WG_CONV3) && !tw16) ? 32 : 16; }
 
 template <typename T, int MODE, bool WS>
-static int launch_wg(const WgradParams& p, hipStream_t s, int grid) {
+static int launch_wg(const WgradParams& p, hipStream_t s, int grid, int tw16) {
     const dim3 blk(WS ? 512 : 256);
     constexpr bool NARROW_ONLY = __is_same(T, split_t) && MODE == WG_CONV3;      // wgrad_tw() never picks 32 there
     if constexpr (!NARROW_ONLY) {
-        if (wgrad_tw(p.W, MODE, false) == 32) {
+        if (wgrad_tw(p.W, MODE, false, tw16) == 32) {
             hipLaunchKernelGGL((wgrad_kernel<T, MODE, 32, WS>), dim3(grid), blk, 0, s, p);
             return clamd_check_launch("wgrad");
         }
@@ -501,10 +496,10 @@ static int launch_wg(const WgradParams& p, hipStream_t s, int grid) {
 }
 
 template <typename T>
-static int launch_wg_mode(int mode, bool ws, const WgradParams& p, hipStream_t s, int grid) {
-    if (mode == WG_CONV3) return ws ? launch_wg<T, WG_CONV3, true>(p, s, grid) : launch_wg<T, WG_CONV3, false>(p, s, grid);
-    if (mode == WG_PW) return launch_wg<T, WG_PW, false>(p, s, grid);
-    return launch_wg<T, WG_UP2, false>(p, s, grid);
+static int launch_wg_mode(int mode, bool ws, const WgradParams& p, hipStream_t s, int grid, int tw16) {
+    if (mode == WG_CONV3) return ws ? launch_wg<T, WG_CONV3, true>(p, s, grid, tw16) : launch_wg<T, WG_CONV3, false>(p, s, grid, tw16);
+    if (mode == WG_PW) return launch_wg<T, WG_PW, false>(p, s, grid, tw16);
+    return launch_wg<T, WG_UP2, false>(p, s, grid, tw16);
 }
 
 template <int KP>
@@ -544,8 +539,10 @@ size_t clamd_wgrad_workspace_bytes(int mode, int B, int H, int W, int Rp, int Cp
 
 int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, float* workspace, size_t ws_bytes,
                 float* out, int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0,
-                int c_seg0p, int dtype, void* stream) {
+                int c_seg0p, int dtype, const clamd_tuning* tune, void* stream) {
     if (mode < 0 || mode > 2) return clamd_fail("wgrad: bad mode");
+    if (int e = clamd_check_tuning(tune)) return e;
+    const clamd_tuning& tn = clamd_tune(tune);
     if (Rp % 32 || Cp % 32 || a_ldc % 8 || b_ldc % 8) return clamd_fail("wgrad: channel counts/pitches must be padded");
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("wgrad: empty problem");
     {   // buffer descriptors address one image with 32-bit byte offsets (OOB marker = 2^31)
@@ -554,28 +551,28 @@ int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, fl
             return clamd_fail("wgrad: one image exceeds 2^30 bytes");
     }
     const int NT = mode == WG_CONV3 ? 9 : (mode == WG_UP2 ? 4 : 1);
-    const int TW = wgrad_tw(W, mode, dtype == CLAMD_SPLIT);
+    const int TW = wgrad_tw(W, mode, dtype == CLAMD_SPLIT, tn.wgrad_tw16);
     const int TH = (dtype == CLAMD_BF16 ? 128 : 64) / (mode == WG_UP2 ? 2 : 1) / TW;    // CLAMD_SPLIT tiles like fp32
     const int ntiles = ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
     const int rt = (Rp + 63) / 64, ct = (Cp + 63) / 64;
     // the producer/consumer kernel runs one workgroup per CU: half the slabs of the 2-per-CU kernel
-    const bool ws = g_wgrad_ws && mode == WG_CONV3;
-    int nsplit = (ws ? g_wgrad_target_blocks / 2 : g_wgrad_target_blocks) / (rt * ct);
+    const bool ws = tn.wgrad_ws && mode == WG_CONV3;
+    int nsplit = (ws ? tn.wgrad_blocks / 2 : tn.wgrad_blocks) / (rt * ct);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > ntiles) nsplit = ntiles;
     int per = (ntiles + nsplit - 1) / nsplit;
     nsplit = (ntiles + per - 1) / per;
     const size_t need = (size_t)nsplit * NT * Rp * Cp * sizeof(float);
     if (need > ws_bytes) return clamd_fail("wgrad: workspace too small");
-    WgradParams p{a, a_ldc, b, b_ldc, workspace, B, H, W, Rp, Cp, nsplit, per, g_wgrad_xcd};
+    WgradParams p{a, a_ldc, b, b_ldc, workspace, B, H, W, Rp, Cp, nsplit, per, tn.wgrad_xcd};
     const int grid = rt * ct * nsplit;
     hipStream_t s = (hipStream_t)stream;
     int e;
     // LDS-DMA staging: +3..11 % except on the single-tile 64x64-channel layers (HBM-heavy, 6 % slower there); 2 = always
-    if (dtype == CLAMD_BF16 && ws && (g_wgrad_dma == 2 || (g_wgrad_dma == 1 && rt * ct > 1))) e = launch_wgrad_dma(p, s, grid, TW);
-    else if (dtype == CLAMD_BF16) e = launch_wg_mode<bf16_t>(mode, ws, p, s, grid);
-    else if (dtype == CLAMD_F32) e = launch_wg_mode<float>(mode, ws, p, s, grid);
-    else if (dtype == CLAMD_SPLIT) e = launch_wg_mode<split_t>(mode, ws, p, s, grid);
+    if (dtype == CLAMD_BF16 && ws && (tn.wgrad_dma == 2 || (tn.wgrad_dma == 1 && rt * ct > 1))) e = launch_wgrad_dma(p, s, grid, TW);
+    else if (dtype == CLAMD_BF16) e = launch_wg_mode<bf16_t>(mode, ws, p, s, grid, tn.wgrad_tw16);
+    else if (dtype == CLAMD_F32) e = launch_wg_mode<float>(mode, ws, p, s, grid, tn.wgrad_tw16);
+    else if (dtype == CLAMD_SPLIT) e = launch_wg_mode<split_t>(mode, ws, p, s, grid, tn.wgrad_tw16);
     else return clamd_fail("wgrad: bad dtype");
     if (e) return e;
     const int ident = wg_identity(R, Rp, r_seg0, r_seg0p) && wg_identity(C, Cp, c_seg0, c_seg0p);

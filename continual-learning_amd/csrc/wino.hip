@@ -40,7 +40,7 @@ struct WinoParams {
     const float* w;              // [Kp/8][16][Np][8]
     const float* bias;
     float* y; int y_ldc;
-    float* stats;                // [STAT_REPLICAS][2][Np] or null
+    float* stats;                // partial rows [pixel tile][2][Np] (plain stores) or null
     int B, H, W, Kp, Np, relu;
     int band;                    // output-channel slabs per band of the block order (see clamd_conv3x3_winograd)
     int nblk;                    // (pixel tile, slab) pairs; the grid is min(nblk, CUs) persistent workgroups
@@ -67,9 +67,9 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
     static_assert(WN_LDS * 16 <= 160 * 1024, "LDS budget");
     __shared__ uint4 smem[WN_LDS];
 
-    // Persistent: workgroup g walks the tiles g, g + grid, ... (same XCD every round).  The output stores and statistics
-    // atomics of a tile drain while the next tile is loaded and multiplied; a workgroup per tile instead waits for its
-    // last store to be acknowledged before the CU can start the next one (measured: 3 us of 30 per 64-channel tile).
+    // Persistent: workgroup g walks the tiles g, g + grid, ... (same XCD every round).  The output stores and the
+    // statistics row of a tile drain while the next tile is loaded and multiplied; a workgroup per tile instead waits for
+    // its last store to be acknowledged before the CU can start the next one (measured: 3 us of 30 per 64-channel tile).
     for (int v = blockIdx.x; v < p.nblk; v += gridDim.x) {
         // everything below is re-derived per tile from an opaque copy of the thread id: hoisted out of the tile loop the
         // per-lane constants would stay live through the MFMA loop and spill (344 bytes per lane, measured)
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
             if (tid < 128) {
                 const int k = tid >> 6, c = tid & 63;
                 const float t = sb[(0 * 2 + k) * 64 + c] + sb[(1 * 2 + k) * 64 + c] + sb[(2 * 2 + k) * 64 + c] + sb[(3 * 2 + k) * 64 + c];
-                if (n0 + c < p.Np) atomicAdd(p.stats + ((size_t)(v % STAT_REPLICAS) * 2 + k) * p.Np + n0 + c, t);
+                if (n0 + c < p.Np) p.stats[((size_t)tm * 2 + k) * p.Np + n0 + c] = t;      // row = pixel tile: independent of the grid
             }
         }
 
@@ -396,22 +396,10 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const WinoPackJob* __res
 
 using namespace clamd;
 
-namespace clamd { int g_wino_band = 0; int g_wino_persist = 1; int g_wino_mt = 0; }
-
-static int clamd_num_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus = n;
-    }
-    return cus;
-}   // tuning knob "wino_band": 0 = choose per launch, else forced (rounded down to a divisor of the slab count)
-
 // HBM traffic model of one launch: an XCD holds 32 workgroups at a time = a pixel tiles x b slabs (a * b = 32); every
 // such group fetches its a input tiles and b filter slabs once, so bytes ~ X * (slabs / b) + F * (tiles / a).  Measured
 // with b = all slabs (slab-fastest order): 553 MB for 1024 -> 1024 @ 16^2, where activations + filters are 88 MB.
-static int wino_band(long long tiles, long long slabs, double x_elems, double f_elems) {
+static int wino_band(long long tiles, long long slabs, double x_elems, double f_elems, int forced) {
     int best = 1;
     double best_cost = 0;
     for (int b = 1; b <= 32 && b <= slabs; b *= 2) {
@@ -420,8 +408,18 @@ static int wino_band(long long tiles, long long slabs, double x_elems, double f_
         const double cost = x_elems * ((double)slabs / b) + f_elems * ((double)tiles / a);
         if (b == 1 || cost < best_cost) { best = b; best_cost = cost; }
     }
-    if (g_wino_band > 0) { best = 1; while (best * 2 <= g_wino_band && slabs % (best * 2) == 0) best *= 2; }
+    if (forced > 0) { best = 1; while (best * 2 <= forced && slabs % (best * 2) == 0) best *= 2; }   // "wino_band": rounded down to a divisor
     return best;
+}
+
+// 16x16-pixel tiles unless that grid would leave a quarter of the CUs without a workgroup
+static bool wino_mt2(int B, int H, int W, int Cout_p, const clamd_tuning& tn) {
+    const long long ntn = (Cout_p + 63) / 64, nblk2 = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ntn;
+    const long long nblk1 = (long long)B * ((H + 7) / 8) * ((W + 15) / 16) * ntn;
+    return tn.wino_mt ? tn.wino_mt == 2 : (nblk2 >= 192 || nblk1 == nblk2);
+}
+long long clamd_winograd_stat_rows(int B, int H, int W, int Cout_p, const clamd_tuning& tn) {
+    return (long long)B * ((H + (wino_mt2(B, H, W, Cout_p, tn) ? 15 : 7)) / (wino_mt2(B, H, W, Cout_p, tn) ? 16 : 8)) * ((W + 15) / 16);
 }
 
 extern "C" {
@@ -435,21 +433,24 @@ int clamd_wino_pack(const void* jobs_dev, int njobs, int total_blocks, void* str
 }
 
 int clamd_conv3x3_winograd(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
-                           float* stats, int B, int H, int W, int Cin_p, int Cout_p, int relu, void* stream) {
+                           float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
+                           const clamd_tuning* tune, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("conv3x3_winograd: empty problem");
     if ((H | W) & 1) return clamd_fail("conv3x3_winograd: H and W must be even (2x2 output tiles)");
     if (Cin_p % 32 || Cout_p % 32 || x_ldc % 8 || y_ldc % 8) return clamd_fail("conv3x3_winograd: channel counts/pitches must be padded");
     if ((long long)H * W * x_ldc * 4 >= (1ll << 31) || (long long)16 * Cout_p * Cin_p * 4 >= (1ll << 31))
         return clamd_fail("conv3x3_winograd: image or filter exceeds 2^31 bytes");
+    if (int e = clamd_check_tuning(tune)) return e;
+    const clamd_tuning& tn = clamd_tune(tune);
     WinoParams p{x, x_ldc, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 1, 0};
     const long long ntn = (Cout_p + 63) / 64, nblk2 = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ntn;
     const long long nblk1 = (long long)B * ((H + 7) / 8) * ((W + 15) / 16) * ntn;
     if (nblk1 > 0x7fffffff) return clamd_fail("conv3x3_winograd: grid out of range");
-    // one workgroup per CU: 16x16-pixel tiles unless that grid would leave a quarter of the CUs without one
-    const bool mt2 = g_wino_mt ? g_wino_mt == 2 : (nblk2 >= 192 || nblk1 == nblk2);
-    p.band = wino_band((mt2 ? nblk2 : nblk1) / ntn, ntn, (double)B * H * W * Cin_p, 16.0 * Cin_p * Cout_p);
+    const bool mt2 = wino_mt2(B, H, W, Cout_p, tn);
+    p.band = wino_band((mt2 ? nblk2 : nblk1) / ntn, ntn, (double)B * H * W * Cin_p, 16.0 * Cin_p * Cout_p, tn.wino_band);
     p.nblk = (int)(mt2 ? nblk2 : nblk1);
-    const unsigned grid = g_wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_num_cus()) : (unsigned)p.nblk;
+    if (stats && stat_rows != p.nblk / ntn) return clamd_fail("conv3x3_winograd: stat_rows does not match clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD, ...)");
+    const unsigned grid = tn.wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_usable_cus(tn)) : (unsigned)p.nblk;
     const bool ragged = (H % (mt2 ? 16 : 8)) != 0 || (W % 16) != 0 || (Cout_p % 64) != 0;
 #define WN_LAUNCH(MT_, RG_) hipLaunchKernelGGL((wino_kernel<MT_, RG_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p)
     if (mt2) { if (ragged) WN_LAUNCH(2, true); else WN_LAUNCH(2, false); }
@@ -793,8 +794,9 @@ size_t clamd_wgrad_winograd_workspace_bytes(int Rp, int Cp) {
 
 int clamd_wgrad_winograd(const float* gz, int gz_ldc, const float* x, int x_ldc, float* workspace, size_t ws_bytes, float* out,
                          int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p,
-                         void* stream) {
+                         const clamd_tuning* tune, void* stream) {
     using namespace clamd;
+    if (int e = clamd_check_tuning(tune)) return e;
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("wgrad_winograd: empty problem");
     if ((H | W) & 1) return clamd_fail("wgrad_winograd: H and W must be even");
     if (Rp % 32 || Cp % 32 || gz_ldc % 8 || x_ldc % 8) return clamd_fail("wgrad_winograd: channel counts/pitches must be padded");

@@ -26,8 +26,9 @@ class GradSync:
         # RCCL's channel workgroups hold CUs for the duration of a collective, and our MFMA kernels need a whole CU per
         # workgroup: a statically strided persistent grid sized to the CU count would then run two full rounds, while the
         # hardware dispatcher spreads one-workgroup-per-tile grids over whatever CUs are free (persistent is worth 0.3 %).
-        from . import _lib
-        _lib.load().clamd_set_tuning(b'wino_persist', 0)
+        # This is a field of THIS model's tuning (passed per call): nothing process-wide is touched, results are unchanged
+        # (the statistics rows of the Winograd kernel are per tile either way).
+        model.tuning.wino_persist = 0
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
             optimizer.pre_step_hooks.append(self.wait)

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import call, ptr
+from ._lib import call, ptr, tune_ptr
 from .ops import PackTable, WinoPackTable, cpad
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
@@ -102,6 +102,15 @@ class UNet(nn.Module):
             self.add_module(st['name'], _Stage(layers) if st['wrapped'] else nn.Sequential(*layers))
         self._engines = {}
         self.grad_sync = None          # set by ddp.GradSync to overlap RCCL all-reduce with backward
+        self._tuning = None
+
+    @property
+    def tuning(self):
+        """Kernel-structure selection of THIS model (a `clamd_tuning`, see include/clamd.h), passed to every launch: the
+        library has no process-wide knobs.  Fields may be changed between steps (A/B tools, ddp.GradSync)."""
+        if self._tuning is None:
+            self._tuning = _lib.Tuning()
+        return self._tuning
 
     def _seq(self, st):
         m = getattr(self, st['name'])
@@ -156,7 +165,7 @@ class _Engine:
         self.B, self.H, self.W, self.dev = B, H, W, device
         self.dcode, self.tdtype = _DTYPES[model.compute_dtype]
         self.wino = bool(WINOGRAD) and self.dcode == _lib.F32
-        self.R = lib.clamd_stat_replicas()
+        self.tuning = model.tuning
         self.NS = lib.clamd_bn_bwd_nsums()
         self.generation = 0
         self.esize = 2 if self.dcode == _lib.BF16 else 4      # activation element size in HBM (bf16x3 stores fp32)
@@ -192,7 +201,6 @@ class _Engine:
         self.gcat = [act(l, 2 * cpad(C[l])) for l in range(4)]
         self.pool = [act(l + 1, cpad(C[l])) for l in range(4)]
         self.gpool = [act(l + 1, cpad(C[l])) for l in range(4)]
-        stat_sizes = []
 
         def unit(prefix, ci, bi, level, cin_segs, cout, xin, xin_ldc, first_of_net=False):
             u = _Conv()
@@ -220,8 +228,6 @@ class _Engine:
             u.wd = None if first_of_net else torch.zeros(ntap * u.cin_p * u.cout_p, dtype=T, device=dev)
             u.bias_p = torch.zeros(u.cout_p, dtype=torch.float32, device=dev)
             u.vec = torch.zeros(7, u.cout_p, dtype=torch.float32, device=dev)   # scale, shift, mean, istd, k0, k1, k2
-            u.stat_off = sum(stat_sizes)
-            stat_sizes.append(self.R * (2 + self.NS) * u.cout_p)
             u.m_fastest = 1 if 9 * u.cout_p > B * u.h * u.w_ else 0
             convs.append(u)
             return u
@@ -291,16 +297,18 @@ class _Engine:
             tail.bias_p = torch.zeros(tail.cout_p, dtype=torch.float32, device=dev)
             self.stages.append(dict(kind='dec', convs=(a, b), tail=tail))
         self.convs = convs
-        self.stat_arena = torch.zeros(sum(stat_sizes), dtype=torch.float32, device=dev)
-        for u in convs:
-            o = u.stat_off
-            u.stats = self.stat_arena[o:o + self.R * 2 * u.cout_p]
-            u.sums = self.stat_arena[o + self.R * 2 * u.cout_p:o + self.R * (2 + self.NS) * u.cout_p]
+        for s in self.stages:
+            t = s.get('tail')
+            if t is not None and t.consumer is not None:
+                t.consumer.sum_src = t          # that unit's five BN-backward sums come from the tail's data-gradient launch
+        self._tune_key = None
+        self._plan_stat_rows()
         self.nbts = [u.nbt for u in convs]
         # split-K slabs of the weight-gradient kernels
         ws = 0
         for u in convs:
             ws = max(ws, lib.clamd_wgrad_workspace_bytes(_lib.WGRAD_CONV3, B, u.h, u.w_, u.cout_p, u.cin_p, self.dcode))
+            ws = max(ws, lib.clamd_channel_sum_workspace_bytes(u.cout_p))
             if u.wino:
                 ws = max(ws, lib.clamd_wgrad_winograd_workspace_bytes(u.cout_p, u.cin_p))
         for s in self.stages:
@@ -313,6 +321,45 @@ class _Engine:
         self.ws_bytes = ws
         self._build_pack_table()
         self._ptrs = None
+
+    # ------------------------------------------------------------------------------------------ statistics rows
+    def _plan_stat_rows(self):
+        """Partial-row buffers of the deterministic per-channel reductions (include/clamd.h, clamd_stat_rows): every unit
+        gets stats [rows][2][Cout_p] (forward launch) and sums [rows][5][Cout_p] (whichever launch produces its five
+        BatchNorm-backward sums).  Row counts depend on the kernel structure, i.e. on the tuning: re-planned when it changes."""
+        key = tuple(self.tuning.as_dict().values())
+        if key == self._tune_key:
+            return
+        self._tune_key = key
+        B, dc, tn = self.B, self.dcode, self.tuning
+        rows = _lib.stat_rows
+        sizes = []
+        for u in self.convs:
+            if u.im2col:
+                u.stat_rows = rows(_lib.OP_CONV1X1, B, u.h, u.w_, u.cin_p, u.cout_p, dc)
+            elif u.wino:
+                u.stat_rows = rows(_lib.OP_CONV3X3_WINOGRAD, B, u.h, u.w_, u.cin_p, u.cout_p, dc, tuning=tn)
+            else:
+                u.stat_rows = rows(_lib.OP_CONV3X3, B, u.h, u.w_, u.cin_p, u.cout_p, dc, tuning=tn)
+            if u.fused_reduce:
+                src = getattr(u, 'sum_src', None)
+                if src is None:       # the 3x3 data-gradient launch of the next conv of this stage (K = its output channels)
+                    b = next(c for c in self.convs if c.consumer is u)
+                    u.sum_rows = rows(_lib.OP_CONV3X3, B, b.h, b.w_, b.cout_p, b.cin_p, dc, fused_bn=True, tuning=tn)
+                elif src.kind == 'head':
+                    u.sum_rows = rows(_lib.OP_CONV1X1, B, u.h, u.w_, src.cout_p, src.cin_p, dc, fused_bn=True)
+                else:                 # ConvTranspose2d data gradient: the launch runs on the convT INPUT grid (= this unit's)
+                    u.sum_rows = rows(_lib.OP_CONVT2X2_DGRAD, B, u.h, u.w_, src.cin_p, src.cout_p, dc, fused_bn=True)
+            else:
+                u.sum_rows = rows(_lib.OP_BN_BWD_REDUCE, B, u.h, u.w_, 1 if u.g_src[2] is not None else 0, u.cout_p, dc, tuning=tn)
+            sizes.append((u.stat_rows * 2 + u.sum_rows * self.NS) * u.cout_p)
+        self.stat_arena = torch.empty(sum(sizes), dtype=torch.float32, device=self.dev)
+        off = 0
+        for u, n in zip(self.convs, sizes):
+            k = u.stat_rows * 2 * u.cout_p
+            u.stats = self.stat_arena[off:off + k]
+            u.sums = self.stat_arena[off + k:off + n]
+            off += n
 
     # ------------------------------------------------------------------------------------------ pack table
     def _build_pack_table(self):
@@ -361,8 +408,7 @@ class _Engine:
         self._check_ptrs(params)
         s = _lib.stream_ptr()
         B, H, W, dc = self.B, self.H, self.W, self.dcode
-        if training:
-            self.stat_arena.zero_()
+        self._plan_stat_rows()
         self.pack_table.run(dc, s)
         if self.wino_table is not None:
             self.wino_table.run(s)
@@ -396,20 +442,21 @@ class _Engine:
         return self.esize * (self.B * u.h * u.w_ * (u.cin + u.cout) + 9 * u.cin * u.cout)
 
     def _conv_fwd(self, u, training, s):
-        B, dc = self.B, self.dcode
+        B, dc, tp = self.B, self.dcode, tune_ptr(self.tuning)
         v = u.vec
         if u.im2col:
             call('clamd_conv1x1', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
-                 ptr(u.stats) if training else None, None, None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
+                 ptr(u.stats) if training else None, None, None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
         elif u.wino:
             _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
                    'clamd_conv3x3_winograd', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
-                   ptr(u.stats) if training else None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, s)
+                   ptr(u.stats) if training else None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
         else:
             _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
                    'clamd_conv3x3', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
-                   ptr(u.stats) if training else None, None, None, B, u.h, u.w_, u.cin_p, u.cout_p, 1, u.m_fastest, dc, s)
-        call('clamd_bn_finalize', ptr(u.stats) if training else None, ptr(u.gamma), ptr(u.beta), ptr(u.rm), ptr(u.rv),
+                   ptr(u.stats) if training else None, None, None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1,
+                   u.m_fastest, dc, tp, s)
+        call('clamd_bn_finalize', ptr(u.stats) if training else None, u.stat_rows, ptr(u.gamma), ptr(u.beta), ptr(u.rm), ptr(u.rv),
              ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), u.cout_p, u.cout, float(B * u.h * u.w_), BN_MOMENTUM, BN_EPS, s)
         call('clamd_bn_apply', ptr(u.y), u.cout_p, ptr(v[0]), ptr(v[1]), ptr(u.out), u.out_ldc,
              ptr(u.pooled), u.pooled.shape[-1] if u.pooled is not None else 0, B, u.h, u.w_, u.cout_p, dc, s)
@@ -432,29 +479,30 @@ class _Engine:
         g = {n: base + 4 * o for n, (o, _) in self.goffset.items()}      # raw device pointers into the flat buffer
         sync = m.grad_sync
         self._gp = g
+        tp = tune_ptr(self.tuning)
         for st in reversed(self.stages):
             t = st.get('tail')
             if t is not None:
                 h, w = H >> t.level, W >> t.level
-                call('clamd_fill_f32', g[t.keys[1]], t.cout, 0.0, s)
                 if t.kind == 'head':
                     call('clamd_nchw_to_nhwc', ptr(gout), ptr(self.dl), self.Kp, B, self.K, H, W, self.Kp, 1.0, dc, s)
                     call('clamd_wgrad', _lib.WGRAD_PW, ptr(self.dl), self.Kp, ptr(t.x), t.x.shape[-1], ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cout_p, t.cin_p, t.cout, t.cin,
-                         t.cout, t.cout_p, t.cin, t.cin_p, dc, s)
-                    call('clamd_channel_sum', ptr(self.dl), self.Kp, g[t.keys[1]], B * h * w, self.Kp, t.cout, dc, s)
+                         t.cout, t.cout_p, t.cin, t.cin_p, dc, tp, s)
+                    call('clamd_channel_sum', ptr(self.dl), self.Kp, g[t.keys[1]], B * h * w, self.Kp, t.cout, dc,
+                         ptr(self.ws), self.ws_bytes, tp, s)
                     call('clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], None,
                          ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
-                         B, h, w, t.cout_p, t.cin_p, 0, dc, s)
+                         t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cout_p, t.cin_p, 0, dc, s)
                 else:
                     call('clamd_wgrad', _lib.WGRAD_UP2, ptr(t.x), t.x.shape[-1], ptr(t.gy_slice), t.y_ldc, ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cin_p, t.cout_p, t.cin, t.cout,
-                         t.cin, t.cin_p, t.cout, t.cout_p, dc, s)
+                         t.cin, t.cin_p, t.cout, t.cout_p, dc, tp, s)
                     call('clamd_channel_sum', ptr(t.gy_slice), t.y_ldc, g[t.keys[1]], B * 4 * h * w, t.cout_p,
-                         t.cout, dc, s)
+                         t.cout, dc, ptr(self.ws), self.ws_bytes, tp, s)
                     call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
                          ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
-                         B, h, w, t.cin_p, t.cout_p, dc, s)
+                         t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cin_p, t.cout_p, dc, s)
             for u in reversed(st['convs']):
                 self._conv_bwd(u, s)
             if sync is not None:
@@ -465,20 +513,22 @@ class _Engine:
     def _fuse_sums(self, b):
         """Does the data-gradient launch of conv `b` (3x3, K = b.cout_p gradient channels) also reduce the BN-backward sums
         of the unit in front of it?"""
+        if b.wino:                     # the Winograd data-gradient kernel has no BatchNorm-sums epilogue
+            return False
         if FUSE_BN_SUMS == 'auto':     # persistent bf16 kernel: <= 256 input channels, K-steps in pairs (64 channels)
             return self.dcode == _lib.BF16 and b.cout_p <= 256 and b.cout_p % 64 == 0
         return bool(FUSE_BN_SUMS)
 
     def _conv_bwd(self, u, s):
-        B, dc = self.B, self.dcode
+        B, dc, tp = self.B, self.dcode, tune_ptr(self.tuning)
         v = u.vec
         ga, ga_ldc, gp = u.g_src
         count = float(B * u.h * u.w_)
         g = self._gp
         if not u.fused_reduce:     # otherwise the five sums were accumulated by the epilogue of the kernel that wrote `ga`
             call('clamd_bn_bwd_reduce', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.cout_p,
-                 ptr(v[0]), ptr(v[1]), ptr(u.sums), B, u.h, u.w_, u.cout_p, dc, s)
-        call('clamd_bn_bwd_finalize', ptr(u.sums), ptr(u.gamma), ptr(v[2]), ptr(v[3]), ptr(v[4]), g[u.keys[2]],
+                 ptr(v[0]), ptr(v[1]), ptr(u.sums), u.sum_rows, B, u.h, u.w_, u.cout_p, dc, tp, s)
+        call('clamd_bn_bwd_finalize', ptr(u.sums), u.sum_rows, ptr(u.gamma), ptr(v[2]), ptr(v[3]), ptr(v[4]), g[u.keys[2]],
              g[u.keys[3]], g[u.keys[1]], u.cout_p, u.cout, count, s)
         call('clamd_bn_bwd_apply', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.cout_p,
              ptr(v[0]), ptr(v[1]), ptr(v[4]), ptr(u.gz), u.cout_p, B, u.h, u.w_, u.cout_p, dc, s)
@@ -489,23 +539,24 @@ class _Engine:
         flops = 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout
         if u.im2col:
             call('clamd_wgrad', _lib.WGRAD_PW, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
-                 g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, 9 * u.cin, u.cout, u.cout_p, 9 * u.cin, u.cin_p, dc, s)
+                 g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, 9 * u.cin, u.cout, u.cout_p, 9 * u.cin, u.cin_p, dc, tp, s)
             return
         if u.wino:
             _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
                    'clamd_wgrad_winograd', ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
-                   g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, s)
+                   g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, tp, s)
         else:
             _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
                    'clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
-                   g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, dc, s)
+                   g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, dc, tp, s)
         if u.g_in is not None and u.wino:
             _timed('igemm_conv3x3', flops, self._conv_bytes(u),
-                   'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
-                   B, u.h, u.w_, u.cout_p, u.cin_p, 0, s)
+                   'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
+                   B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
         elif u.g_in is not None:
             _timed('igemm_conv3x3', flops, self._conv_bytes(u),
                    'clamd_conv3x3', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
                    ptr(u.consumer.y) if u.consumer is not None else None,
                    ptr(u.consumer.sums) if u.consumer is not None else None,
-                   B, u.h, u.w_, u.cout_p, u.cin_p, 0, 1 if 9 * u.cin_p > B * u.h * u.w_ else 0, dc, s)
+                   u.consumer.sum_rows if u.consumer is not None else 0,
+                   B, u.h, u.w_, u.cout_p, u.cin_p, 0, 1 if 9 * u.cin_p > B * u.h * u.w_ else 0, dc, tp, s)

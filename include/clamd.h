@@ -37,21 +37,60 @@ int clamd_sizeof_pack_job(void);
 int clamd_sizeof_adam_tensor(void);
 int clamd_adam_chunk_elems(void);
 int clamd_pack_tile(void);            /* clamd_pack: blocks per job = ceil(Np/tile) * ceil(Kp/tile) */
-int clamd_stat_replicas(void);
 int clamd_bn_bwd_nsums(void);
+
+/* ---- per-call kernel-structure selection --------------------------------------------------------------------
+ * The library keeps NO mutable process state (nn.DataParallel, trainer.py:122, drives one Python thread
+ * per GPU through the same code).  Every entry point that chooses between kernel structures takes a
+ * `const clamd_tuning*`; NULL = the defaults clamd_tuning_init() writes.  Activations are bit-identical under every
+ * setting; statistics / weight gradients differ only in (fixed) summation order.
+ *   igemm_pws      0|1|2   persistent conv kernel: never | <= 256 input channels | always
+ *   igemm_ws       0..4    producer/consumer kernel: never | 256-px | heuristic | 512-px | 128-px tiles
+ *   igemm_variant  0|1|2   baseline kernel prefetch variants
+ *   pws_wres       0|1     persistent kernel: filter slab kept in LDS across tiles when a tile has two K-steps
+ *   wgrad_ws 0|1, wgrad_dma 0|1|2 (LDS-DMA staging: never | heuristic | always), wgrad_xcd 0|1,
+ *   wgrad_blocks 1..512 (split-K target), wgrad_tw16 0|1
+ *   wino_band      0 (per-launch choice) | 1..32 output-channel slabs per band of the Winograd block order
+ *   wino_persist   0|1     one workgroup per tile | persistent tile loop
+ *   wino_mt        0|1|2   tile height: per-launch choice | 8 | 16 pixels
+ *   bn_reduce_blocks / chsum_blocks   0 (per-launch choice) | n: grid cap of the per-channel reductions
+ *   cu_reserve     CUs the persistent grids leave free (for RCCL channel workgroups under data parallelism) */
+typedef struct clamd_tuning {
+    int igemm_pws, igemm_ws, igemm_variant, pws_wres;
+    int wgrad_ws, wgrad_dma, wgrad_xcd, wgrad_blocks, wgrad_tw16;
+    int wino_band, wino_persist, wino_mt;
+    int bn_reduce_blocks, chsum_blocks;
+    int cu_reserve;
+    int reserved[9];
+} clamd_tuning;
+int clamd_sizeof_tuning(void);
+void clamd_tuning_init(clamd_tuning* t);
+
+/* ---- deterministic per-channel reductions ---------------------------------------------------------------------
+ * BatchNorm statistics (sum, sum of squares) and the five BatchNorm-backward sums are never accumulated with float
+ * atomics: every producing launch writes `rows` partial rows [row][nk][Cp] (nk = 2 or 5) with plain stores, one row per
+ * workgroup (or per tile), and clamd_bn_finalize / clamd_bn_bwd_finalize add rows 0..rows-1 in a fixed order in fp64.
+ * Two runs on the same inputs are bit-identical.  The caller sizes the buffer with clamd_stat_rows() for the SAME
+ * arguments it launches with and passes that row count to the launch (checked) and to the finalize call. */
+enum { CLAMD_OP_CONV3X3 = 0, CLAMD_OP_CONV3X3_WINOGRAD = 1, CLAMD_OP_CONV1X1 = 2, CLAMD_OP_CONVT2X2_DGRAD = 3,
+       CLAMD_OP_BN_BWD_REDUCE = 4 };
+/* rows a launch of `op` writes: (B,H,W) = pixel grid of the launch, Cin_p/Cout_p as passed to it (BN_BWD_REDUCE: Cout_p = Cp,
+ * Cin_p != 0 means the pooled variant), fused_bn != 0 when bn_y/bn_sums are passed.  Negative on error. */
+int clamd_stat_rows(int op, int B, int H, int W, int Cin_p, int Cout_p, int dtype, int fused_bn, const clamd_tuning* tune);
 
 /* ---- implicit-GEMM convolutions (igemm.hip) ---------------------------------------------------------------
  * nn.Conv2d(k3,s1,p1)+bias followed by nn.ReLU (models/unet.py:13-14,16-17,28-29,31-32,50-51,53-54,66-67,69-70):
- *   y = relu?(conv3x3(x, w) + bias), and (if stats != NULL) per-channel sum / sum-of-squares of y accumulated
- *   into stats[replica][2][Cout_p] for the following nn.BatchNorm2d (unet.py:15,...).  The same entry point run
+ *   y = relu?(conv3x3(x, w) + bias), and (if stats != NULL) per-channel sum / sum-of-squares of y written as
+ *   partial rows stats[row][2][Cout_p] for the following nn.BatchNorm2d (unet.py:15,...).  The same entry point run
  *   on the flipped/transposed packing computes the data gradient of that conv (loss.backward(), trainer.py:175).
  *   w_packed: [9][Cout_p][Cin_p] compute dtype, Cin innermost (see clamd_pack).  m_fastest: block order hint.
  *   bn_y/bn_sums (optional, data-gradient launches): when y of THIS launch is the gradient w.r.t. a BatchNorm output,
  *   also accumulate the five per-channel sums of clamd_bn_bwd_reduce (bn_y = that unit's saved activation
- *   [B,H,W,Cout_p], bn_sums = [replica][5][Cout_p]) in the epilogue, so the separate reduce pass is not needed. */
+ *   [B,H,W,Cout_p], bn_sums = [row][5][Cout_p]) in the epilogue, so the separate reduce pass is not needed.
+ *   stat_rows = clamd_stat_rows(CLAMD_OP_CONV3X3, ...) (ignored when neither stats nor bn_sums is given). */
 int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
-                  float* stats, const void* bn_y, float* bn_sums, int B, int H, int W, int Cin_p, int Cout_p, int relu,
-                  int m_fastest, int dtype, void* stream);
+                  float* stats, const void* bn_y, float* bn_sums, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p,
+                  int relu, int m_fastest, int dtype, const clamd_tuning* tune, void* stream);
 /* The same convolution (fp32 only; H, W even) by Winograd F(2x2,3x3): 2.25x fewer multiply-adds, fp32 transforms
  * (relative error vs fp64 3.5e-7 against 2.3e-7 for the direct sum).  w_wino = [Cin_p/8][16][Cout_p][8] written by
  * clamd_wino_pack (jobs: device table of WinoPackJob, see ops.WinoPackTable; the data gradient uses the tap-flipped,
@@ -59,19 +98,20 @@ int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* b
 int clamd_sizeof_wino_pack_job(void);
 int clamd_wino_pack(const void* jobs_dev, int njobs, int total_blocks, void* stream);
 int clamd_conv3x3_winograd(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
-                           float* stats, int B, int H, int W, int Cin_p, int Cout_p, int relu, void* stream);
+                           float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
+                           const clamd_tuning* tune, void* stream);
 /* Weight gradient of the same convolution by Winograd (fp32, H and W even): out [R][C][3][3] = G^T (sum over tiles of
  * (A dY A^T) x (B^T d B)) G; arguments as clamd_wgrad(CLAMD_WGRAD_CONV3, ...) (gz = d loss / d conv output, x = conv input). */
 size_t clamd_wgrad_winograd_workspace_bytes(int Rp, int Cp);
 int clamd_wgrad_winograd(const float* gz, int gz_ldc, const float* x, int x_ldc, float* workspace, size_t ws_bytes, float* out,
                          int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p,
-                         void* stream);
+                         const clamd_tuning* tune, void* stream);
 /* 1x1 convolution, NHWC output, same epilogue options as clamd_conv3x3 (bias, ReLU, BN statistics).  Used for the
  * data gradient of the head (unet.py:72) and, on an im2col'ed input (clamd_nchw_im2col3), for the first conv
  * enc1.0 (unet.py:50, Cin = 3).  w_packed [1][Cout_p][Cin_p]. */
 int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
-                  float* stats, const void* bn_y, float* bn_sums, int B, int H, int W, int Cin_p, int Cout_p, int relu,
-                  int dtype, void* stream);
+                  float* stats, const void* bn_y, float* bn_sums, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p,
+                  int relu, int dtype, void* stream);
 /* the head nn.Conv2d(conv_dim, num_classes, k1) (unet.py:72): logits written as fp32 NCHW [B,num_classes,H,W]. */
 int clamd_conv1x1_logits(const void* x, int x_ldc, const void* w_packed, const float* bias, float* logits_nchw,
                          int B, int H, int W, int Cin_p, int Cout_p, int num_classes, int dtype, void* stream);
@@ -81,7 +121,7 @@ int clamd_convT2x2_fwd(const void* x, int x_ldc, const void* w_packed, const flo
                        int h, int w, int Cin_p, int Cout_p, int dtype, void* stream);
 /* data gradient of the above: gy [B,2h,2w,...] -> gx [B,h,w,Cin_p].  w_packed [Cin_p][4][Cout_p]. */
 int clamd_convT2x2_dgrad(const void* gy, int gy_ldc, const void* w_packed, void* gx, int gx_ldc, const void* bn_y,
-                         float* bn_sums, int B, int h, int w, int Cin_p, int Cout_p, int dtype, void* stream);
+                         float* bn_sums, int stat_rows, int B, int h, int w, int Cin_p, int Cout_p, int dtype, void* stream);
 
 /* ---- weight gradients (wgrad.hip) --------------------------------------------------------------------------
  * out[r][c][t] = sum_pixels a[p, r] * b[nbr_t(p), c]  written in the parameter's own fp32 layout:
@@ -94,11 +134,13 @@ int clamd_convT2x2_dgrad(const void* gy, int gy_ldc, const void* w_packed, void*
 size_t clamd_wgrad_workspace_bytes(int mode, int B, int H, int W, int Rp, int Cp, int dtype);
 int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, float* workspace, size_t ws_bytes,
                 float* out, int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0,
-                int c_seg0p, int dtype, void* stream);
+                int c_seg0p, int dtype, const clamd_tuning* tune, void* stream);
 
 /* ---- BatchNorm / ReLU / MaxPool / concat plumbing (elementwise.hip) ------------------------------------------
- * nn.BatchNorm2d train mode (unet.py:15): stats -> scale/shift (+ running stats, momentum 0.1, unbiased var). */
-int clamd_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
+ * nn.BatchNorm2d train mode (unet.py:15): partial rows stats[stat_rows][2][Cp] -> scale/shift (+ running stats,
+ * momentum 0.1, unbiased var); rows are added in a fixed order in fp64, mean/variance formed in fp64.
+ * stats == NULL: eval mode, normalise with the running statistics. */
+int clamd_bn_finalize(const float* stats, int stat_rows, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float* scale, float* shift, float* save_mean, float* save_istd,
                       int Cp, int C, double count, double momentum, double eps, void* stream);
 /* out = y*scale+shift into `out` (possibly a concat slice: replaces torch.cat, unet.py:83-87); pooled (optional)
@@ -106,18 +148,22 @@ int clamd_bn_finalize(const float* stats, const float* gamma, const float* beta,
 int clamd_bn_apply(const void* y, int y_ldc, const float* scale, const float* shift, void* out, int out_ldc,
                    void* pooled, int p_ldc, int B, int H, int W, int Cp, int dtype, void* stream);
 /* backward of ReLU->BatchNorm (+ max-pool routing of `gp`, the gradient w.r.t. the pooled tensor):
- * reduce -> 5 per-channel sums (replicated), finalize -> k0,k1,k2 + d gamma, d beta, d conv-bias, apply -> g_z. */
+ * reduce -> partial rows sums[sum_rows][5][Cp] (sum_rows = clamd_stat_rows(CLAMD_OP_BN_BWD_REDUCE, ...)),
+ * finalize -> k0,k1,k2 + d gamma, d beta, d conv-bias, apply -> g_z. */
 int clamd_bn_bwd_reduce(const void* ga, int ga_ldc, const void* gp, int gp_ldc, const void* y, int y_ldc,
-                        const float* scale, const float* shift, float* sums, int B, int H, int W, int Cp,
-                        int dtype, void* stream);
-int clamd_bn_bwd_finalize(const float* sums, const float* gamma, const float* save_mean, const float* save_istd,
+                        const float* scale, const float* shift, float* sums, int sum_rows, int B, int H, int W, int Cp,
+                        int dtype, const clamd_tuning* tune, void* stream);
+int clamd_bn_bwd_finalize(const float* sums, int sum_rows, const float* gamma, const float* save_mean, const float* save_istd,
                           float* k012, float* dgamma, float* dbeta, float* dbias, int Cp, int C, double count,
                           void* stream);
 int clamd_bn_bwd_apply(const void* ga, int ga_ldc, const void* gp, int gp_ldc, const void* y, int y_ldc,
                        const float* scale, const float* shift, const float* k012, void* gz, int gz_ldc, int B,
                        int H, int W, int Cp, int dtype, void* stream);
-/* out[c] += sum_pixels g[p,c]  (bias gradients of convT / head). */
-int clamd_channel_sum(const void* g, int ldc, float* out, long long npix, int Cp, int C, int dtype, void* stream);
+/* out[c] = sum_pixels g[p,c]  (bias gradients of convT / head): per-block partial rows in `workspace`
+ * (>= clamd_channel_sum_workspace_bytes(Cp)), then a fixed-order fp64 sum -- no float atomics, out is overwritten. */
+size_t clamd_channel_sum_workspace_bytes(int Cp);
+int clamd_channel_sum(const void* g, int ldc, float* out, long long npix, int Cp, int C, int dtype, float* workspace,
+                      size_t ws_bytes, const clamd_tuning* tune, void* stream);
 /* boundary layout conversion: visible tensors are fp32 NCHW; replaces images.to(device) layout
  * handling (trainer.py:168) and feeds grad_output into the backward. */
 int clamd_nchw_to_nhwc(const float* src, void* dst, int ldc, int B, int C, int H, int W, int Cp, double mul,
@@ -152,16 +198,6 @@ int clamd_voc_prepare(const unsigned char* img_rgb, const unsigned char* mask_rg
 /* voc.to_rgb (datasets/voc.py:74-89): labels int64 [N,H,W] -> palette colours [N,3,H,W] (0..255 as float). */
 int clamd_label_to_rgb(const long long* labels, float* rgb, long long n_img, long long hw, void* stream);
 int clamd_fill_f32(float* p, long long n, double v, void* stream);
-/* Kernel-structure selection for A/B measurements and tests (activations stay bit-identical; wgrad / statistics differ
- * only in summation order).  Keys: "igemm_pws" 0|1|2 (persistent conv kernel: never | <= 256 input channels | always),
- * "igemm_ws" 0|1|2|3|4 (producer/consumer kernel: never | 256-px | heuristic | 512-px | 128-px tiles),
- * "igemm_variant" 0|1|2 (baseline kernel prefetch variants), "wgrad_ws" 0|1, "wgrad_dma" 0|1|2 (LDS-DMA staging: never | heuristic | always), "wgrad_xcd" 0|1, "wgrad_blocks" 1..512,
- * "wgrad_tw16" 0|1, "wino_band" 0 (per-launch choice) | 1..32 (output-channel slabs per band of the Winograd block
- * order), "bn_reduce_blocks" / "chsum_blocks" 0 (per-launch choice) | n (grid cap of the per-channel reductions),
- * "pws_wres" 0|1 (persistent kernel: filter slab kept in LDS across tiles when a tile has two K-steps),
- * "wino_persist" 0|1 (one workgroup per tile | persistent tile loop), "wino_mt" 0|1|2 (tile height: per-launch
- * choice | 8 | 16 pixels).  Process-wide, not thread-safe: set before launching. */
-int clamd_set_tuning(const char* key, int value);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,70 @@ def test_abi_library_exports_every_declared_symbol(C):
     l = C._lib.load()
     assert l.clamd_version() >= 100
     assert l.clamd_sizeof_pack_job() == 120 and l.clamd_sizeof_adam_tensor() == 48
-    assert l.clamd_stat_replicas() == 16 and l.clamd_bn_bwd_nsums() == 5
+    assert l.clamd_bn_bwd_nsums() == 5
+    assert l.clamd_sizeof_tuning() == ctypes.sizeof(C._lib.Tuning)
+
+
+def test_header_prototypes_match_ctypes_signature_table(C):
+    """Every prototype of include/clamd.h is parsed and compared, argument by argument, with _lib.SIGNATURES (pointer /
+    int / double / long long / size_t classes): a stale binding would put an int into a pointer slot.
+    INTEGRATION.md's example bindings are generated from the same table and checked here too."""
+    src = open(os.path.join(ROOT, 'include', 'clamd.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    src = re.sub(r'typedef struct clamd_tuning \{.*?\} clamd_tuning;', '', src, flags=re.S)
+    protos = re.findall(r'(?:^|\n)\s*((?:const\s+)?[a-z_ ]+?\**)\s*(clamd_[A-Za-z0-9_]+)\s*\(([^;{]*?)\)\s*;', src)
+    assert len(protos) == len(C._lib.SIGNATURES), (len(protos), len(C._lib.SIGNATURES))
+
+    def klass(ctype):
+        ctype = ctype.strip()
+        if ctype in ('void', ''):
+            return None
+        if '*' in ctype:
+            return 'char*' if ctype.replace('const', '').strip().startswith('char') else 'ptr'
+        return {'int': 'int', 'double': 'double', 'long long': 'll', 'size_t': 'size', 'unsigned int': 'int'}[ctype.replace('const', '').strip()]
+
+    from ctypes import c_char_p, c_double, c_int, c_longlong, c_size_t, c_void_p
+    cls = {c_void_p: 'ptr', c_int: 'int', c_double: 'double', c_longlong: 'll', c_size_t: 'size', c_char_p: 'char*', None: None}
+    for ret, name, args in protos:
+        res, argtypes = C._lib.SIGNATURES[name]
+        assert cls[res] == klass(ret), (name, ret)
+        want = []
+        for a in [a for a in args.split(',') if a.strip() and a.strip() != 'void']:
+            a = a.strip()
+            want.append(klass(a if a.endswith('*') else a.rsplit(' ', 1)[0] + ('*' if a.rsplit(' ', 1)[1].startswith('*') else '')))
+        assert [cls[t] for t in argtypes] == want, f'{name}: header {want} vs ctypes {[cls[t] for t in argtypes]}'
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    for name in re.findall(r"lib\.(clamd_[a-z0-9_]+)\.argtypes = \[([^\]]*)\]", doc):
+        fn, listed = name
+        short = {'ptr': 'P', 'int': 'I', 'double': 'D', 'll': 'LL', 'size': 'SZ', 'char*': 'S'}
+        assert [x.strip() for x in listed.split(',')] == [short[cls[t]] for t in C._lib.SIGNATURES[fn][1]], f'INTEGRATION.md: stale argtypes for {fn}'
+
+
+def test_stat_rows_and_tuning_are_per_call(C):
+    """clamd_stat_rows answers from the same plan the launchers use; tuning arrives per call (no process state)."""
+    L = C._lib
+    lib = L.load()
+    t = L.Tuning()
+    assert t.as_dict()['igemm_pws'] == 1 and t.as_dict()['wgrad_blocks'] == 512 and t.cu_reserve == 0
+    # persistent kernel: one row per workgroup of a 64-channel slab (256 CUs / slabs); producer/consumer kernel: one per tile
+    assert L.stat_rows(L.OP_CONV3X3, 16, 256, 256, 64, 64, L.BF16) == 256
+    assert L.stat_rows(L.OP_CONV3X3, 16, 256, 256, 64, 64, L.BF16, tuning=L.Tuning(cu_reserve=16)) == 240
+    assert L.stat_rows(L.OP_CONV3X3, 16, 128, 128, 128, 128, L.BF16) == 128
+    assert L.stat_rows(L.OP_CONV3X3, 16, 256, 256, 64, 64, L.BF16, tuning=L.Tuning(igemm_pws=0, igemm_ws=1)) == 16 * 32 * 8
+    assert L.stat_rows(L.OP_CONV3X3, 16, 256, 256, 64, 64, L.F32, fused_bn=True) == 16 * 32 * 8     # pws declines fp32 + fused sums
+    assert L.stat_rows(L.OP_CONV3X3_WINOGRAD, 16, 256, 256, 64, 64, L.F32) == 16 * 16 * 16
+    assert L.stat_rows(L.OP_CONV3X3_WINOGRAD, 16, 256, 256, 64, 64, L.F32, tuning=L.Tuning(wino_persist=0)) == 16 * 16 * 16
+    assert L.stat_rows(L.OP_CONV1X1, 2, 64, 64, 32, 64, L.F32) == 2 * 8 * 2
+    assert L.stat_rows(L.OP_BN_BWD_REDUCE, 16, 256, 256, 0, 64, L.BF16) == 1024
+    assert L.stat_rows(L.OP_BN_BWD_REDUCE, 16, 16, 16, 0, 1024, L.BF16) == 256
+    assert lib.clamd_stat_rows(99, 1, 8, 8, 32, 32, 0, 0, None) < 0 and 'unknown op' in lib.clamd_last_error().decode()
+    bad = L.Tuning(); bad.wgrad_blocks = 100000
+    assert lib.clamd_stat_rows(L.OP_CONV3X3, 1, 8, 8, 32, 32, 0, 0, bad.ref()) < 0 and 'wgrad_blocks' in lib.clamd_last_error().decode()
+    with pytest.raises(KeyError):
+        L.Tuning(no_such_knob=1)
+    m = C.UNet(2, 3, 4)
+    m.tuning.wino_persist = 0
+    assert C.UNet(2, 3, 4).tuning.wino_persist == 1          # per model, not per process
 
 
 def test_module_surface_matches_reference_state_dict(C, golden):
@@ -128,16 +191,21 @@ def test_abi_rejects_bad_arguments_before_any_launch(C):
     lib = C._lib.load()
     call = C._lib.call
     cases = [
-        ('empty problem', 'clamd_conv3x3', (None, 32, None, None, None, 32, None, None, None, 0, 16, 16, 32, 32, 1, 0, 0, None)),
-        ('padded', 'clamd_conv3x3', (None, 32, None, None, None, 32, None, None, None, 1, 16, 16, 24, 32, 1, 0, 0, None)),
-        ('bad dtype', 'clamd_conv3x3', (None, 32, None, None, None, 32, None, None, None, 1, 16, 16, 32, 32, 1, 0, 9, None)),
-        ('empty problem', 'clamd_conv3x3_winograd', (None, 32, None, None, None, 32, None, 1, 0, 16, 32, 32, 1, None)),
-        ('must be even', 'clamd_conv3x3_winograd', (None, 32, None, None, None, 32, None, 1, 15, 16, 32, 32, 1, None)),
-        ('padded', 'clamd_conv3x3_winograd', (None, 32, None, None, None, 32, None, 1, 16, 16, 40, 32, 1, None)),
-        ('must be even', 'clamd_wgrad_winograd', (None, 32, None, 32, None, 0, None, 1, 16, 17, 32, 32, 32, 32, 32, 32, 32, 32, None)),
-        ('workspace too small', 'clamd_wgrad_winograd', (None, 32, None, 32, None, 0, None, 1, 16, 16, 32, 32, 32, 32, 32, 32, 32, 32, None)),
-        ('bad mode', 'clamd_wgrad', (7, None, 32, None, 32, None, 0, None, 1, 16, 16, 32, 32, 32, 32, 32, 32, 32, 32, 0, None)),
-        ('empty problem', 'clamd_wgrad', (0, None, 32, None, 32, None, 0, None, 0, 16, 16, 32, 32, 32, 32, 32, 32, 32, 32, 0, None)),
+        ('empty problem', 'clamd_conv3x3', (None, 32, None, None, None, 32, None, None, None, 0, 0, 16, 16, 32, 32, 1, 0, 0, None, None)),
+        ('padded', 'clamd_conv3x3', (None, 32, None, None, None, 32, None, None, None, 0, 1, 16, 16, 24, 32, 1, 0, 0, None, None)),
+        ('bad dtype', 'clamd_conv3x3', (None, 32, None, None, None, 32, None, None, None, 0, 1, 16, 16, 32, 32, 1, 0, 9, None, None)),
+        ('partial rows', 'clamd_conv3x3', (None, 32, None, None, None, 32, 1, None, None, 5, 1, 16, 16, 32, 32, 1, 0, 0, None, None)),
+        ('empty problem', 'clamd_conv3x3_winograd', (None, 32, None, None, None, 32, None, 0, 1, 0, 16, 32, 32, 1, None, None)),
+        ('must be even', 'clamd_conv3x3_winograd', (None, 32, None, None, None, 32, None, 0, 1, 15, 16, 32, 32, 1, None, None)),
+        ('padded', 'clamd_conv3x3_winograd', (None, 32, None, None, None, 32, None, 0, 1, 16, 16, 40, 32, 1, None, None)),
+        ('stat_rows', 'clamd_conv3x3_winograd', (None, 32, None, None, None, 32, 1, 7, 1, 16, 16, 32, 32, 1, None, None)),
+        ('must be even', 'clamd_wgrad_winograd', (None, 32, None, 32, None, 0, None, 1, 16, 17, 32, 32, 32, 32, 32, 32, 32, 32, None, None)),
+        ('workspace too small', 'clamd_wgrad_winograd', (None, 32, None, 32, None, 0, None, 1, 16, 16, 32, 32, 32, 32, 32, 32, 32, 32, None, None)),
+        ('bad mode', 'clamd_wgrad', (7, None, 32, None, 32, None, 0, None, 1, 16, 16, 32, 32, 32, 32, 32, 32, 32, 32, 0, None, None)),
+        ('empty problem', 'clamd_wgrad', (0, None, 32, None, 32, None, 0, None, 0, 16, 16, 32, 32, 32, 32, 32, 32, 32, 32, 0, None, None)),
+        ('stat_rows', 'clamd_bn_finalize', (1, 0, None, None, None, None, None, None, None, None, 32, 32, 1.0, 0.1, 1e-5, None)),
+        ('sum_rows', 'clamd_bn_bwd_reduce', (1, 32, None, 0, 1, 32, None, None, 1, 3, 1, 16, 16, 32, 0, None, None)),
+        ('workspace too small', 'clamd_channel_sum', (1, 32, 1, 64, 32, 32, 0, None, 0, None, None)),
         ('empty job table', 'clamd_wino_pack', (None, 0, 0, None)),
     ]
     for needle, name, args in cases:
@@ -145,6 +213,3 @@ def test_abi_rejects_bad_arguments_before_any_launch(C):
             call(name, *args)
         assert needle in str(e.value), (name, str(e.value))
         assert needle in lib.clamd_last_error().decode()
-    assert lib.clamd_set_tuning(b'no_such_key', 1) < 0 and 'unknown key' in lib.clamd_last_error().decode()
-    assert lib.clamd_set_tuning(b'wgrad_blocks', 100000) < 0
-    assert lib.clamd_set_tuning(b'wino_band', 0) == 0

@@ -149,6 +149,13 @@ def test_pack_layouts(C, name, dcode):
     assert cpad(21) == 32 and cpad(64) == 64 and cpad(65) == 128
 
 
+def stat_buf(C, op, B, H, W, cin_p, cout_p, dcode, nk=2, fused=False, tuning=None):
+    """Partial-row buffer of a statistics-producing launch, sized by clamd_stat_rows and pre-filled with NaN: a row the
+    launch fails to write shows up in every sum."""
+    rows = C._lib.stat_rows(op, B, H, W, cin_p, cout_p, dcode, fused, tuning)
+    return torch.full((rows, nk, cout_p), float('nan'), device='cuda'), rows
+
+
 CONV_SHAPES = [  # B, Cin segs, Cout, H, W
     (2, [(5, 32)], 7, 8, 12),                 # tiny ragged image, heavy channel padding
     (1, [(64, 64)], 64, 16, 16),              # exact 16x16 tile (the centre of the full-size net)
@@ -187,15 +194,14 @@ def test_conv3x3_fwd_relu_stats(C, name, dcode, shape, m_fastest):
     lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
     T = C.ops.TORCH_DT[dcode]
     y = torch.full((B, H, W, cout_p), 7.0, dtype=T, device='cuda')
-    R = lib.load().clamd_stat_replicas()
-    stats = torch.zeros(R, 2, cout_p, device='cuda')
-    lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, B, H, W, cin_p, cout_p, 1,
-             m_fastest, dcode, s)
+    stats, rows = stat_buf(C, lib.OP_CONV3X3, B, H, W, cin_p, cout_p, dcode)
+    lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, rows, B, H, W, cin_p, cout_p, 1,
+             m_fastest, dcode, None, s)
     sync()
     ref = O.relu_fwd(O.conv3x3_fwd(x, w, b))
     got = C.ops.from_nhwc(y, cout, dcode).cpu().numpy()
     assert rel_l2(got, ref) < TOL[dcode]
-    st = stats.sum(0).cpu().numpy()
+    st = stats.double().sum(0).cpu().numpy()
     np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=2e-3 if dcode == 1 else 1e-4, atol=1e-2 if dcode == 1 else 1e-3)
     np.testing.assert_allclose(st[1, :cout], (ref ** 2).sum((0, 2, 3)), rtol=4e-3 if dcode == 1 else 1e-4, atol=1e-2 if dcode == 1 else 1e-3)
     assert float(y[..., cout:].float().abs().max()) == 0.0 if cout < cout_p else True
@@ -217,14 +223,15 @@ def test_conv3x3_dgrad_and_wgrad(C, name, dcode, shape):
     pm_ = phys_map(segs)
     yb = np.maximum(rnd(rng, B, cin, H, W), 0)
     ybt = nhwc_with_segs(C, rb(yb, dcode), segs, dcode)
-    bsums = torch.zeros(lib.load().clamd_stat_replicas(), 5, cin_p, device='cuda')
-    lib.call('clamd_conv3x3', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, ptr(ybt), ptr(bsums), B, H, W, cout_p, cin_p, 0, 0, dcode, s)
+    bsums, brows = stat_buf(C, lib.OP_CONV3X3, B, H, W, cout_p, cin_p, dcode, nk=5, fused=True)
+    lib.call('clamd_conv3x3', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, ptr(ybt), ptr(bsums), brows, B, H, W, cout_p, cin_p, 0, 0,
+             dcode, None, s)
     wsb = lib.load().clamd_wgrad_workspace_bytes(0, B, H, W, cout_p, cin_p, dcode)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
     c_seg0, c_seg0p = (segs[0][0], segs[0][1]) if len(segs) == 2 else (cin, cin_p)
     lib.call('clamd_wgrad', 0, ptr(gzt), cout_p, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, cin_p, cout, cin,
-             cout, cout_p, c_seg0, c_seg0p, dcode, s)
+             cout, cout_p, c_seg0, c_seg0p, dcode, None, s)
     sync()
     rgx, rgw, _ = O.conv3x3_bwd(x, w, gz)
     pm = phys_map(segs)
@@ -241,8 +248,9 @@ def test_conv3x3_dgrad_and_wgrad(C, name, dcode, shape):
 
 
 # Every structure of the 3x3 kernels (baseline two-workgroups-per-CU, producer/consumer with 128/256/512-pixel tiles,
-# persistent producer/consumer) is forced in turn through clamd_set_tuning and must (a) match the oracle and (b) give
-# bit-identical activations -- they share the tile, the LDS image and the summation order of every output element.
+# persistent producer/consumer) is forced in turn through a per-call clamd_tuning and must (a) match the oracle, (b) give
+# bit-identical activations -- they share the tile, the LDS image and the summation order of every output element -- and
+# (c) write bit-identical statistics rows when launched twice (no float atomics).
 VARIANT_SHAPES = [  # B, Cin, Cout, H, W
     (2, 64, 64, 40, 64),      # short K, ragged tile rows
     (1, 256, 96, 16, 16),     # long K, 16-wide tiles, ragged Cout tile
@@ -263,31 +271,32 @@ def test_conv3x3_kernel_structures_agree(C, name, dcode, shape):
     x, w, b, xt, wf, wd, bp, cin_p, cout_p = _conv_case(C, rng, B, segs, cout, H, W, dcode)
     lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
     T = C.ops.TORCH_DT[dcode]
-    R = lib.load().clamd_stat_replicas()
     ref = O.relu_fwd(O.conv3x3_fwd(x, w, b))
     first = None
-    try:
-        for k1, v1, k2, v2 in CONV_VARIANTS:
-            lib.load().clamd_set_tuning(k1.encode(), v1)
-            lib.load().clamd_set_tuning(k2.encode(), v2)
-            y = torch.full((B, H, W, cout_p), 7.0, dtype=T, device='cuda')
-            stats = torch.zeros(R, 2, cout_p, device='cuda')
-            lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, B, H, W, cin_p,
-                     cout_p, 1, 0, dcode, s)
-            sync()
-            got = C.ops.from_nhwc(y, cout, dcode).cpu().numpy()
-            assert rel_l2(got, ref) < TOL[dcode], (k1, v1, k2, v2)
-            st = stats.sum(0).cpu().numpy()
-            np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=2e-3 if dcode == 1 else 1e-4, atol=1e-2 if dcode == 1 else 1e-3)
-            np.testing.assert_allclose(st[1, :cout], (ref ** 2).sum((0, 2, 3)), rtol=4e-3 if dcode == 1 else 1e-4, atol=1e-2 if dcode == 1 else 1e-3)
-            if first is None:
-                first = y.clone()
-            else:
-                assert torch.equal(first, y), f'{k1}={v1} {k2}={v2} changed the activations'
-    finally:
-        lib.load().clamd_set_tuning(b'igemm_pws', 1)
-        lib.load().clamd_set_tuning(b'igemm_ws', 2)
-        lib.load().clamd_set_tuning(b'pws_wres', 1)
+    for k1, v1, k2, v2 in CONV_VARIANTS:
+        tn = lib.Tuning(**{k1: v1, k2: v2})
+        y = torch.full((B, H, W, cout_p), 7.0, dtype=T, device='cuda')
+        stats, rows = stat_buf(C, lib.OP_CONV3X3, B, H, W, cin_p, cout_p, dcode, tuning=tn)
+        lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, rows, B, H, W, cin_p,
+                 cout_p, 1, 0, dcode, tn.ref(), s)
+        stats2 = torch.full_like(stats, float('nan'))
+        lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats2), None, None, rows, B, H, W, cin_p,
+                 cout_p, 1, 0, dcode, tn.ref(), s)
+        sync()
+        assert torch.equal(stats, stats2), f'{k1}={v1} {k2}={v2}: statistics rows differ between two identical launches'
+        got = C.ops.from_nhwc(y, cout, dcode).cpu().numpy()
+        assert rel_l2(got, ref) < TOL[dcode], (k1, v1, k2, v2)
+        st = stats.double().sum(0).cpu().numpy()
+        np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=2e-3 if dcode == 1 else 1e-4, atol=1e-2 if dcode == 1 else 1e-3)
+        np.testing.assert_allclose(st[1, :cout], (ref ** 2).sum((0, 2, 3)), rtol=4e-3 if dcode == 1 else 1e-4, atol=1e-2 if dcode == 1 else 1e-3)
+        if first is None:
+            first = y.clone()
+        else:
+            assert torch.equal(first, y), f'{k1}={v1} {k2}={v2} changed the activations'
+    # a wrong row count is refused, not silently mis-summed
+    with pytest.raises(RuntimeError, match='partial rows'):
+        lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, rows + 1, B, H, W, cin_p,
+                 cout_p, 1, 0, dcode, tn.ref(), s)
 
 
 @pytest.mark.parametrize('name,dcode', DT)
@@ -304,18 +313,17 @@ def test_wgrad_kernel_structures_agree(C, name, dcode, shape):
     wsb = lib.load().clamd_wgrad_workspace_bytes(0, B, H, W, cout_p, cin_p, dcode)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     rgw = O.conv3x3_bwd(x, np.zeros((cout, cin, 3, 3), np.float32), gz)[1]
-    try:
-        for v in (0, 1, 2):          # 2 = producer/consumer kernel with LDS-DMA staging forced (bf16 only; same as 1 otherwise)
-            lib.load().clamd_set_tuning(b'wgrad_ws', min(v, 1))
-            lib.load().clamd_set_tuning(b'wgrad_dma', 2 if v == 2 else 0)
-            gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
-            lib.call('clamd_wgrad', 0, ptr(gzt), cout_p, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, cin_p, cout, cin,
-                     cout, cout_p, cin, cin_p, dcode, s)
-            sync()
-            assert rel_l2(gw.cpu().numpy(), rgw) < (6e-5 if dcode == 2 else 2e-5), v
-    finally:
-        lib.load().clamd_set_tuning(b'wgrad_ws', 1)
-        lib.load().clamd_set_tuning(b'wgrad_dma', 1)
+    for v in (0, 1, 2):          # 2 = producer/consumer kernel with LDS-DMA staging forced (bf16 only; same as 1 otherwise)
+        tn = lib.Tuning(wgrad_ws=min(v, 1), wgrad_dma=2 if v == 2 else 0)
+        gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
+        lib.call('clamd_wgrad', 0, ptr(gzt), cout_p, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, cin_p, cout, cin,
+                 cout, cout_p, cin, cin_p, dcode, tn.ref(), s)
+        gw2 = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
+        lib.call('clamd_wgrad', 0, ptr(gzt), cout_p, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw2), B, H, W, cout_p, cin_p, cout, cin,
+                 cout, cout_p, cin, cin_p, dcode, tn.ref(), s)
+        sync()
+        assert torch.equal(gw, gw2), f'wgrad variant {v} is not bit-reproducible'
+        assert rel_l2(gw.cpu().numpy(), rgw) < (6e-5 if dcode == 2 else 2e-5), v
 
 
 WINO_SHAPES = [  # B, Cin segs, Cout, H, W (H, W even)
@@ -366,18 +374,17 @@ def test_conv3x3_winograd_fp32(C, shape):
     tab = C.ops.WinoPackTable(); tab.conv3x3(wt, wf, wd, segs, cout); tab.finalize('cuda').run()
     pt = C.ops.PackTable(0); pt.vector(bt, bp, cout); pt.finalize('cuda').run(0)
     lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
-    R = lib.load().clamd_stat_replicas()
     y = torch.full((B, H, W, cout_p), 7.0, device='cuda')
-    stats = torch.zeros(R, 2, cout_p, device='cuda')
-    lib.call('clamd_conv3x3_winograd', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), B, H, W, cin_p, cout_p, 1, s)
+    stats, rows = stat_buf(C, lib.OP_CONV3X3_WINOGRAD, B, H, W, cin_p, cout_p, 0)
+    lib.call('clamd_conv3x3_winograd', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), rows, B, H, W, cin_p, cout_p, 1, None, s)
     gz = rnd(rng, B, cout, H, W)
     gzt = C.ops.to_nhwc(dev(gz), 0)
     gx = torch.full((B, H, W, cin_p), 3.0, device='cuda')
-    lib.call('clamd_conv3x3_winograd', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, B, H, W, cout_p, cin_p, 0, s)
+    lib.call('clamd_conv3x3_winograd', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, 0, B, H, W, cout_p, cin_p, 0, None, s)
     sync()
     ref = O.relu_fwd(O.conv3x3_fwd(x, w, b))
     assert rel_l2(C.ops.from_nhwc(y, cout, 0).cpu().numpy(), ref) < TOL[0]
-    st = stats.sum(0).cpu().numpy()
+    st = stats.double().sum(0).cpu().numpy()
     np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(st[1, :cout], (ref ** 2).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
     assert float(y[..., cout:].abs().max()) == 0.0 if cout < cout_p else True
@@ -387,25 +394,27 @@ def test_conv3x3_winograd_fp32(C, shape):
     assert rel_l2(got_gx[:, [p_ for p_, l in enumerate(pm) if l >= 0]], rgx) < TOL[0]
     pad = [p_ for p_, l in enumerate(pm) if l < 0]
     assert not pad or float(np.abs(got_gx[:, pad]).max()) == 0.0
-    # block order, persistence and tile height are scheduling choices: bit-identical activations under every setting
-    try:
-        for key, val in ((b'wino_band', 1), (b'wino_band', 32), (b'wino_persist', 0), (b'wino_mt', 1), (b'wino_mt', 2)):
-            lib.load().clamd_set_tuning(key, val)
-            y2 = torch.full((B, H, W, cout_p), 7.0, device='cuda')
-            lib.call('clamd_conv3x3_winograd', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y2), cout_p, None, B, H, W, cin_p, cout_p, 1, s)
-            sync()
-            assert torch.equal(y, y2), (key, val)
-            lib.load().clamd_set_tuning(key, {b'wino_band': 0, b'wino_persist': 1, b'wino_mt': 0}[key])
-    finally:
-        for key, val in ((b'wino_band', 0), (b'wino_persist', 1), (b'wino_mt', 0)):
-            lib.load().clamd_set_tuning(key, val)
+    # block order, persistence and tile height are scheduling choices: bit-identical activations under every setting,
+    # and the statistics rows (one per pixel tile) do not depend on the grid: persistent == one workgroup per tile, bit for bit
+    for key, val in (('wino_band', 1), ('wino_band', 32), ('wino_persist', 0), ('wino_mt', 1), ('wino_mt', 2), ('cu_reserve', 37)):
+        tn = lib.Tuning(**{key: val})
+        y2 = torch.full((B, H, W, cout_p), 7.0, device='cuda')
+        stats2, rows2 = stat_buf(C, lib.OP_CONV3X3_WINOGRAD, B, H, W, cin_p, cout_p, 0, tuning=tn)
+        lib.call('clamd_conv3x3_winograd', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y2), cout_p, ptr(stats2), rows2, B, H, W, cin_p, cout_p, 1,
+                 tn.ref(), s)
+        sync()
+        assert torch.equal(y, y2), (key, val)
+        if rows2 == rows:
+            assert torch.equal(stats, stats2), (key, val)
+        else:       # another tile height: other rows, same totals
+            np.testing.assert_allclose(stats2.double().sum(0).cpu().numpy(), stats.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
     # weight gradient by Winograd
     wsb = lib.load().clamd_wgrad_winograd_workspace_bytes(cout_p, cin_p)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
     c_seg0, c_seg0p = (segs[0][0], segs[0][1]) if len(segs) == 2 else (cin, cin_p)
     lib.call('clamd_wgrad_winograd', ptr(gzt), cout_p, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, cin_p, cout, cin,
-             cout, cout_p, c_seg0, c_seg0p, s)
+             cout, cout_p, c_seg0, c_seg0p, None, s)
     sync()
     rgw = O.conv3x3_bwd(x, w, gz)[1]
     assert rel_l2(gw.cpu().numpy(), rgw) < 2e-5
@@ -435,23 +444,22 @@ def test_conv3x3_random_shapes(C, name, dcode, shape):
     x, w, b, xt, wf, wd, bp, cin_p, cout_p = _conv_case(C, rng, B, segs, cout, H, W, dcode)
     lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
     T = C.ops.TORCH_DT[dcode]
-    R = lib.load().clamd_stat_replicas()
     y = torch.full((B, H, W, cout_p), 7.0, dtype=T, device='cuda')
-    stats = torch.zeros(R, 2, cout_p, device='cuda')
-    lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, B, H, W, cin_p, cout_p, 1, 0, dcode, s)
+    stats, rows = stat_buf(C, lib.OP_CONV3X3, B, H, W, cin_p, cout_p, dcode)
+    lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, rows, B, H, W, cin_p, cout_p, 1, 0, dcode, None, s)
     gz = rb(rnd(rng, B, cout, H, W), dcode)
     gzt = C.ops.to_nhwc(dev(gz), dcode)
     gx = torch.zeros(B, H, W, cin_p, dtype=T, device='cuda')
-    lib.call('clamd_conv3x3', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, None, None, B, H, W, cout_p, cin_p, 0, 0, dcode, s)
+    lib.call('clamd_conv3x3', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, None, None, 0, B, H, W, cout_p, cin_p, 0, 0, dcode, None, s)
     wsb = lib.load().clamd_wgrad_workspace_bytes(0, B, H, W, cout_p, cin_p, dcode)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
     lib.call('clamd_wgrad', 0, ptr(gzt), cout_p, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, cin_p, cout, cin,
-             cout, cout_p, cin, cin_p, dcode, s)
+             cout, cout_p, cin, cin_p, dcode, None, s)
     sync()
     ref = O.relu_fwd(O.conv3x3_fwd(x, w, b))
     assert rel_l2(C.ops.from_nhwc(y, cout, dcode).cpu().numpy(), ref) < TOL[dcode]
-    st = stats.sum(0).cpu().numpy()
+    st = stats.double().sum(0).cpu().numpy()
     np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=2e-3 if dcode == 1 else 1e-4, atol=2e-2 if dcode == 1 else 1e-3)
     assert float(y[..., cout:].float().abs().max()) == 0.0 if cout < cout_p else True
     rgx, rgw, _ = O.conv3x3_bwd(x, w, gz)
@@ -489,15 +497,20 @@ def test_convT2x2_fwd_dgrad_wgrad(C, name, dcode, shape):
     gcat[..., cout_p:cout_p + cout] = dev(gy.transpose(0, 2, 3, 1)).to(T)
     gsl = gcat[..., cout_p:]
     gx = torch.zeros(B, h, w_, cin_p, dtype=T, device='cuda')
-    lib.call('clamd_convT2x2_dgrad', ptr(gsl), 2 * cout_p, ptr(wd), ptr(gx), cin_p, None, None, B, h, w_, cin_p, cout_p, dcode, s)
+    lib.call('clamd_convT2x2_dgrad', ptr(gsl), 2 * cout_p, ptr(wd), ptr(gx), cin_p, None, None, 0, B, h, w_, cin_p, cout_p, dcode, s)
     wsb = lib.load().clamd_wgrad_workspace_bytes(2, B, h, w_, cin_p, cout_p, dcode)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     gw = torch.zeros(cin, cout, 2, 2, device='cuda')
     lib.call('clamd_wgrad', 2, ptr(xt), cin_p, ptr(gsl), 2 * cout_p, ptr(ws), wsb, ptr(gw), B, h, w_, cin_p, cout_p, cin, cout,
-             cin, cin_p, cout, cout_p, dcode, s)
-    gb = torch.zeros(cout, device='cuda')
-    lib.call('clamd_channel_sum', ptr(gsl), 2 * cout_p, ptr(gb), B * 4 * h * w_, cout_p, cout, dcode, s)
+             cin, cin_p, cout, cout_p, dcode, None, s)
+    gb = torch.full((cout,), 9.0, device='cuda')          # overwritten, not accumulated into
+    csb = lib.load().clamd_channel_sum_workspace_bytes(cout_p)
+    cws = torch.empty(csb // 4, device='cuda')
+    lib.call('clamd_channel_sum', ptr(gsl), 2 * cout_p, ptr(gb), B * 4 * h * w_, cout_p, cout, dcode, ptr(cws), csb, None, s)
+    gb2 = torch.full((cout,), 9.0, device='cuda')
+    lib.call('clamd_channel_sum', ptr(gsl), 2 * cout_p, ptr(gb2), B * 4 * h * w_, cout_p, cout, dcode, ptr(cws), csb, None, s)
     sync()
+    assert torch.equal(gb, gb2)
     rgx, rgw, rgb = O.convT2x2_bwd(x, w, gy)
     assert rel_l2(C.ops.from_nhwc(gx, cin, dcode).cpu().numpy(), rgx) < TOL[dcode]
     assert rel_l2(gw.cpu().numpy(), rgw) < (6e-5 if dcode == 2 else 2e-5)
@@ -527,11 +540,11 @@ def test_head_fwd_bwd(C, name, dcode, shape):
     g = rb(rnd(rng, B, K, H, W), dcode)
     gt = C.ops.to_nhwc(dev(g), dcode)
     gx = torch.zeros(B, H, W, cin_p, dtype=T, device='cuda')
-    lib.call('clamd_conv1x1', ptr(gt), kp, ptr(wd), None, ptr(gx), cin_p, None, None, None, B, H, W, kp, cin_p, 0, dcode, s)
+    lib.call('clamd_conv1x1', ptr(gt), kp, ptr(wd), None, ptr(gx), cin_p, None, None, None, 0, B, H, W, kp, cin_p, 0, dcode, s)
     wsb = lib.load().clamd_wgrad_workspace_bytes(1, B, H, W, kp, cin_p, dcode)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
     gw = torch.zeros(K, cin, 1, 1, device='cuda')
-    lib.call('clamd_wgrad', 1, ptr(gt), kp, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, kp, cin_p, K, cin, K, kp, cin, cin_p, dcode, s)
+    lib.call('clamd_wgrad', 1, ptr(gt), kp, ptr(xt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, kp, cin_p, K, cin, K, kp, cin, cin_p, dcode, None, s)
     sync()
     rgx, rgw, _ = O.conv1x1_bwd(x, w, g)
     assert rel_l2(C.ops.from_nhwc(gx, cin, dcode).cpu().numpy(), rgx) < TOL[dcode]
@@ -558,8 +571,8 @@ def test_first_layer_im2col_path(C, name, dcode, shape):
     wf = torch.zeros(cout_p * kp, dtype=T, device='cuda'); bp = torch.zeros(cout_p, device='cuda')
     tab = C.ops.PackTable(dcode); tab.head(wt, wf, None, 9 * cin, cout); tab.vector(bt, bp, cout); tab.finalize('cuda').run(dcode)
     y = torch.zeros(B, H, W, cout_p, dtype=T, device='cuda')
-    stats = torch.zeros(lib.load().clamd_stat_replicas(), 2, cout_p, device='cuda')
-    lib.call('clamd_conv1x1', ptr(xcol), kp, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, B, H, W, kp, cout_p, 1, dcode, s)
+    stats, rows = stat_buf(C, lib.OP_CONV1X1, B, H, W, kp, cout_p, dcode)
+    lib.call('clamd_conv1x1', ptr(xcol), kp, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, rows, B, H, W, kp, cout_p, 1, dcode, s)
     sync()
     xr = rb(x, dcode)                                    # the gather rounds the image to the compute dtype
     ref = O.relu_fwd(O.conv3x3_fwd(xr, w, b))
@@ -570,7 +583,7 @@ def test_first_layer_im2col_path(C, name, dcode, shape):
     wsb = lib.load().clamd_wgrad_workspace_bytes(1, B, H, W, cout_p, kp, dcode)
     ws = torch.empty(wsb // 4 + 4, device='cuda'); gw = torch.zeros(cout, cin, 3, 3, device='cuda')
     lib.call('clamd_wgrad', 1, ptr(gzt), cout_p, ptr(xcol), kp, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, kp, cout, 9 * cin,
-             cout, cout_p, 9 * cin, kp, dcode, s)
+             cout, cout_p, 9 * cin, kp, dcode, None, s)
     sync()
     _, rgw, _ = O.conv3x3_bwd(xr, w, gz, need_gx=False)
     assert rel_l2(gw.cpu().numpy(), rgw) < (6e-5 if dcode == 2 else 2e-5)
@@ -587,20 +600,20 @@ def test_bn_fwd_bwd_pool(C, name, dcode, shape, pool):
     lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
     T = C.ops.TORCH_DT[dcode]
     cp = C.ops.cpad(Cc)
-    R, NS = lib.load().clamd_stat_replicas(), lib.load().clamd_bn_bwd_nsums()
+    R, NS = 16, lib.load().clamd_bn_bwd_nsums()          # R: any number of partial rows
     y = np.maximum(rnd(rng, B, Cc, H, W), 0)                       # a ReLU output: many exact zeros (ties)
     y = rb(y, dcode)
     gamma, beta = rnd(rng, Cc), rnd(rng, Cc)
     rm0, rv0 = rnd(rng, Cc), np.abs(rnd(rng, Cc)) + 0.5
     yt = C.ops.to_nhwc(dev(y), dcode)
-    # statistics as the conv epilogue would have produced them, spread over two replicas
+    # statistics as a conv epilogue would have produced them, spread over partial rows
     stats = torch.zeros(R, 2, cp, device='cuda')
     stats[0, 0, :Cc] = dev(y.sum((0, 2, 3)) * 0.25); stats[3, 0, :Cc] = dev(y.sum((0, 2, 3)) * 0.75)
     stats[1, 1, :Cc] = dev((y.astype(np.float64) ** 2).sum((0, 2, 3)).astype(np.float32))
     vec = torch.zeros(7, cp, device='cuda')
     gt_, bt_, rm, rv = dev(gamma), dev(beta), dev(rm0), dev(rv0)
     n = B * H * W
-    lib.call('clamd_bn_finalize', ptr(stats), ptr(gt_), ptr(bt_), ptr(rm), ptr(rv), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]),
+    lib.call('clamd_bn_finalize', ptr(stats), R, ptr(gt_), ptr(bt_), ptr(rm), ptr(rv), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]),
              ptr(vec[3]), cp, Cc, float(n), 0.1, 1e-5, s)
     cat = torch.full((B, H, W, 2 * cp), 2.0, dtype=T, device='cuda')       # BN output goes to the FIRST half of a concat buffer
     pooled = torch.zeros(B, H // 2, W // 2, cp, dtype=T, device='cuda') if pool else None
@@ -626,10 +639,11 @@ def test_bn_fwd_bwd_pool(C, name, dcode, shape, pool):
     gat[..., :Cc] = dev(ga.transpose(0, 2, 3, 1)).to(T)
     gp = rb(rnd(rng, B, Cc, H // 2, W // 2), dcode) if pool else None
     gpt = C.ops.to_nhwc(dev(gp), dcode) if pool else None
-    sums = torch.zeros(R, NS, cp, device='cuda')
-    lib.call('clamd_bn_bwd_reduce', ptr(gat), 2 * cp, ptr(gpt), cp, ptr(yt), cp, ptr(vec[0]), ptr(vec[1]), ptr(sums), B, H, W, cp, dcode, s)
+    sums, srows = stat_buf(C, lib.OP_BN_BWD_REDUCE, B, H, W, 1 if pool else 0, cp, dcode, nk=NS)
+    lib.call('clamd_bn_bwd_reduce', ptr(gat), 2 * cp, ptr(gpt), cp, ptr(yt), cp, ptr(vec[0]), ptr(vec[1]), ptr(sums), srows, B, H, W, cp,
+             dcode, None, s)
     dg, db, dcb = torch.zeros(Cc, device='cuda'), torch.zeros(Cc, device='cuda'), torch.zeros(Cc, device='cuda')
-    lib.call('clamd_bn_bwd_finalize', ptr(sums), ptr(gt_), ptr(vec[2]), ptr(vec[3]), ptr(vec[4]), ptr(dg), ptr(db), ptr(dcb), cp, Cc, float(n), s)
+    lib.call('clamd_bn_bwd_finalize', ptr(sums), srows, ptr(gt_), ptr(vec[2]), ptr(vec[3]), ptr(vec[4]), ptr(dg), ptr(db), ptr(dcb), cp, Cc, float(n), s)
     gz = torch.zeros(B, H, W, cp, dtype=T, device='cuda')
     lib.call('clamd_bn_bwd_apply', ptr(gat), 2 * cp, ptr(gpt), cp, ptr(yt), cp, ptr(vec[0]), ptr(vec[1]), ptr(vec[4]), ptr(gz), cp, B, H, W, cp, dcode, s)
     sync()
@@ -654,12 +668,36 @@ def test_bn_eval_mode(C):
     yt = C.ops.to_nhwc(dev(y), 0)
     vec = torch.zeros(4, 32, device='cuda'); rm, rv = dev(rm0), dev(rv0)
     gt_, bt_ = dev(gamma), dev(beta)          # keep the tensors alive: raw pointers are only borrowed
-    lib.call('clamd_bn_finalize', None, ptr(gt_), ptr(bt_), ptr(rm), ptr(rv), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), 32, 9, 48.0, 0.1, 1e-5, s)
+    lib.call('clamd_bn_finalize', None, 0, ptr(gt_), ptr(bt_), ptr(rm), ptr(rv), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), 32, 9, 48.0, 0.1, 1e-5, s)
     out = torch.zeros(2, 4, 6, 32, device='cuda')
     lib.call('clamd_bn_apply', ptr(yt), 32, ptr(vec[0]), ptr(vec[1]), ptr(out), 32, None, 0, 2, 4, 6, 32, 0, s)
     sync()
     assert rel_l2(C.ops.from_nhwc(out, 9, 0).cpu().numpy(), O.bn_eval_fwd(y, gamma, beta, rm0, rv0)) < 1e-5
     assert np.array_equal(rm.cpu().numpy(), rm0) and np.array_equal(rv.cpu().numpy(), rv0)   # eval updates nothing
+
+
+def test_integration_md_snippet_runs(C):
+    """The binding example of INTEGRATION.md, executed as written (its Conv2d -> ReLU -> BatchNorm2d unit, models/unet.py:13-15)
+    and compared with the oracle: a stale example would put an int into a pointer slot."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, 'INTEGRATION.md')).read()
+    code = doc[doc.index('```python\nimport ctypes, torch') + len('```python\n'):]
+    code = code[:code.index('```')].replace("'continual-learning_amd/libclamd.so'", repr(C._lib.LIB_PATH))
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    rng = np.random.default_rng(5)
+    B, cin, cout, H, W = 2, 20, 40, 24, 40
+    segs = [(cin, C.ops.cpad(cin))]
+    x, w, b, xt, wf, wd, bp, cin_p, cout_p = _conv_case(C, rng, B, segs, cout, H, W, 0)
+    gamma, beta = rnd(rng, cout), rnd(rng, cout)
+    rm0, rv0 = np.zeros(cout, np.float32), np.ones(cout, np.float32)
+    g_, b_, rm, rv = dev(gamma), dev(beta), dev(rm0), dev(rv0)
+    out, y, vec = ns['conv_relu_bn'](xt, wf, bp, g_, b_, rm, rv, B, H, W, cin_p, cout_p, cout)
+    sync()
+    yr = O.relu_fwd(O.conv3x3_fwd(x, w, b))
+    u_ref, _, rm_ref, rv_ref = O.bn_train_fwd(yr, gamma, beta, rm0, rv0)
+    assert rel_l2(C.ops.from_nhwc(out, cout, 0).cpu().numpy(), u_ref) < 2e-5
+    np.testing.assert_allclose(rm.cpu().numpy(), rm_ref, rtol=1e-5, atol=1e-6)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -100,7 +100,7 @@ def test_numpy_unet_small_model(golden):
         assert rel_l2(G[k], g['g0/' + k]) < 2e-3, k        # tiny grads of conv biases before BN are ~0: see below
     W1 = _state(g, 'w1')
     for k, v in W1.items():
-        # Adam's first step is lr*sign-like (m/sqrt(v) = +-1): elements whose gradient is at rounding-noise
+        # Adam's first step is lr*sign-like (m/sqrt(v) = +-1): elements whose gradient is at rounding
         # level may move by up to 2*lr differently; bound the L2 error and the fraction of such elements.
         assert rel_l2(P1[k], v) < 1e-3, k
         assert np.mean(np.abs(P1[k] - v) > 1e-4) < 0.01, k
