@@ -23,6 +23,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FLOP_PER_IMAGE_256 = 289_281_146_880          # train step, SURVEY.md §8d / BASELINE.md
+CONV3_FLOP_PER_IMAGE_256 = 275_867_762_688    # of which 3x3 convolutions (fwd + dgrad + wgrad)
+ENC10_FLOP_PER_IMAGE_256 = 2 * 226_492_416    # ... of which enc1.0 (fwd + wgrad; im2col GEMM, never Winograd)
+WINO_EXECUTED = 16.0 / 36.0                   # Winograd F(2x2,3x3): multiply-adds executed per algorithmic multiply-add
 PEAK = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0 / 3}   # dense MFMA TFLOP/s (MI355X_MICROARCH.md:42-43); bf16x3
 #                                                              # issues 3 bf16 MFMAs per algorithmic multiply-add
 DTYPE_NAME = {'fp32': 'f32', 'bf16': 'bf16', 'bf16x3': 'bf16x3 (f32 storage, hi/lo-split bf16 MFMA, f32 accumulate)'}
@@ -105,22 +108,28 @@ def run(args, dtype, rank, world, device, timing=True):
     return dt, float(loss.detach()), kern
 
 
-def pmc_traffic(dtype):
-    """HBM bytes per launch of the conv3x3 implicit-GEMM kernel from the committed rocprofv3 PMC passes
-    (profiles/*traffic_<dtype>.json, written by tools/pmc_summary.py; FETCH_SIZE x2 gfx950 correction applied).
-    A running process cannot read PMC counters of its own kernels, so this is the profile of the same command."""
+def pmc_traffic(dtype, size, batch, conv_dim):
+    """HBM bytes per launch of the conv3x3 kernel from the committed rocprofv3 PMC passes of the SAME workload
+    (profiles/*traffic_<dtype>*.json, written by tools/pmc_summary.py with a `workload` record; FETCH_SIZE x2 gfx950
+    correction applied).  A running process cannot read PMC counters of its own kernels, so this is the profile of the
+    same command; None when no profile of this exact (dtype, size, batch, conv_dim) is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'*traffic_{dtype}.json')))
-    if not files:
+    d = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', f'*traffic_{dtype}*.json')), reverse=True):
+        c = json.load(open(f))
+        if c.get('workload') == {'dtype': dtype, 'size': size, 'batch': batch, 'conv_dim': conv_dim}:
+            d = c
+            d['_file'] = os.path.basename(f)
+            break
+    if d is None:
         return None
-    d = json.load(open(files[-1]))
     tot, n = 0.0, 0
     names = ('wino_kernel<',) if dtype == 'fp32' else ('igemm_ws_kernel<', 'igemm_pws_kernel<')
     for k, v in d['kernels'].items():
         if (dtype != 'fp32' and k.startswith('igemm_kernel<') and k.replace(' ', '').split(',')[1:3] == ['0', '0']) or k.startswith(names):
             tot += (v['hbm_read_bytes_per_launch'] + v['hbm_write_bytes_per_launch']) * v['launches']
             n += v['launches']
-    return round(tot / n) if n else None
+    return (round(tot / n), d['_file']) if n else None
 
 
 def main():
@@ -162,17 +171,26 @@ def main():
                                f'{args.dtype} train step (fwd + CE + bwd + Adam), BASELINE.json configs['
                                f'{4 if (args.size, args.batch) == (512, 32) else 2 if args.dtype == "bf16" else 1}]',
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'final_loss': round(loss, 5)},
-        'step_tflops': round(value * flop_img / 1e12, 2),
-        'step_frac_of_mfma_peak': round(value * flop_img / 1e12 / (PEAK[args.dtype] * world), 4),
     }
+    # whole step against the MFMA peak: EXECUTED multiply-adds (the fp32 path runs every 3x3 convolution but enc1.0 as
+    # Winograd F(2x2,3x3): 16/36 of the algorithmic FLOPs); the algorithmic rate and the reduction are separate fields
+    from continual_learning_amd import unet as U_
+    wino = args.dtype == 'fp32' and bool(U_.WINOGRAD)
+    exec_img = flop_img - (1.0 - WINO_EXECUTED) * (CONV3_FLOP_PER_IMAGE_256 - ENC10_FLOP_PER_IMAGE_256) * scale if wino else flop_img
+    out['step_algorithmic_tflops'] = round(value * flop_img / 1e12, 2)
+    out['step_executed_tflops'] = round(value * exec_img / 1e12, 2)
+    out['step_frac_of_mfma_peak'] = round(value * exec_img / 1e12 / (PEAK[args.dtype] * world), 4)
+    out['algorithmic_speedup'] = round(flop_img / exec_img, 4)
     if kern:
         # dominant kernel = the 3x3 implicit-GEMM (forward + data-gradient launches share one kernel template)
         sec, flops, n, nbytes = kern.get('igemm_conv3x3', (0, 0, 0, 0))
         if sec > 0:
-            ach = flops / sec / 1e12
-            traffic = pmc_traffic(args.dtype)
+            alg = flops / sec / 1e12
+            ach = alg * (WINO_EXECUTED if wino else 1.0)       # FLOP/s the MFMA pipe executes
+            tr = pmc_traffic(args.dtype, args.size, args.batch, args.conv_dim)
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK[args.dtype], 'unit': 'TFLOP/s',
-                               'frac': round(ach / PEAK[args.dtype], 4), 'traffic': traffic,
+                               'frac': round(ach / PEAK[args.dtype], 4), 'traffic': tr[0] if tr else None,
+                               'traffic_source': ('profiles/' + tr[1]) if tr else None,
                                'kernel': ('conv3x3 fwd + dgrad launches: clamd::wino_kernel (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)'
                                           if args.dtype == 'fp32' else
                                           'conv3x3 implicit GEMM, fwd + dgrad launches: clamd::igemm_pws_kernel<T,TW> (persistent, <= 256 input '
@@ -181,19 +199,24 @@ def main():
                                'algorithmic_bytes_per_launch': round(nbytes / n),
                                'ms_per_step': round(sec / 2 * 1e3, 3),
                                'timing': 'HIP events around every launch, 2 instrumented steps after the timed region'}
-            if args.dtype == 'fp32':
-                # `achieved` counts ALGORITHMIC (direct-convolution) FLOPs; the Winograd kernel executes 16/36 of them
-                out['roofline']['executed_flop_fraction'] = round(16.0 / 36.0, 4)
-                out['roofline']['frac_executed'] = round(ach * 16.0 / 36.0 / PEAK[args.dtype], 4)
+            if wino:
+                # `achieved` / `frac` = EXECUTED multiply-adds (MFMA pipe utilisation); the algorithmic (direct-convolution)
+                # rate is reported beside it
+                out['roofline']['algorithmic_tflops'] = round(alg, 2)
+                out['roofline']['algorithmic_speedup'] = round(1.0 / WINO_EXECUTED, 4)
                 out['roofline']['note'] = ('Winograd F(2x2,3x3): 16 MFMA multiply-adds per 2x2 output tile and channel pair instead of 36; '
-                                           'frac = algorithmic FLOP/s / MFMA peak may exceed 1, frac_executed = MFMA pipe utilisation')
+                                           'achieved/frac count the executed 16, algorithmic_tflops the 36')
         sec, flops, n, _ = kern.get('wgrad_conv3x3', (0, 0, 0, 0))
         if sec > 0:
-            ach = flops / sec / 1e12
+            alg = flops / sec / 1e12
+            ach = alg * (WINO_EXECUTED if wino else 1.0)
             out['roofline_wgrad'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK[args.dtype],
                                      'unit': 'TFLOP/s', 'frac': round(ach / PEAK[args.dtype], 4), 'launches': n,
                                      'avg_launch_ms': round(sec / n * 1e3, 4), 'ms_per_step': round(sec / 2 * 1e3, 3),
                                      'note': 'wgrad kernel + its split-K reduce kernel'}
+            if wino:
+                out['roofline_wgrad']['algorithmic_tflops'] = round(alg, 2)
+                out['roofline_wgrad']['algorithmic_speedup'] = round(1.0 / WINO_EXECUTED, 4)
     # further dtypes: by default on the single-GPU run only (the N-GPU scaling runs measure the headline dtype and nothing else)
     also = args.also if args.also is not None else ('bf16x3,bf16' if world == 1 else '')
     for other in [d for d in also.split(',') if d and d != args.dtype]:
@@ -216,8 +239,11 @@ def main():
         import continual_learning_amd as C
         xb = torch.from_numpy(C.synth.images(1234, args.batch, 3, args.size, args.size))
         yb = torch.from_numpy(C.synth.labels(1234, args.batch, args.size, args.size, args.num_classes))
-        cb = TC.time_cpu_baseline(batch=args.batch, size=args.size, num_classes=args.num_classes,
-                                  conv_dim=args.conv_dim, steps=1, warmup=1, images=xb, labels=yb)
+        # 1 warm-up + best of 3 steps on the BASELINE workload (~25 s of CPU work on 16 cores); larger
+        # workloads (config 5 is 8x the work) get one timed step so the run stays bounded
+        cb = TC.time_cpu_baseline(batch=args.batch, size=args.size, num_classes=args.num_classes, conv_dim=args.conv_dim,
+                                  steps=3 if args.size * args.size * args.batch <= 256 * 256 * 16 else 1, warmup=1,
+                                  images=xb, labels=yb)
         out['cpu_baseline'] = {'value': round(cb['value'], 3), 'unit': 'images/sec', 'cores': cb['cores'],
                                'kind': 'port', 'sample': cb['sample']}
     if rank == 0:

@@ -1,11 +1,12 @@
 """Summarise rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs) into per-kernel HBM traffic.
 
-    python tools/pmc_summary.py gpurun_out/pmc_fp32_FETCH_SIZE gpurun_out/pmc_fp32_WRITE_SIZE fp32 3 > profiles/r01_traffic_fp32.json
+    python tools/pmc_summary.py gpurun_out/pmc_fp32_FETCH_SIZE gpurun_out/pmc_fp32_WRITE_SIZE fp32 3 [size batch conv_dim] > profiles/r02_traffic_fp32.json
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: both counters are in KiB; on gfx950
 FETCH_SIZE reports exactly HALF the bytes of a wide coalesced stream (16 B/lane loads -- what every kernel here
 issues), so it is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
-Last argument = number of train steps the profiled command ran (warm-up + timed).
+4th argument = number of train steps the profiled command ran (warm-up + timed); then the workload the command ran
+(image size, batch, conv_dim; default 256 16 64), recorded so that bench.py only quotes a profile of ITS workload.
 """
 import csv
 import glob
@@ -34,7 +35,9 @@ def short(n):
 def main():
     fd, wd, dtype, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
     F, W = load(fd), load(wd)
-    out = {'dtype': dtype, 'steps_profiled': steps, 'units': 'bytes',
+    size, batch, cd = (int(v) for v in (sys.argv[5:8] + ['256', '16', '64'][len(sys.argv[5:8]):]))
+    out = {'dtype': dtype, 'workload': {'dtype': dtype, 'size': size, 'batch': batch, 'conv_dim': cd},
+           'steps_profiled': steps, 'units': 'bytes',
            'correction': 'FETCH_SIZE KiB x1024 x2 (gfx950 half-count of wide coalesced reads); WRITE_SIZE KiB x1024',
            'kernels': {}}
     tot = init = 0.0
