@@ -80,12 +80,14 @@ SIGNATURES = {
     'clamd_wgrad_winograd': (_I, [_P, _I, _P, _I, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_conv3x3_winograd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_ce_workspace_bytes': (_SZ, []),
+    'clamd_ce_bad_label_count_offset': (_SZ, []),
     'clamd_ce_fwd_bwd': (_I, [_P, _P, _P, _I, _I, _D, _D, _P, _P, _P, _SZ, _I, _I, _I, _I, _LL, _D, _P]),
     'clamd_adam_step': (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
     'clamd_argmax_confusion': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'clamd_voc_prepare': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_label_to_rgb': (_I, [_P, _P, _LL, _LL, _P]),
     'clamd_fill_f32': (_I, [_P, _LL, _D, _P]),
+    'clamd_scale_by_device_scalar': (_I, [_P, _LL, _P, _P]),
 }
 
 _lib = None

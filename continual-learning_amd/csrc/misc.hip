@@ -123,19 +123,29 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackJob* __restrict__ j
 // logits NCHW fp32 [B,K,H,W]; labels int64 [B,H,W].  nn.CrossEntropyLoss() (trainer.py:113): mean over pixels
 // whose label != ignore_index.  Optional distillation (build-defined, parity unpinned):
 //   + lam * mean_px KL( softmax(z_old[:, :c_old]/T) || softmax(z[:, :c_old]/T) )
+// count[0] = pixels that take part in the mean (label != ignore_index and inside [0, K)); count[1] = pixels whose label is
+// neither ignore_index nor a class -- torch's CrossEntropyLoss asserts on those; here they are left out of the loss and
+// REPORTED (the host side exposes the counter, loss.py), so a label bug in a class split cannot hide.
 __global__ void count_valid_kernel(const long long* __restrict__ labels, long long n, long long ignore_index,
                                    int K, unsigned int* count) {
-    unsigned int c = 0;
+    unsigned int c = 0, bad = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long l = labels[i];
-        c += (l != ignore_index && l >= 0 && l < K) ? 1u : 0u;
+        const bool in = l >= 0 && l < K;
+        c += (l != ignore_index && in) ? 1u : 0u;
+        bad += (l != ignore_index && !in) ? 1u : 0u;
     }
-    // ONE atomic per block: atomics on a single address serialise at ~12 ns each (1024 blocks x 4 waves: 50 us, measured)
-    __shared__ unsigned int wsum[4];
+    // ONE (integer, order-independent) atomic per block: atomics on a single address serialise at ~12 ns each
+    __shared__ unsigned int wsum[2][4];
     c = (unsigned int)wave_sum((float)c);   // <= 64 * iterations: exact in fp32 for the sizes used here
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    bad = (unsigned int)wave_sum((float)bad);
+    if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = c; wsum[1][threadIdx.x >> 6] = bad; }
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(count, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    if (threadIdx.x == 0) {
+        atomicAdd(count, wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3]);
+        const unsigned int b = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+        if (b) atomicAdd(count + 1, b);
+    }
 }
 
 template <int KMAX>
@@ -308,7 +318,7 @@ __global__ void argmax_confusion_kernel(const float* __restrict__ logits, const 
         if (pred) pred[i] = arg;
         if (labels) {
             const long long t = labels[i];
-            if (t >= 0 && t < Kc) atomicAdd(&hist[(int)t * Kc + arg], 1u);
+            if (t >= 0 && t < Kc && arg < Kc) atomicAdd(&hist[(int)t * Kc + arg], 1u);      // Kc < K: predictions outside the matrix are dropped
         }
     }
     __syncthreads();
@@ -373,6 +383,14 @@ __global__ void label_to_rgb_kernel(const long long* __restrict__ labels, float*
     }
 }
 
+// p *= *scale unless *scale == 1 (wave-uniform early exit: no memory traffic).  loss.backward() hands the loss function an
+// upstream gradient of exactly 1 as a DEVICE scalar; testing it on the device avoids both a host sync and a 176-MB pass.
+__global__ void scale_by_dev_kernel(float* p, long long n, const float* __restrict__ scale) {
+    const float v = *scale;
+    if (v == 1.f) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] *= v;
+}
+
 __global__ void fill_kernel(float* p, long long n, float v) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -404,6 +422,7 @@ int clamd_pack(const void* jobs_dev, int njobs, int total_blocks, int dtype, voi
 }
 
 size_t clamd_ce_workspace_bytes(void) { return (size_t)(2 * 2048 + 4) * sizeof(float); }
+size_t clamd_ce_bad_label_count_offset(void) { return (size_t)(2 * 2048 + 1) * sizeof(float); }
 
 int clamd_ce_fwd_bwd(const float* logits, const long long* labels, const float* old_logits, int K_old_total, int c_old,
                      double temperature, double lam, float* dlogits, float* loss3, void* workspace, size_t ws_bytes,
@@ -415,7 +434,7 @@ int clamd_ce_fwd_bwd(const float* logits, const long long* labels, const float* 
     float* partial = (float*)workspace;
     unsigned int* nvalid = (unsigned int*)(partial + 2 * 2048);
     const long long HW = (long long)H * W, npix = (long long)B * HW;
-    hipError_t me = hipMemsetAsync(nvalid, 0, sizeof(unsigned int), s);
+    hipError_t me = hipMemsetAsync(nvalid, 0, 2 * sizeof(unsigned int), s);
     if (me != hipSuccess) return clamd_fail("ce: memset failed");
     int g = (int)((npix + 255) / 256);
     if (g > 2048) g = 2048;
@@ -466,6 +485,14 @@ int clamd_label_to_rgb(const long long* labels, float* rgb, long long n_img, lon
     if (g < 1) g = 1;
     hipLaunchKernelGGL(label_to_rgb_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, labels, rgb, n_img, hw);
     return clamd_check_launch("label_to_rgb");
+}
+
+int clamd_scale_by_device_scalar(float* p, long long n, const float* scale_dev, void* stream) {
+    if (n <= 0 || !scale_dev) return clamd_fail("scale_by_device_scalar: bad arguments");
+    long long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(scale_by_dev_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p, n, scale_dev);
+    return clamd_check_launch("scale_by_device_scalar");
 }
 
 int clamd_fill_f32(float* p, long long n, double v, void* stream) {

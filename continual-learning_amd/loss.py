@@ -17,7 +17,7 @@ from ._lib import call, ptr
 
 class _CEFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, labels, old_logits, c_old, temperature, lam, ignore_index):
+    def forward(ctx, logits, labels, old_logits, c_old, temperature, lam, ignore_index, holder):
         if not logits.is_cuda:
             raise RuntimeError('continual-learning_amd loss runs only on GPU tensors: there is no CPU fallback')
         lib = _lib.load()
@@ -42,22 +42,29 @@ class _CEFn(torch.autograd.Function):
              float(lam), ptr(dl), ptr(out3), ptr(ws), wsb, B, K, H, W, int(ignore_index), 1.0, _lib.stream_ptr())
         ctx.save_for_backward(dl)
         ctx.parts = out3
+        # labels outside [0, K) that are not ignore_index: a device counter on the criterion (int(...) synchronises);
+        # torch's CrossEntropyLoss asserts on such labels, here they are left out of the mean and counted
+        off = lib.clamd_ce_bad_label_count_offset() // 4
+        holder.bad_labels = ws[off:off + 1].view(torch.int32)
         return out3[0].clone()
 
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        # g is the scalar upstream gradient (1.0 for loss.backward()); scaling happens in place on our own buffer
-        return dl.mul_(g), None, None, None, None, None, None
+        # g is the scalar upstream gradient on the DEVICE (exactly 1 for loss.backward()): the kernel tests it there and
+        # touches d logits only when it is not 1 -- no host sync, no 176-MB multiply-by-one pass per step
+        call('clamd_scale_by_device_scalar', ptr(dl), dl.numel(), ptr(g.contiguous().float()), _lib.stream_ptr())
+        return dl, None, None, None, None, None, None, None
 
 
 class CrossEntropyLoss(nn.Module):
     def __init__(self, ignore_index=-100):
         super().__init__()
         self.ignore_index = ignore_index
+        self.bad_labels = None        # after a forward: device int32[1], labels that are neither ignore_index nor a class
 
     def forward(self, logits, labels):
-        return _CEFn.apply(logits, labels, None, 0, 1.0, 0.0, self.ignore_index)
+        return _CEFn.apply(logits, labels, None, 0, 1.0, 0.0, self.ignore_index, self)
 
 
 class DistillationCrossEntropy(nn.Module):
@@ -68,4 +75,4 @@ class DistillationCrossEntropy(nn.Module):
         self.c_old, self.temperature, self.lam, self.ignore_index = c_old, temperature, lam, ignore_index
 
     def forward(self, logits, labels, old_logits):
-        return _CEFn.apply(logits, labels, old_logits.detach(), self.c_old, self.temperature, self.lam, self.ignore_index)
+        return _CEFn.apply(logits, labels, old_logits.detach(), self.c_old, self.temperature, self.lam, self.ignore_index, self)

@@ -55,6 +55,21 @@ def labels(seed, batch, height, width, num_classes, cell=16, first_image=0, clas
     return lab
 
 
+def class_colours(num_classes, seed=0):
+    """One RGB triple in [-1, 1) per class (closed form), for ``images_with_signal``."""
+    return (_uniform01(seed ^ 0x5EED, num_classes * 3) * np.float32(2.0) - np.float32(1.0)).reshape(num_classes, 3)
+
+
+def images_with_signal(seed, lab, num_classes, mix=0.5, first_image=0):
+    """Images that carry their labels: x = (1 - mix) * U(-1,1) noise + mix * colour[label] (fp32 NCHW, still inside [-1, 1)).
+    ``images`` alone is independent of the labels (a model can only memorise it); the fixed 64-image set of the
+    mIoU-after-training check uses this so that a few Adam steps move mIoU far from chance."""
+    b, h, w = lab.shape
+    noise = images(seed, b, 3, h, w, first_image=first_image)
+    col = class_colours(num_classes)[lab].transpose(0, 3, 1, 2)            # [B,3,H,W]
+    return (np.float32(1.0 - mix) * noise + np.float32(mix) * col).astype(np.float32)
+
+
 def closed_form_tensor(name, shape, seed=0):
     """Deterministic stand-in for torch's default init, as a function of (name, flat index):
     conv / convT weights and biases ~ U(+-1/sqrt(fan_in)); BN gamma in [0.5,1.5), beta in [-0.25,0.25)

@@ -12,7 +12,6 @@ Out of scope here: JPEG dumps, prints, checkpoint file
 Continual learning (config 4): ``begin_task2(c_old, ...)`` snapshots the model and switches the criterion to
 DistillationCrossEntropy and/or enables the L2-to-old-weights term (both build-defined).
 """
-import copy
 import os
 import warnings
 from types import SimpleNamespace
@@ -56,7 +55,12 @@ class Trainer:
 
     def begin_task2(self, c_old, distill_lambda=1.0, temperature=2.0, l2_lambda=0.0):
         """Freeze a snapshot of the current model (task 1) and regularise further training towards it."""
-        self.old_model = copy.deepcopy(self.model).eval()
+        # a fresh module with a CLONE of the state (not copy.deepcopy: that would duplicate the engine's multi-GB activation
+        # buffers and, under data parallelism, the GradSync object with its process group and stream)
+        m = self.model
+        self.old_model = UNet(m.num_classes, m.in_dim, m.conv_dim, compute_dtype=m.compute_dtype).to(self.device)
+        self.old_model.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()}, strict=True)
+        self.old_model.eval()
         for p in self.old_model.parameters():
             p.requires_grad_(False)
         self.distill = DistillationCrossEntropy(c_old, temperature, distill_lambda) if distill_lambda > 0 else None

@@ -474,6 +474,11 @@ class _Engine:
             if lo <= p0.grad.data_ptr() < lo + 4 * self.gflat.numel():
                 # the previous gradients are still installed as .grad (no zero_grad since): accumulate semantics
                 # need them intact, so this backward writes into a fresh buffer
+                if m.grad_sync is not None:
+                    # AccumulateGrad would add the new buffer into .grad on this stream while RCCL is still reducing it
+                    # on the side stream: refuse instead of racing (the reference zeroes gradients every step, trainer.py:173)
+                    raise RuntimeError('gradient accumulation (backward without zero_grad) is not supported together with '
+                                       'ddp.GradSync: call optimizer.zero_grad() before every backward')
                 self.gflat = torch.empty_like(self.gflat)
         base = self.gflat.data_ptr()
         g = {n: base + 4 * o for n, (o, _) in self.goffset.items()}      # raw device pointers into the flat buffer

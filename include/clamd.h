@@ -179,6 +179,9 @@ int clamd_pack(const void* jobs_dev, int njobs, int total_blocks, int dtype, voi
 /* nn.CrossEntropyLoss() forward+backward (trainer.py:113,174-175) on fp32 NCHW logits / int64 labels, plus the
  * build-defined distillation term when old_logits != NULL.  loss3 = {total, ce, kd}. */
 size_t clamd_ce_workspace_bytes(void);
+/* byte offset inside the workspace of an unsigned int: pixels whose label is neither ignore_index nor a class (torch's
+ * CrossEntropyLoss asserts on those; here they are left out of the mean and counted for the caller to check). */
+size_t clamd_ce_bad_label_count_offset(void);
 int clamd_ce_fwd_bwd(const float* logits, const long long* labels, const float* old_logits, int K_old_total, int c_old,
                      double temperature, double lam, float* dlogits, float* loss3, void* workspace, size_t ws_bytes,
                      int B, int K, int H, int W, long long ignore_index, double grad_scale, void* stream);
@@ -198,6 +201,9 @@ int clamd_voc_prepare(const unsigned char* img_rgb, const unsigned char* mask_rg
 /* voc.to_rgb (datasets/voc.py:74-89): labels int64 [N,H,W] -> palette colours [N,3,H,W] (0..255 as float). */
 int clamd_label_to_rgb(const long long* labels, float* rgb, long long n_img, long long hw, void* stream);
 int clamd_fill_f32(float* p, long long n, double v, void* stream);
+/* p[i] *= *scale_dev for a DEVICE scalar, nothing at all when it is exactly 1 (the upstream gradient loss.backward()
+ * hands to the loss function, trainer.py:175): no host sync, no pass over d logits in the common case. */
+int clamd_scale_by_device_scalar(float* p, long long n, const float* scale_dev, void* stream);
 
 #ifdef __cplusplus
 }

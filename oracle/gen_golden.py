@@ -6,6 +6,9 @@ The reference cannot travel to the GPU box, so the vectors captured here are com
 (inputs + expected outputs only; no reference source).  What runs below:
   * /root/reference/models/unet.py  UNet            (imported, unmodified)
   * /root/reference/metrics.py      eval_metrics    (imported, unmodified)
+  * /root/reference/datasets/voc.py to_mask, to_rgb (imported, unmodified, with an EMPTY stand-in module named
+    `torchvision` in sys.modules: voc.py imports torchvision.transforms at :7 but the two palette functions at
+    :56-89 use only numpy and torch -- SURVEY.md §8c)
   * trainer.py cannot be imported (needs torchvision, SURVEY.md §8c -- an ordinary
     ModuleNotFoundError, not a denial); its hot loop trainer.py:108-114,147,172-176 is 12 lines of
     stock torch calls, which are issued here verbatim in meaning: Adam(lr, betas=[b1,b2]),
@@ -41,6 +44,106 @@ def _np(sd):
 def _shapes(model):
     return {k: tuple(v.shape) for k, v in model.state_dict().items()
             if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))}
+
+
+def capture_forward_only(ref_unet, ref_metrics, synth, tag, num_classes, conv_dim, batch, size, logits_stride):
+    """Train-mode forward + loss of a workload whose full train step does not fit this container's memory (config 5:
+    512x512 bs32 is 8x config 2's ~8 GB of saved activations): logits subsample, loss, arg-max histogram, mIoU and the
+    BatchNorm running statistics after the one forward.  The full step at this image size is pinned by the bs8 capture."""
+    torch.manual_seed(0)
+    model = ref_unet.UNet(num_classes=num_classes, in_dim=3, conv_dim=conv_dim)
+    state = synth.closed_form_state(_shapes(model), seed=0)
+    sd = model.state_dict()
+    for k, v in state.items():
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    model.train()
+    xt = torch.from_numpy(synth.images(1234, batch, 3, size, size))
+    yt = torch.from_numpy(synth.labels(1234, batch, size, size, num_classes))
+    with torch.no_grad():
+        logits = model(xt)
+        loss = torch.nn.CrossEntropyLoss()(logits, yt)
+    pred = logits.argmax(1)
+    oa, pc, miu, mx = ref_metrics.eval_metrics(yt, pred, num_classes)
+    out = {'num_classes': num_classes, 'conv_dim': conv_dim, 'batch': batch, 'size': size, 'data_seed': 1234, 'weight_seed': 0,
+           'logits_flat_stride': logits_stride, 'logits': logits.numpy().reshape(-1)[::logits_stride].copy(),
+           'loss': float(loss), 'pred_hist': np.bincount(pred.numpy().reshape(-1), minlength=num_classes),
+           'metrics': np.array([float(oa), float(pc), float(miu), float(mx)], np.float32),
+           'stats1': np.concatenate([v.numpy().reshape(-1) for k, v in model.state_dict().items()
+                                     if k.endswith(('running_mean', 'running_var'))])}
+    np.savez_compressed(os.path.join(OUT, f'unet_{tag}.npz'), **out)
+    print(tag, 'loss', float(loss), 'mIoU', float(miu))
+
+
+def capture_training_miou(ref_unet, ref_metrics, synth, tag, num_classes, conv_dim, batch, size, nimg, epochs, lr):
+    """north_star: 'mIoU within +-0.1 of reference on a fixed synthetic 21-class set' (64 images).  The
+    reference model is trained with the hot loop of trainer.py:147,165-176 (scheduler-less: constant lr) for `epochs`
+    passes over the fixed nimg-image set in batches of `batch`, then evaluated on the same set: the training-time metric of
+    trainer.py:183-188 (arg-max of the train-mode outputs of the LAST epoch, confusion accumulated over its batches) and
+    the eval-mode pass of trainer.py:270-284 (model.eval())."""
+    torch.manual_seed(0)
+    model = ref_unet.UNet(num_classes=num_classes, in_dim=3, conv_dim=conv_dim)
+    state = synth.closed_form_state(_shapes(model), seed=0)
+    sd = model.state_dict()
+    for k, v in state.items():
+        sd[k] = torch.from_numpy(v)
+    model.load_state_dict(sd)
+    model.train()
+    optim = torch.optim.Adam(model.parameters(), lr=lr, betas=[0.5, 0.99])
+    crit = torch.nn.CrossEntropyLoss()
+    nb = nimg // batch
+    data = []
+    for i in range(nb):      # images that carry their labels (synth.images_with_signal): mIoU moves far from chance in a few steps
+        lab = synth.labels(1234, batch, size, size, num_classes, first_image=i * batch)
+        data.append((torch.from_numpy(synth.images_with_signal(1234, lab, num_classes, first_image=i * batch)), torch.from_numpy(lab)))
+    losses, train_conf = [], torch.zeros(num_classes, num_classes)
+    for ep in range(epochs):
+        for xt, yt in data:
+            logits = model(xt)
+            optim.zero_grad()
+            loss = crit(logits, yt)
+            loss.backward()
+            optim.step()
+            losses.append(float(loss))
+            if ep == epochs - 1:
+                pred = logits.detach().argmax(1)
+                for a, b in zip(yt, pred):
+                    train_conf += ref_metrics._fast_conf_matrix(a.flatten(), b.flatten(), num_classes)
+    model.eval()
+    eval_conf = torch.zeros(num_classes, num_classes)
+    with torch.no_grad():
+        for xt, yt in data:
+            pred = model(xt).argmax(1)
+            for a, b in zip(yt, pred):
+                eval_conf += ref_metrics._fast_conf_matrix(a.flatten(), b.flatten(), num_classes)
+    out = {'num_classes': num_classes, 'conv_dim': conv_dim, 'batch': batch, 'size': size, 'nimg': nimg, 'epochs': epochs,
+           'lr': lr, 'losses': np.array(losses), 'train_conf': train_conf.numpy(), 'eval_conf': eval_conf.numpy(),
+           'train_miou': float(ref_metrics.mean_IU_2(train_conf)), 'eval_miou': float(ref_metrics.mean_IU_2(eval_conf)),
+           'train_acc': float(ref_metrics.overall_pixel_acc(train_conf)), 'eval_acc': float(ref_metrics.overall_pixel_acc(eval_conf))}
+    np.savez_compressed(os.path.join(OUT, f'train_{tag}.npz'), **out)
+    print(tag, 'losses', losses[0], '->', losses[-1], 'train mIoU', out['train_miou'], 'eval mIoU', out['eval_miou'])
+
+
+def capture_voc():
+    """datasets/voc.py:56-89 to_mask / to_rgb, imported from the reference with an empty `torchvision` stand-in (the module
+    only needs to EXIST for voc.py:7's import; neither function touches it)."""
+    import types
+    tv = types.ModuleType('torchvision')
+    tv.transforms = types.ModuleType('torchvision.transforms')
+    sys.modules.setdefault('torchvision', tv)
+    sys.modules.setdefault('torchvision.transforms', tv.transforms)
+    voc = _load('ref_voc', os.path.join(REF, 'datasets', 'voc.py'))
+    rng = np.random.RandomState(7)
+    pal = np.array(voc.palette, np.uint8)                       # 22 colours, the last one is "void"
+    idx = rng.randint(0, 22, (24, 40))
+    idx[:3, :5] = 21                                            # void pixels -> class 0 (voc.py:67-68)
+    mask_rgb = pal[idx]
+    labels = voc.to_mask(mask_rgb).numpy()
+    lab_in = rng.randint(0, 22, (3, 10, 12)).astype(np.int64)
+    rgb = voc.to_rgb(torch.from_numpy(lab_in)).numpy()
+    np.savez_compressed(os.path.join(OUT, 'voc.npz'), palette=pal, mask_rgb=mask_rgb, labels=labels.astype(np.int64),
+                        to_rgb_in=lab_in, to_rgb_out=rgb)
+    print('voc ok', labels.shape, rgb.shape, rgb.dtype)
 
 
 def capture_model(ref_unet, ref_metrics, synth, tag, num_classes, conv_dim, batch, size, steps, lr,
@@ -206,7 +309,9 @@ def main():
     ref_unet = _load('ref_unet', os.path.join(REF, 'models', 'unet.py'))
     ref_metrics = _load('ref_metrics', os.path.join(REF, 'metrics.py'))
     synth = _synth()
-    which = sys.argv[1:] or ['ops', 'metrics', 'small', 'mid', 'full']
+    which = sys.argv[1:] or ['ops', 'metrics', 'voc', 'small', 'mid', 'full', 'c5', 'miou64']
+    if 'voc' in which:
+        capture_voc()
     if 'ops' in which:
         capture_ops()
     if 'metrics' in which:
@@ -218,6 +323,17 @@ def main():
     if 'full' in which:      # config 2: the real thing, 256x256 bs16 conv_dim 64 (about 1 minute of CPU)
         capture_model(ref_unet, ref_metrics, synth, 'cd64_c21_256', 21, 64, 16, 256, 2, 1e-4,
                       store_weights=False, logits_stride=997, store_grads=False)
+
+
+    if 'c5' in which:
+        # BASELINE.json configs[4] (512x512, bs32 per GPU).  The full train step at bs32 needs ~60 GB of saved activations on
+        # the CPU -- more than this container has -- so: (a) the full 2-step capture at 512x512 with bs8 (every 512^2 tile
+        # geometry, gradients, Adam), (b) the train-mode forward + loss at the real bs32 (BatchNorm statistics over 32 images).
+        capture_model(ref_unet, ref_metrics, synth, 'cd64_c21_512_b8', 21, 64, 8, 512, 2, 1e-4,
+                      store_weights=False, logits_stride=1999, store_grads=False)
+        capture_forward_only(ref_unet, ref_metrics, synth, 'cd64_c21_512_b32_fwd', 21, 64, 32, 512, logits_stride=7993)
+    if 'miou64' in which:    # the fixed 64-image set of SURVEY §8d, 4 epochs of 4 x bs16 steps at 256x256 (about 4 CPU-minutes)
+        capture_training_miou(ref_unet, ref_metrics, synth, 'cd64_c21_256_n64', 21, 64, 16, 256, 64, 4, 1e-3)
 
 
 if __name__ == '__main__':

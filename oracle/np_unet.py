@@ -290,20 +290,27 @@ def pad_center_crop(a, h, w, pad=10):
     return a[top:top + h, left:left + w]
 
 
+def to_mask(mask_rgb):
+    """voc.to_mask (datasets/voc.py:56-72): [H,W,3] uint8 palette colours -> [H,W] int64 class index, void -> 0; a colour
+    outside the palette raises ValueError (list.index).  Pinned by tests/golden/voc.npz (captured from the reference)."""
+    H, W = mask_rgb.shape[:2]
+    m = mask_rgb.reshape(-1, 3)
+    lab = np.empty(m.shape[0], np.int64)
+    for i, px in enumerate(map(tuple, m)):           # the reference's per-pixel loop, voc.py:64-70
+        lab[i] = 0 if px == (224, 224, 192) else VOC_PALETTE.index(px)
+    return lab.reshape(H, W)
+
+
 def voc_prepare(img_u8, mask_u8, h, w):
     """VOC.__getitem__ (datasets/voc.py:127-144): image -> Pad, CenterCrop, ToTensor, Normalize(0.5, 0.5) [3,h,w] f32;
     mask -> Pad, CenterCrop, to_mask (voc.py:56-72: palette index, void -> 0) [h,w] int64."""
     img = pad_center_crop(img_u8, h, w).astype(np.float32) / np.float32(255)
     image = ((img - np.float32(0.5)) / np.float32(0.5)).transpose(2, 0, 1)
-    m = pad_center_crop(mask_u8, h, w).reshape(-1, 3)
-    lab = np.empty(m.shape[0], np.int64)
-    for i, px in enumerate(map(tuple, m)):           # the reference's per-pixel loop, voc.py:64-70
-        lab[i] = 0 if px == (224, 224, 192) else VOC_PALETTE.index(px)
-    return np.ascontiguousarray(image), lab.reshape(h, w)
+    return np.ascontiguousarray(image), to_mask(pad_center_crop(mask_u8, h, w))
 
 
 def to_rgb(labels):
-    """voc.to_rgb (datasets/voc.py:74-89)."""
+    """voc.to_rgb (datasets/voc.py:74-89).  Pinned by tests/golden/voc.npz."""
     pal = np.array(VOC_PALETTE, np.float32)
     return pal[labels].transpose(0, 3, 1, 2)
 

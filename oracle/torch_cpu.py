@@ -94,6 +94,45 @@ def train_step(model, optim, criterion, images, labels):
     return out, loss
 
 
+def distill_loss(z_new, z_old, c_old, temperature, lam):
+    """BUILD-DEFINED (no reference code; SURVEY.md §8a A12, parity unpinned): the autograd form of
+    oracle.np_unet.distill_kl -- lam * mean_px KL(softmax(z_old[:, :c_old]/T) || softmax(z_new[:, :c_old]/T))."""
+    la = torch.log_softmax(z_new[:, :c_old] / temperature, 1)
+    lb = torch.log_softmax(z_old[:, :c_old].detach() / temperature, 1)
+    npx = z_new.shape[0] * z_new.shape[2] * z_new.shape[3]
+    return lam * (lb.exp() * (lb - la)).sum() / npx
+
+
+def continual_two_task(model, task1, task2, c_old, distill_lambda, temperature, l2_lambda, lr):
+    """BASELINE.json configs[3] (SURVEY.md §8d "Config 4"), composed from stock torch ops: task 1 = the hot loop of
+    trainer.py:172-176 over `task1` [(images, labels restricted to classes < c_old)]; snapshot; task 2 = the same loop over
+    `task2` with loss = CE + distillation towards the frozen snapshot (eval mode) + l2_lambda * sum ||theta - theta_old||^2.
+    BUILD-DEFINED procedure (the reference has no continual-learning code): parity unpinned.
+    Returns dict(losses1, losses2 [(total, ce, kd, l2)], old_state)."""
+    import copy
+    optim = make_optimizer(model, lr=lr)
+    crit = nn.CrossEntropyLoss()
+    model.train()
+    losses1 = [float(train_step(model, optim, crit, x, y)[1].detach()) for x, y in task1]
+    old = copy.deepcopy(model).eval()
+    for p in old.parameters():
+        p.requires_grad_(False)
+    old_params = [p.detach().clone() for p in model.parameters()]
+    losses2 = []
+    for x, y in task2:
+        out = model(x)
+        optim.zero_grad()
+        with torch.no_grad():
+            zo = old(x)
+        ce = crit(out, y)
+        kd = distill_loss(out, zo, c_old, temperature, distill_lambda) if distill_lambda > 0 else out.new_zeros(())
+        l2 = l2_lambda * sum(((p - o) ** 2).sum() for p, o in zip(model.parameters(), old_params)) if l2_lambda > 0 else out.new_zeros(())
+        (ce + kd + l2).backward()
+        optim.step()
+        losses2.append((float((ce + kd).detach()), float(ce.detach()), float(kd.detach()), float(l2.detach())))
+    return {'losses1': losses1, 'losses2': losses2, 'old_state': {k: v.detach().clone() for k, v in old.state_dict().items()}}
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota (os.cpu_count() reports the
     whole host on the GPU box and oversubscribing 256 threads on a 16-core share is ~10x slower)."""

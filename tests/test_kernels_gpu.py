@@ -676,6 +676,30 @@ def test_bn_eval_mode(C):
     assert np.array_equal(rm.cpu().numpy(), rm0) and np.array_equal(rv.cpu().numpy(), rv0)   # eval updates nothing
 
 
+def test_ce_counts_out_of_range_labels_and_confusion_guards_small_matrix(C):
+    """Labels that are neither ignore_index nor a class: torch's CrossEntropyLoss asserts; here they are excluded from the
+    mean AND counted on the criterion (a label bug in a class split cannot hide).  argmax_confusion with a matrix smaller
+    than the class count drops predictions outside it instead of writing past the histogram."""
+    rng = np.random.default_rng(3)
+    logits = torch.from_numpy(rnd(rng, 2, 5, 8, 8)).cuda()
+    labels = torch.from_numpy(rng.integers(0, 5, (2, 8, 8))).cuda()
+    crit = C.CrossEntropyLoss()
+    crit(logits, labels)
+    assert int(crit.bad_labels) == 0
+    bad = labels.clone(); bad[0, 0, :3] = 7; bad[1, 2, 2] = -100          # three out-of-range labels, one ignored pixel
+    loss = crit(logits, bad)
+    assert int(crit.bad_labels) == 3
+    keep = (bad >= 0) & (bad < 5)
+    ref = torch.nn.functional.cross_entropy(logits.permute(0, 2, 3, 1)[keep], bad[keep])
+    assert abs(float(loss) - float(ref)) < 1e-5
+    conf, _ = C.metrics.argmax_confusion(logits, labels.clamp(max=2), 3)       # 3x3 matrix, 5 classes predicted
+    pred = logits.argmax(1)
+    m = (pred < 3)
+    want = np.zeros((3, 3), np.int64)
+    np.add.at(want, (labels.clamp(max=2)[m].cpu().numpy(), pred[m].cpu().numpy()), 1)
+    assert np.array_equal(conf.cpu().numpy(), want)
+
+
 def test_integration_md_snippet_runs(C):
     """The binding example of INTEGRATION.md, executed as written (its Conv2d -> ReLU -> BatchNorm2d unit, models/unet.py:13-15)
     and compared with the oracle: a stale example would put an int into a pointer slot."""
@@ -813,3 +837,16 @@ def test_voc_data_path_vs_oracle(C):
     bad = mask.copy(); bad[hs // 2, ws // 2] = (1, 2, 3)          # a pixel inside the centre crop
     with pytest.raises(ValueError):
         C.data.prepare_sample(torch.from_numpy(img).cuda(), torch.from_numpy(bad).cuda(), (h, w))
+
+
+def test_voc_palette_kernels_vs_reference_fixture(C, golden):
+    """The palette kernels against vectors captured from the reference's own voc.to_mask / voc.to_rgb (tests/golden/voc.npz):
+    Pad(10) + CenterCrop to the image's own size is the identity, so prepare_sample's labels must equal to_mask's."""
+    g = golden('voc.npz')
+    mask = torch.from_numpy(g['mask_rgb']).cuda()
+    hs, ws = mask.shape[:2]
+    _, labels = C.data.prepare_sample(None, mask, (hs, ws))
+    sync()
+    assert np.array_equal(labels.cpu().numpy(), g['labels'])
+    rgb = C.data.to_rgb(torch.from_numpy(g['to_rgb_in']).cuda())
+    assert np.array_equal(rgb.cpu().numpy().astype(np.float64), g['to_rgb_out'])

@@ -141,3 +141,16 @@ def test_torch_counterpart(golden, name, nc, cd, size):
             np.testing.assert_allclose(gn, g['grad_norms'], rtol=1e-3, atol=1e-7)
     np.testing.assert_allclose(losses, g['losses'], rtol=1e-5)
     assert [n for n, _ in m.named_parameters()] == list(g['grad_names'])
+
+
+def test_voc_palette_functions_vs_reference(golden):
+    """datasets/voc.py:56-89 to_mask / to_rgb, captured by importing the reference (oracle/gen_golden.py capture_voc):
+    the palette table, void -> 0, and the label -> colour map of the oracle restatement."""
+    g = golden('voc.npz')
+    assert np.array_equal(np.array(O.VOC_PALETTE, np.uint8), g['palette'])
+    assert np.array_equal(O.to_mask(g['mask_rgb']), g['labels'])
+    assert (g['labels'][:3, :5] == 0).all()                      # the void block
+    assert np.array_equal(O.to_rgb(g['to_rgb_in']).astype(np.float64), g['to_rgb_out'])
+    bad = g['mask_rgb'].copy(); bad[5, 5] = (1, 2, 3)
+    with pytest.raises(ValueError):
+        O.to_mask(bad)
