@@ -55,9 +55,10 @@ def run(args, dtype, rank, world, device, timing=True):
     model = C.UNet(args.num_classes, 3, args.conv_dim, compute_dtype=dtype).to(device).train()
     opt = C.FusedAdam(model.parameters(), lr=1e-4, betas=[0.5, 0.99])
     crit = C.CrossEntropyLoss()
+    sync = None
     if world > 1:
         C.ddp.broadcast_parameters(model)
-        C.ddp.GradSync(model, opt)
+        sync = C.ddp.GradSync(model, opt, timing=True)
     x = torch.from_numpy(C.synth.images(1234, args.batch, 3, args.size, args.size, first_image=rank * args.batch)).to(device)
     y = torch.from_numpy(C.synth.labels(1234, args.batch, args.size, args.size, args.num_classes,
                                         first_image=rank * args.batch)).to(device)
@@ -73,6 +74,9 @@ def run(args, dtype, rank, world, device, timing=True):
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
+    if sync is not None:
+        sync.exposed_ms()               # drop the warm-up's wait events
+        sync.launches = 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -84,10 +88,16 @@ def run(args, dtype, rank, world, device, timing=True):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    comm = None
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        exposed = sync.exposed_ms() / args.steps
+        t = torch.tensor([dt, exposed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        dt = float(t[0])
+        comm = dict(C.ddp.rccl_settings(), rccl_ranks=world, collectives_per_step=sync.launches // args.steps,
+                    gradient_bytes_per_step=4 * sum(p.numel() for p in model.parameters()),
+                    exposed_comm_ms_per_step=round(float(t[1]), 4), cu_reserve=model.tuning.cu_reserve,
+                    note='exposed = HIP-event time the compute stream waits in GradSync.wait() before Adam, max over ranks')
     # Per-launch HIP-event timing of the MFMA kernels: a SEPARATE pass of 2 steps right after the timed region
     # (an event pair around each of ~54 launches per step costs ~5 ms of dispatch bubbles per fp32 step, which would
     # distort `value`); events are recorded on the stream the kernels are launched on.
@@ -105,7 +115,7 @@ def run(args, dtype, rank, world, device, timing=True):
         k[1] += flops
         k[2] += 1
         k[3] += nbytes
-    return dt, float(loss.detach()), kern
+    return dt, float(loss.detach()), kern, comm
 
 
 def pmc_traffic(dtype, size, batch, conv_dim):
@@ -151,11 +161,12 @@ def main():
     device = torch.device('cuda', local)
     if world > 1:
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)   # "nccl" IS RCCL on ROCm
+            import continual_learning_amd as C
+            C.ddp.init_rccl(device)                             # "nccl" IS RCCL on ROCm; caps the channel count
         else:
             dist.init_process_group(backend)
 
-    dt, loss, kern = run(args, args.dtype, rank, world, device, timing=not args.no_kernel_timing)
+    dt, loss, kern, comm = run(args, args.dtype, rank, world, device, timing=not args.no_kernel_timing)
     images = args.batch * world * args.steps
     value = images / dt
     scale = (args.size / 256.0) ** 2 * (args.conv_dim / 64.0) ** 2
@@ -181,6 +192,8 @@ def main():
     out['step_executed_tflops'] = round(value * exec_img / 1e12, 2)
     out['step_frac_of_mfma_peak'] = round(value * exec_img / 1e12 / (PEAK[args.dtype] * world), 4)
     out['algorithmic_speedup'] = round(flop_img / exec_img, 4)
+    if comm is not None:
+        out['comm'] = comm
     if kern:
         # dominant kernel = the 3x3 implicit-GEMM (forward + data-gradient launches share one kernel template)
         sec, flops, n, nbytes = kern.get('igemm_conv3x3', (0, 0, 0, 0))
@@ -220,7 +233,7 @@ def main():
     # further dtypes: by default on the single-GPU run only (the N-GPU scaling runs measure the headline dtype and nothing else)
     also = args.also if args.also is not None else ('bf16x3,bf16' if world == 1 else '')
     for other in [d for d in also.split(',') if d and d != args.dtype]:
-        dt2, loss2, k2 = run(args, other, rank, world, device, timing=not args.no_kernel_timing)
+        dt2, loss2, k2, _ = run(args, other, rank, world, device, timing=not args.no_kernel_timing)
         v2 = images / dt2
         o = {'dtype': DTYPE_NAME[other], 'value': round(v2, 2), 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
              'step_frac_of_mfma_peak': round(v2 * flop_img / 1e12 / (PEAK[other] * world), 4),

@@ -469,7 +469,8 @@ static Conv3Plan plan_conv3x3(const IgemmParams& p, int dtype, const clamd_tunin
         const long long ntn = (p.Np + 63) / 64;
         const long long blocks4 = (long long)p.B * ((p.H + 15) / 16) * ((p.W + 31) / 32) * ntn;
         const long long blocks2 = (long long)p.B * (p.W >= 32 ? ((p.H + 7) / 8) * ((p.W + 31) / 32) : ((p.H + 15) / 16) * ((p.W + 15) / 16)) * ntn;
-        mt = (p.W >= 32 && blocks4 >= 224) ? 4 : blocks2 >= 224 ? 2 : 1;
+        const long long fill = 7LL * clamd_usable_cus(tn) / 8;           // 224 of 256 CUs; fewer when CUs are left to RCCL
+        mt = (p.W >= 32 && blocks4 >= fill) ? 4 : blocks2 >= fill ? 2 : 1;
     }
     if (mt) return {1, mt, ws_rows(p, mt)};
     const long long t = igemm_tiles(p);

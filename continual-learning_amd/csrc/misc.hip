@@ -391,6 +391,18 @@ __global__ void scale_by_dev_kernel(float* p, long long n, const float* __restri
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] *= v;
 }
 
+// Rehearsal aid (tools/cu_steal.py, tests): `gridDim.x` workgroups that each keep one CU to themselves for `ticks`
+// 100-MHz ticks -- 96 KB of LDS per workgroup means at most one per CU and no room beside it for the 120-160-KB MFMA
+// workgroups of this library -- the way an RCCL channel workgroup holds a CU during a collective.  Every wave exits at the
+// deadline; nothing is read or written.
+__global__ void __launch_bounds__(256) hold_cus_kernel(unsigned long long ticks, unsigned int* sink) {
+    __shared__ unsigned int pad[96 * 1024 / 4];
+    if (threadIdx.x == 0) pad[0] = 1u;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (ticks == ~0ull && sink) sink[0] = pad[threadIdx.x];       // never true: keeps the LDS allocation alive
+}
+
 __global__ void fill_kernel(float* p, long long n, float v) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -493,6 +505,12 @@ int clamd_scale_by_device_scalar(float* p, long long n, const float* scale_dev, 
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(scale_by_dev_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p, n, scale_dev);
     return clamd_check_launch("scale_by_device_scalar");
+}
+
+int clamd_debug_hold_cus(int ncus, int usec, void* stream) {
+    if (ncus < 1 || ncus > 256 || usec < 1 || usec > 2000000) return clamd_fail("debug_hold_cus: 1..256 CUs for 1..2000000 us");
+    hipLaunchKernelGGL(hold_cus_kernel, dim3(ncus), dim3(256), 0, (hipStream_t)stream, (unsigned long long)usec * 100ull, (unsigned int*)nullptr);
+    return clamd_check_launch("debug_hold_cus");
 }
 
 int clamd_fill_f32(float* p, long long n, double v, void* stream) {

@@ -557,7 +557,9 @@ int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, fl
     const int rt = (Rp + 63) / 64, ct = (Cp + 63) / 64;
     // the producer/consumer kernel runs one workgroup per CU: half the slabs of the 2-per-CU kernel
     const bool ws = tn.wgrad_ws && mode == WG_CONV3;
-    int nsplit = (ws ? tn.wgrad_blocks / 2 : tn.wgrad_blocks) / (rt * ct);
+    // split-K target: wgrad_blocks workgroups on a whole chip (512 = two per CU), scaled down with the CUs left to RCCL
+    const int target = (int)((long long)tn.wgrad_blocks * clamd_usable_cus(tn) / clamd_num_cus());
+    int nsplit = (ws ? target / 2 : target) / (rt * ct);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > ntiles) nsplit = ntiles;
     int per = (ntiles + nsplit - 1) / nsplit;

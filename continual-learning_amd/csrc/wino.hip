@@ -787,7 +787,7 @@ int clamd_debug_ww_diag(unsigned long long* out4, int reset) {
 #endif
 
 size_t clamd_wgrad_winograd_workspace_bytes(int Rp, int Cp) {
-    int nsplit = 256 / (((Rp + 63) / 64) * ((Cp + 63) / 64));
+    int nsplit = clamd_num_cus() / (((Rp + 63) / 64) * ((Cp + 63) / 64));
     if (nsplit < 1) nsplit = 1;
     return (size_t)nsplit * 16 * Rp * Cp * sizeof(float);
 }
@@ -803,7 +803,7 @@ int clamd_wgrad_winograd(const float* gz, int gz_ldc, const float* x, int x_ldc,
     if ((long long)H * W * gz_ldc * 4 >= (1ll << 30) || (long long)H * W * x_ldc * 4 >= (1ll << 30)) return clamd_fail("wgrad_winograd: one image exceeds 2^30 bytes");
     const int rt = (Rp + 63) / 64, ct = (Cp + 63) / 64;
     const int ntiles = ((W + 2 * WW_TX - 1) / (2 * WW_TX)) * ((H + 2 * WW_TY - 1) / (2 * WW_TY)) * B;
-    int nsplit = 256 / (rt * ct);
+    int nsplit = clamd_usable_cus(clamd_tune(tune)) / (rt * ct);          // one workgroup per CU the grid may occupy
     if (nsplit < 1) nsplit = 1;
     if (nsplit > ntiles) nsplit = ntiles;
     const int per = (ntiles + nsplit - 1) / nsplit;

@@ -8,12 +8,35 @@ overlapped with the rest of the backward pass.  The 1/world factor is folded int
 xGMI is point-to-point (7 links per GPU): a few large buckets keep RCCL's per-call latency off the critical path; the
 big dec1/dec2 buckets (77 % of the bytes) finish early and hide behind the whole encoder backward.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
+# RCCL runs one workgroup per channel and a channel workgroup keeps its CU for the whole collective.  The MFMA kernels of
+# this library want a whole CU per workgroup, so the channel count is capped and exactly that many CUs are left out of
+# every grid that is sized to the chip (clamd_tuning::cu_reserve): a collective in flight then costs cu_reserve/256 of the
+# convolution throughput instead of a second round of workgroups.  8 channels move the 124 MB of fp32 gradients of a step
+# in a few ms over xGMI -- far inside the >= 16 ms (fp32) / 4.5 ms (bf16) backward pass they are overlapped with.
+RCCL_MAX_CHANNELS = 8
+
+
+def init_rccl(device, max_channels=RCCL_MAX_CHANNELS, **kw):
+    """``init_process_group('nccl')`` (= RCCL on ROCm) with the channel cap in place.  NCCL_MAX_NCHANNELS /
+    NCCL_MIN_NCHANNELS already present in the environment win.  Returns the settings (bench.py records them)."""
+    os.environ.setdefault('NCCL_MAX_NCHANNELS', str(max_channels))
+    os.environ.setdefault('NCCL_MIN_NCHANNELS', str(min(4, max_channels)))
+    dist.init_process_group('nccl', device_id=device, **kw)
+    return rccl_settings()
+
+
+def rccl_settings():
+    return {'backend': dist.get_backend() if dist.is_initialized() else None,
+            'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS'), 'NCCL_MIN_NCHANNELS': os.environ.get('NCCL_MIN_NCHANNELS')}
+
 
 class GradSync:
-    def __init__(self, model, optimizer=None, process_group=None, min_bucket_bytes=4 << 20):
+    def __init__(self, model, optimizer=None, process_group=None, min_bucket_bytes=4 << 20, cu_reserve=None, timing=False):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         self.group = process_group
@@ -22,6 +45,9 @@ class GradSync:
         self._pending = []
         self._lo = None
         self._stream = None
+        self.timing = timing              # bench.py: HIP-event time the main stream spends waiting for the collectives
+        self._waits = []
+        self.launches = 0
         model.grad_sync = self
         # RCCL's channel workgroups hold CUs for the duration of a collective, and our MFMA kernels need a whole CU per
         # workgroup: a statically strided persistent grid sized to the CU count would then run two full rounds, while the
@@ -29,6 +55,11 @@ class GradSync:
         # This is a field of THIS model's tuning (passed per call): nothing process-wide is touched, results are unchanged
         # (the statistics rows of the Winograd kernel are per tile either way).
         model.tuning.wino_persist = 0
+        # grids sized to the chip (persistent conv kernel, split-K weight gradients) leave the CUs of the RCCL channels free
+        if cu_reserve is None:
+            nccl = dist.get_backend(process_group) == 'nccl' and self.world > 1
+            cu_reserve = int(os.environ.get('NCCL_MAX_NCHANNELS', '0') or 0) if nccl else 0
+        model.tuning.cu_reserve = max(0, min(128, int(cu_reserve)))
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
             optimizer.pre_step_hooks.append(self.wait)
@@ -54,6 +85,7 @@ class GradSync:
             self._lo = None
 
     def _launch(self, flat):
+        self.launches += 1
         if flat.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream()
@@ -69,8 +101,23 @@ class GradSync:
             if h is not None:
                 h.wait()
         if self._stream is not None:
-            torch.cuda.current_stream().wait_stream(self._stream)
+            if self.timing and self._pending:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                torch.cuda.current_stream().wait_stream(self._stream)
+                e1.record()
+                self._waits.append((e0, e1))
+            else:
+                torch.cuda.current_stream().wait_stream(self._stream)
         self._pending = []
+
+    def exposed_ms(self):
+        """Total time (ms) the compute stream stalled in wait() since the last call: gradient exchange that was NOT hidden
+        behind the backward pass.  Synchronises."""
+        torch.cuda.synchronize()
+        t = sum(a.elapsed_time(b) for a, b in self._waits)
+        self._waits = []
+        return t
 
 
 def broadcast_parameters(model, src=0, group=None):

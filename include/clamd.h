@@ -201,6 +201,10 @@ int clamd_voc_prepare(const unsigned char* img_rgb, const unsigned char* mask_rg
 /* voc.to_rgb (datasets/voc.py:74-89): labels int64 [N,H,W] -> palette colours [N,3,H,W] (0..255 as float). */
 int clamd_label_to_rgb(const long long* labels, float* rgb, long long n_img, long long hw, void* stream);
 int clamd_fill_f32(float* p, long long n, double v, void* stream);
+/* Rehearsal aid for data parallelism on a one-GPU box: `ncus` workgroups that each hold a whole CU for `usec` microseconds
+ * and do nothing else -- what an RCCL channel workgroup does to the one-workgroup-per-CU MFMA kernels during a collective
+ * (tools/cu_steal.py measures the step with and without clamd_tuning::cu_reserve).  Not used by the product path. */
+int clamd_debug_hold_cus(int ncus, int usec, void* stream);
 /* p[i] *= *scale_dev for a DEVICE scalar, nothing at all when it is exactly 1 (the upstream gradient loss.backward()
  * hands to the loss function, trainer.py:175): no host sync, no pass over d logits in the common case. */
 int clamd_scale_by_device_scalar(float* p, long long n, const float* scale_dev, void* stream);

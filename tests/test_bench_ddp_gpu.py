@@ -32,3 +32,23 @@ def test_bench_two_ranks_on_one_gpu():
     assert d['value'] == pytest.approx(8 * 3 / (d['ms_per_step'] * 3 / 1e3), rel=1e-3)      # all ranks' images / max-over-ranks time
     assert 'cpu_baseline' not in d and 'also' not in d                                       # N > 1: headline only
     assert d['config']['final_loss'] == d['config']['final_loss']                            # finite
+    c = d['comm']
+    assert c['rccl_ranks'] == 2 and c['backend'] == 'gloo' and c['collectives_per_step'] >= 1
+    assert c['gradient_bytes_per_step'] == 4 * 31_044_821 and c['exposed_comm_ms_per_step'] >= 0.0
+    assert c['cu_reserve'] == 0                                                               # gloo holds no CUs
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_step_survives_stolen_cus(dtype):
+    """SURVEY.md §8e ('cap RCCL channels/CUs'), rehearsed on one GPU: a dummy kernel holds 8 CUs for the whole measurement,
+    as 8 RCCL channel workgroups would during a collective.  With clamd_tuning::cu_reserve = 8 (what ddp.GradSync sets from
+    NCCL_MAX_NCHANNELS) the grids sized to the chip fit beside the held CUs: measured 1.11x (bf16) / 1.22x (fp32) of the
+    undisturbed step with the CUs held for the WHOLE step, against 1.37x / 1.72x without the reserve.  (The remainder is
+    quantisation: the deep layers have 256-512 equal work items, which take an extra round on 248 CUs whatever the
+    schedule.  Real collectives are in flight for 10-30 % of a step)"""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import cu_steal
+    r = cu_steal.measure(dtype, held=8, steps=5)
+    print(r)
+    assert r['reserved_over_base'] < (1.2 if dtype == 'bf16' else 1.35), r
+    assert r['reserved'] < 0.92 * r['stolen'], r      # the reserve removes most of the second rounds
