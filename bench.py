@@ -23,9 +23,6 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FLOP_PER_IMAGE_256 = 289_281_146_880          # train step, SURVEY.md §8d / BASELINE.md
-CONV3_FLOP_PER_IMAGE_256 = 275_867_762_688    # of which 3x3 convolutions (fwd + dgrad + wgrad)
-ENC10_FLOP_PER_IMAGE_256 = 2 * 226_492_416    # ... of which enc1.0 (fwd + wgrad; im2col GEMM, never Winograd)
-WINO_EXECUTED = 16.0 / 36.0                   # Winograd F(2x2,3x3): multiply-adds executed per algorithmic multiply-add
 PEAK = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0 / 3}   # dense MFMA TFLOP/s (MI355X_MICROARCH.md:42-43); bf16x3
 #                                                              # issues 3 bf16 MFMAs per algorithmic multiply-add
 DTYPE_NAME = {'fp32': 'f32', 'bf16': 'bf16', 'bf16x3': 'bf16x3 (f32 storage, hi/lo-split bf16 MFMA, f32 accumulate)'}
@@ -109,12 +106,16 @@ def run(args, dtype, rank, world, device, timing=True):
         torch.cuda.synchronize()
         U.KERNEL_TIMING = None
     kern = {}
-    for tag, flops, e0, e1, nbytes in events:
-        k = kern.setdefault(tag, [0.0, 0.0, 0, 0.0])
+    for tag, flops, e0, e1, nbytes, _unit, frac in events:
+        k = kern.setdefault(tag, [0.0, 0.0, 0, 0.0, 0.0])
+        k[4] += flops * frac
         k[0] += e0.elapsed_time(e1) * 1e-3
         k[1] += flops
         k[2] += 1
         k[3] += nbytes
+    eng = next(iter(model._engines.values()))
+    kern['_deficit_per_image'] = eng.executed_flop_deficit() / args.batch
+    kern['_forms'] = sorted({('F(2x4,3x3)' if u.w24 else 'F(2x2,3x3)') for u in eng.convs if u.wino})
     return dt, float(loss.detach()), kern, comm
 
 
@@ -134,7 +135,7 @@ def pmc_traffic(dtype, size, batch, conv_dim):
     if d is None:
         return None
     tot, n = 0.0, 0
-    names = ('wino_kernel<',) if dtype == 'fp32' else ('igemm_ws_kernel<', 'igemm_pws_kernel<')
+    names = ('wino_kernel<', 'wino24_kernel<') if dtype == 'fp32' else ('igemm_ws_kernel<', 'igemm_pws_kernel<')
     for k, v in d['kernels'].items():
         if (dtype != 'fp32' and k.startswith('igemm_kernel<') and k.replace(' ', '').split(',')[1:3] == ['0', '0']) or k.startswith(names):
             tot += (v['hbm_read_bytes_per_launch'] + v['hbm_write_bytes_per_launch']) * v['launches']
@@ -185,9 +186,10 @@ def main():
     }
     # whole step against the MFMA peak: EXECUTED multiply-adds (the fp32 path runs every 3x3 convolution but enc1.0 as
     # Winograd F(2x2,3x3): 16/36 of the algorithmic FLOPs); the algorithmic rate and the reduction are separate fields
-    from continual_learning_amd import unet as U_
-    wino = args.dtype == 'fp32' and bool(U_.WINOGRAD)
-    exec_img = flop_img - (1.0 - WINO_EXECUTED) * (CONV3_FLOP_PER_IMAGE_256 - ENC10_FLOP_PER_IMAGE_256) * scale if wino else flop_img
+    deficit = kern.pop('_deficit_per_image', 0.0)
+    forms = kern.pop('_forms', [])
+    wino = deficit > 0
+    exec_img = flop_img - deficit
     out['step_algorithmic_tflops'] = round(value * flop_img / 1e12, 2)
     out['step_executed_tflops'] = round(value * exec_img / 1e12, 2)
     out['step_frac_of_mfma_peak'] = round(value * exec_img / 1e12 / (PEAK[args.dtype] * world), 4)
@@ -196,16 +198,16 @@ def main():
         out['comm'] = comm
     if kern:
         # dominant kernel = the 3x3 implicit-GEMM (forward + data-gradient launches share one kernel template)
-        sec, flops, n, nbytes = kern.get('igemm_conv3x3', (0, 0, 0, 0))
+        sec, flops, n, nbytes, xflops = kern.get('igemm_conv3x3', (0, 0, 0, 0, 0))
         if sec > 0:
             alg = flops / sec / 1e12
-            ach = alg * (WINO_EXECUTED if wino else 1.0)       # FLOP/s the MFMA pipe executes
+            ach = xflops / sec / 1e12                          # FLOP/s the MFMA pipe executes
             tr = pmc_traffic(args.dtype, args.size, args.batch, args.conv_dim)
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK[args.dtype], 'unit': 'TFLOP/s',
                                'frac': round(ach / PEAK[args.dtype], 4), 'traffic': tr[0] if tr else None,
                                'traffic_source': ('profiles/' + tr[1]) if tr else None,
-                               'kernel': ('conv3x3 fwd + dgrad launches: clamd::wino_kernel (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)'
-                                          if args.dtype == 'fp32' else
+                               'kernel': (f'conv3x3 fwd + dgrad launches: clamd::wino24_kernel / clamd::wino_kernel (Winograd {" / ".join(forms)} '
+                                          'on v_mfma_f32_32x32x2_f32)' if wino else
                                           'conv3x3 implicit GEMM, fwd + dgrad launches: clamd::igemm_pws_kernel<T,TW> (persistent, <= 256 input '
                                           'channels) and clamd::igemm_ws_kernel<T,TW,MT> (> 256 input channels)'),
                                'launches': n, 'avg_launch_ms': round(sec / n * 1e3, 4),
@@ -216,20 +218,21 @@ def main():
                 # `achieved` / `frac` = EXECUTED multiply-adds (MFMA pipe utilisation); the algorithmic (direct-convolution)
                 # rate is reported beside it
                 out['roofline']['algorithmic_tflops'] = round(alg, 2)
-                out['roofline']['algorithmic_speedup'] = round(1.0 / WINO_EXECUTED, 4)
-                out['roofline']['note'] = ('Winograd F(2x2,3x3): 16 MFMA multiply-adds per 2x2 output tile and channel pair instead of 36; '
-                                           'achieved/frac count the executed 16, algorithmic_tflops the 36')
-        sec, flops, n, _ = kern.get('wgrad_conv3x3', (0, 0, 0, 0))
+                out['roofline']['algorithmic_speedup'] = round(flops / xflops, 4)
+                out['roofline']['note'] = ('Winograd: F(2x4,3x3) executes 24 MFMA multiply-adds per 2x4 output tile and channel pair instead of '
+                                           '72 (F(2x2,3x3): 16 instead of 36); achieved/frac count the EXECUTED multiply-adds, '
+                                           'algorithmic_tflops the direct-convolution ones')
+        sec, flops, n, _, xflops = kern.get('wgrad_conv3x3', (0, 0, 0, 0, 0))
         if sec > 0:
             alg = flops / sec / 1e12
-            ach = alg * (WINO_EXECUTED if wino else 1.0)
+            ach = xflops / sec / 1e12
             out['roofline_wgrad'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK[args.dtype],
                                      'unit': 'TFLOP/s', 'frac': round(ach / PEAK[args.dtype], 4), 'launches': n,
                                      'avg_launch_ms': round(sec / n * 1e3, 4), 'ms_per_step': round(sec / 2 * 1e3, 3),
                                      'note': 'wgrad kernel + its split-K reduce kernel'}
             if wino:
                 out['roofline_wgrad']['algorithmic_tflops'] = round(alg, 2)
-                out['roofline_wgrad']['algorithmic_speedup'] = round(1.0 / WINO_EXECUTED, 4)
+                out['roofline_wgrad']['algorithmic_speedup'] = round(flops / xflops, 4)
     # further dtypes: by default on the single-GPU run only (the N-GPU scaling runs measure the headline dtype and nothing else)
     also = args.also if args.also is not None else ('bf16x3,bf16' if world == 1 else '')
     for other in [d for d in also.split(',') if d and d != args.dtype]:
@@ -238,11 +241,12 @@ def main():
         o = {'dtype': DTYPE_NAME[other], 'value': round(v2, 2), 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
              'step_frac_of_mfma_peak': round(v2 * flop_img / 1e12 / (PEAK[other] * world), 4),
              'final_loss': round(loss2, 5)}
-        sec, flops, n, _ = k2.get('igemm_conv3x3', (0, 0, 0, 0))
+        k2.pop('_deficit_per_image', None); k2.pop('_forms', None)
+        sec, flops, n, _, _x = k2.get('igemm_conv3x3', (0, 0, 0, 0, 0))
         if sec > 0:
             o['conv3x3_igemm_tflops'] = round(flops / sec / 1e12, 1)
             o['conv3x3_igemm_frac_of_peak'] = round(flops / sec / 1e12 / PEAK[other], 4)
-        sec, flops, n, _ = k2.get('wgrad_conv3x3', (0, 0, 0, 0))
+        sec, flops, n, _, _x = k2.get('wgrad_conv3x3', (0, 0, 0, 0, 0))
         if sec > 0:
             o['conv3x3_wgrad_tflops'] = round(flops / sec / 1e12, 1)
         out.setdefault('also', []).append(o)

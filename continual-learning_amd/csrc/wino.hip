@@ -23,6 +23,7 @@
 #include <algorithm>
 #include "common.hip.h"
 #include "clamd_internal.h"
+#include "wino_common.hip.h"
 
 // K-loop issue pattern (sched_mfma_slots): RPS LDS reads per slot in slots [0, R1), NV VALU ops per slot from slot V0.
 // Measured alternatives (build with -DWN_RPS=.. etc.): reads two per slot and VALU from slot 12 (no s_waitcnt lgkmcnt(0)
@@ -34,17 +35,6 @@
 #define WN_NV 2
 #endif
 namespace clamd {
-
-struct WinoParams {
-    const float* x; int x_ldc;
-    const float* w;              // [Kp/8][16][Np][8]
-    const float* bias;
-    float* y; int y_ldc;
-    float* stats;                // partial rows [pixel tile][2][Np] (plain stores) or null
-    int B, H, W, Kp, Np, relu;
-    int band;                    // output-channel slabs per band of the block order (see clamd_conv3x3_winograd)
-    int nblk;                    // (pixel tile, slab) pairs; the grid is min(nblk, CUs) persistent workgroups
-};
 
 constexpr int WN_HW = 18;                                     // input halo width of a 16-pixel-wide output tile
 constexpr int WN_WG = 66;                                     // padded rows per (xi, group)
@@ -340,20 +330,6 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
 // One job = one GEMM operand: dst[(k/8)*16 + xi][n][k%8] = (G g G^T)[xi] with g = w[n_l][k_l] (forward) or the tap-flipped
 // w[k_l][n_l] (data gradient); physical -> logical channel maps as in clamd_pack (two segments for concat inputs, zero
 // padding).  One thread per (n, k): consecutive threads write consecutive floats of every xi row.
-struct WinoPackJob {
-    const float* w; float* dst;
-    int Np, Kp, N, K;                 // physical / logical sizes of the GEMM's N (rows) and K
-    int n_seg0, n_seg0p, k_seg0, k_seg0p;
-    int dgrad;                        // 0: g = w[n][k], src [N][K][3][3]; 1: g = flip(w[k][n]), src [K][N][3][3]
-    int block0;                       // first workgroup of this job
-};
-
-__device__ inline int wn_phys2log(int p, int seg0, int seg0p, int L) {
-    if (p < seg0p) return p < seg0 ? p : -1;
-    const int l = seg0 + (p - seg0p);
-    return l < L ? l : -1;
-}
-
 __global__ void __launch_bounds__(256) wino_pack_kernel(const WinoPackJob* __restrict__ jobs, int njobs) {
     int ji = 0;
     while (ji + 1 < njobs && (int)blockIdx.x >= jobs[ji + 1].block0) ++ji;     // few jobs: linear search
@@ -394,12 +370,12 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const WinoPackJob* __res
 
 }  // namespace clamd
 
-using namespace clamd;
+namespace clamd {
 
 // HBM traffic model of one launch: an XCD holds 32 workgroups at a time = a pixel tiles x b slabs (a * b = 32); every
 // such group fetches its a input tiles and b filter slabs once, so bytes ~ X * (slabs / b) + F * (tiles / a).  Measured
 // with b = all slabs (slab-fastest order): 553 MB for 1024 -> 1024 @ 16^2, where activations + filters are 88 MB.
-static int wino_band(long long tiles, long long slabs, double x_elems, double f_elems, int forced) {
+int wino_band(long long tiles, long long slabs, double x_elems, double f_elems, int forced) {
     int best = 1;
     double best_cost = 0;
     for (int b = 1; b <= 32 && b <= slabs; b *= 2) {
@@ -411,6 +387,10 @@ static int wino_band(long long tiles, long long slabs, double x_elems, double f_
     if (forced > 0) { best = 1; while (best * 2 <= forced && slabs % (best * 2) == 0) best *= 2; }   // "wino_band": rounded down to a divisor
     return best;
 }
+
+}  // namespace clamd
+
+using namespace clamd;
 
 // 16x16-pixel tiles unless that grid would leave a quarter of the CUs without a workgroup
 static bool wino_mt2(int B, int H, int W, int Cout_p, const clamd_tuning& tn) {

@@ -98,13 +98,16 @@ _WINO_DT = np.dtype({'names': ['w', 'dst', 'Np', 'Kp', 'N', 'K', 'n_seg0', 'n_se
 
 
 class WinoPackTable:
-    """Job table for clamd_wino_pack: Winograd F(2x2,3x3) filter transforms of every 3x3 conv in one launch (fp32 path)."""
+    """Job table for clamd_wino_pack / clamd_wino24_pack: Winograd filter transforms of every 3x3 conv of one form in one
+    launch (fp32 path).  ``planes`` = 16: F(2x2,3x3) (wino.hip); 24: F(2x4,3x3) (wino24.hip)."""
 
-    def __init__(self):
+    def __init__(self, planes=16):
+        assert planes in (16, 24)
         self.jobs = []
+        self.planes = planes
 
     def conv3x3(self, w, wf, wd, cin_segs, cout):
-        """w [Cout][Cin][3][3] fp32 -> wf [Cin_p/8][16][Cout_p][8] (forward) and wd [Cout_p/8][16][Cin_p][8] (data
+        """w [Cout][Cin][3][3] fp32 -> wf [Cin_p/8][planes][Cout_p][8] (forward) and wd [Cout_p/8][planes][Cin_p][8] (data
         gradient: tap-flipped, transposed).  cin_segs as in PackTable.conv3x3."""
         cin = sum(s[0] for s in cin_segs)
         cin_p = sum(s[1] for s in cin_segs)
@@ -128,7 +131,8 @@ class WinoPackTable:
         return self
 
     def run(self, stream=None):
-        call('clamd_wino_pack', ptr(self.dev_table), len(self.jobs), self.nblocks, stream or _lib.stream_ptr())
+        call('clamd_wino_pack' if self.planes == 16 else 'clamd_wino24_pack', ptr(self.dev_table), len(self.jobs), self.nblocks,
+             stream or _lib.stream_ptr())
 
 
 # ---- single-kernel wrappers (tests, small tools) ----------------------------------------------------------------

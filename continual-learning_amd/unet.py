@@ -26,11 +26,18 @@ FUSE_BN_SUMS = 'auto'
 # fp32 path: forward and data gradient of the 3x3 convolutions by Winograd F(2x2,3x3) (csrc/wino.hip): 2.25x fewer MFMA
 # cycles, fp32 transforms (error vs fp64 3.5e-7 against 2.3e-7 for the direct sum).  False = direct implicit GEMM.
 WINOGRAD = True
+# ... and, where the image width is a multiple of 4, by the hybrid F(2x4,3x3) (csrc/wino24.hip): 3 instead of 4 multiply-adds
+# per output (1.17x faster launches, error vs fp64 1e-6).  False = F(2x2,3x3) everywhere.
+WINOGRAD24 = True
 
 # bench.py sets this to a list to get per-launch HIP-event timings of the MFMA kernels:
 # entries (tag, algorithmic_flops, start_event, end_event, algorithmic_bytes), recorded on the stream the kernel is
 # launched on.  Algorithmic bytes of a 3x3 convolution launch = both activations once + the filters once.
 KERNEL_TIMING = None
+
+
+_TIMED_UNIT = ['', 1.0]   # conv unit being launched and the fraction of its algorithmic FLOPs the kernel executes (Winograd:
+#                         # 16/36 or 24/72); only read while KERNEL_TIMING is set (bench.py, tools/layer_table.py)
 
 
 def _timed(tag, flops, nbytes, name, *args):
@@ -42,7 +49,7 @@ def _timed(tag, flops, nbytes, name, *args):
     e0.record()
     call(name, *args)
     e1.record()
-    kt.append((tag, flops, e0, e1, nbytes))
+    kt.append((tag, flops, e0, e1, nbytes, _TIMED_UNIT[0], _TIMED_UNIT[1]))
 
 
 def stage_table(num_classes, in_dim=3, conv_dim=64):
@@ -223,7 +230,8 @@ class _Engine:
             u.gz = act(level, u.cout_p)
             # Winograd tiles are 2x2 outputs inside 8x16 / 16x16-pixel workgroup tiles: nothing to gain below 8x8 images
             u.wino = self.wino and not u.im2col and (u.h | u.w_) % 2 == 0 and min(u.h, u.w_) >= 8
-            ntap = 1 if u.im2col else (16 if u.wino else 9)     # Winograd: [Cin_p/8][16][Cout_p][8] transformed filters
+            u.w24 = u.wino and bool(WINOGRAD24) and u.w_ % 4 == 0          # forward / data gradient by F(2x4,3x3)
+            ntap = 1 if u.im2col else ((24 if u.w24 else 16) if u.wino else 9)   # Winograd: [Cin_p/8][16|24][Cout_p][8] transformed filters
             u.wf = torch.zeros(ntap * u.cout_p * u.cin_p, dtype=T, device=dev)
             u.wd = None if first_of_net else torch.zeros(ntap * u.cin_p * u.cout_p, dtype=T, device=dev)
             u.bias_p = torch.zeros(u.cout_p, dtype=torch.float32, device=dev)
@@ -338,7 +346,8 @@ class _Engine:
             if u.im2col:
                 u.stat_rows = rows(_lib.OP_CONV1X1, B, u.h, u.w_, u.cin_p, u.cout_p, dc)
             elif u.wino:
-                u.stat_rows = rows(_lib.OP_CONV3X3_WINOGRAD, B, u.h, u.w_, u.cin_p, u.cout_p, dc, tuning=tn)
+                u.stat_rows = rows(_lib.OP_CONV3X3_WINOGRAD24 if u.w24 else _lib.OP_CONV3X3_WINOGRAD, B, u.h, u.w_, u.cin_p, u.cout_p,
+                                   dc, tuning=tn)
             else:
                 u.stat_rows = rows(_lib.OP_CONV3X3, B, u.h, u.w_, u.cin_p, u.cout_p, dc, tuning=tn)
             if u.fused_reduce:
@@ -364,12 +373,12 @@ class _Engine:
     # ------------------------------------------------------------------------------------------ pack table
     def _build_pack_table(self):
         tab = PackTable(self.dcode)
-        wtab = WinoPackTable()
+        wtab, wtab24 = WinoPackTable(16), WinoPackTable(24)
         for u in self.convs:
             if u.im2col:
                 tab.head(u.w, u.wf, None, 9 * u.cin, u.cout)     # [Cout][Cin*9] is already the (c*9 + tap) K order
             elif u.wino:
-                wtab.conv3x3(u.w, u.wf, u.wd, u.cin_segs, u.cout)
+                (wtab24 if u.w24 else wtab).conv3x3(u.w, u.wf, u.wd, u.cin_segs, u.cout)
             else:
                 tab.conv3x3(u.w, u.wf, u.wd, u.cin_segs, u.cout)
             tab.vector(u.b, u.bias_p, u.cout)
@@ -384,6 +393,7 @@ class _Engine:
             tab.vector(t.b, t.bias_p, t.cout)
         self.pack_table = tab.finalize(self.dev)
         self.wino_table = wtab.finalize(self.dev) if wtab.jobs else None
+        self.wino24_table = wtab24.finalize(self.dev) if wtab24.jobs else None
         self._param_ptrs = [p.data_ptr() for p in self.model.parameters()]
 
     def _check_ptrs(self, params):
@@ -412,6 +422,8 @@ class _Engine:
         self.pack_table.run(dc, s)
         if self.wino_table is not None:
             self.wino_table.run(s)
+        if self.wino24_table is not None:
+            self.wino24_table.run(s)
         if self.convs[0].im2col:
             call('clamd_nchw_im2col3', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
                  self.x_in.shape[-1], dc, s)
@@ -436,6 +448,22 @@ class _Engine:
             torch._foreach_add_(self.nbts, 1)
         return logits
 
+    @staticmethod
+    def executed_fraction(u, direction):
+        """Multiply-adds the kernel executes per algorithmic (direct-convolution) multiply-add of unit u."""
+        if not u.wino:
+            return 1.0
+        return 24.0 / 72.0 if (u.w24 and direction != 'wgrad') else 16.0 / 36.0
+
+    def executed_flop_deficit(self):
+        """Algorithmic minus executed FLOPs of one train step (3x3 convolutions by Winograd), for bench.py."""
+        d = 0.0
+        for u in self.convs:
+            f = 2.0 * self.B * u.h * u.w_ * 9 * u.cin * u.cout
+            for direction in ('fwd', 'wgrad') + (('dgrad',) if u.g_in is not None else ()):
+                d += (1.0 - self.executed_fraction(u, direction)) * f
+        return d
+
     def _conv_bytes(self, u):
         """Algorithmic HBM bytes of one 3x3 launch on unit u (forward, data gradient or weight gradient alike): input and
         output activation once each, filters (or their gradient) once."""
@@ -443,13 +471,14 @@ class _Engine:
 
     def _conv_fwd(self, u, training, s):
         B, dc, tp = self.B, self.dcode, tune_ptr(self.tuning)
+        _TIMED_UNIT[:] = [u.name + ' fwd', self.executed_fraction(u, 'fwd')]
         v = u.vec
         if u.im2col:
             call('clamd_conv1x1', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
                  ptr(u.stats) if training else None, None, None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
         elif u.wino:
             _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
-                   'clamd_conv3x3_winograd', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
+                   'clamd_conv3x3_winograd24' if u.w24 else 'clamd_conv3x3_winograd', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
                    ptr(u.stats) if training else None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
         else:
             _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
@@ -546,6 +575,7 @@ class _Engine:
             call('clamd_wgrad', _lib.WGRAD_PW, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
                  g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, 9 * u.cin, u.cout, u.cout_p, 9 * u.cin, u.cin_p, dc, tp, s)
             return
+        _TIMED_UNIT[:] = [u.name + ' wgrad', self.executed_fraction(u, 'wgrad')]
         if u.wino:
             _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
                    'clamd_wgrad_winograd', ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
@@ -554,9 +584,10 @@ class _Engine:
             _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
                    'clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
                    g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, dc, tp, s)
+        _TIMED_UNIT[:] = [u.name + ' dgrad', self.executed_fraction(u, 'dgrad')]
         if u.g_in is not None and u.wino:
             _timed('igemm_conv3x3', flops, self._conv_bytes(u),
-                   'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
+                   'clamd_conv3x3_winograd24' if u.w24 else 'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
                    B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
         elif u.g_in is not None:
             _timed('igemm_conv3x3', flops, self._conv_bytes(u),

@@ -73,7 +73,7 @@ void clamd_tuning_init(clamd_tuning* t);
  * Two runs on the same inputs are bit-identical.  The caller sizes the buffer with clamd_stat_rows() for the SAME
  * arguments it launches with and passes that row count to the launch (checked) and to the finalize call. */
 enum { CLAMD_OP_CONV3X3 = 0, CLAMD_OP_CONV3X3_WINOGRAD = 1, CLAMD_OP_CONV1X1 = 2, CLAMD_OP_CONVT2X2_DGRAD = 3,
-       CLAMD_OP_BN_BWD_REDUCE = 4 };
+       CLAMD_OP_BN_BWD_REDUCE = 4, CLAMD_OP_CONV3X3_WINOGRAD24 = 5 };
 /* rows a launch of `op` writes: (B,H,W) = pixel grid of the launch, Cin_p/Cout_p as passed to it (BN_BWD_REDUCE: Cout_p = Cp,
  * Cin_p != 0 means the pooled variant), fused_bn != 0 when bn_y/bn_sums are passed.  Negative on error. */
 int clamd_stat_rows(int op, int B, int H, int W, int Cin_p, int Cout_p, int dtype, int fused_bn, const clamd_tuning* tune);
@@ -100,6 +100,14 @@ int clamd_wino_pack(const void* jobs_dev, int njobs, int total_blocks, void* str
 int clamd_conv3x3_winograd(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
                            float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
                            const clamd_tuning* tune, void* stream);
+/* The same convolution by the hybrid Winograd F(2x4,3x3) (fp32 only; H even, W a multiple of 4): F(2,3) down the rows, F(4,3)
+ * along the columns -- 3 multiply-adds per output instead of 4 (F(2x2)) or 9 (direct); fp32 error vs fp64 1e-6.
+ * w_wino = [Cin_p/8][24][Cout_p][8] written by clamd_wino24_pack (same job table as clamd_wino_pack).  Arguments and epilogue
+ * as clamd_conv3x3_winograd; stat_rows = clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD24, ...) (wino24.hip). */
+int clamd_wino24_pack(const void* jobs_dev, int njobs, int total_blocks, void* stream);
+int clamd_conv3x3_winograd24(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
+                             float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
+                             const clamd_tuning* tune, void* stream);
 /* Weight gradient of the same convolution by Winograd (fp32, H and W even): out [R][C][3][3] = G^T (sum over tiles of
  * (A dY A^T) x (B^T d B)) G; arguments as clamd_wgrad(CLAMD_WGRAD_CONV3, ...) (gz = d loss / d conv output, x = conv input). */
 size_t clamd_wgrad_winograd_workspace_bytes(int Rp, int Cp);

@@ -150,8 +150,11 @@ def test_engine_geometry_and_pack_table(C):
     # transformed by the Winograd pack table instead
     wino_units = [u for u in e.convs if u.wino]
     assert len(wino_units) == 15 and all(min(u.h, u.w_) >= 8 for u in wino_units)
-    assert len(e.wino_table.jobs) == 2 * len(wino_units)
-    assert len(jobs) + len(e.wino_table.jobs) == 18 * 3 - 1 + 5 * 3
+    w24 = [u for u in wino_units if u.w24]
+    assert len(w24) == 15                                   # every width here (64 ... 8) is a multiple of 4: F(2x4,3x3)
+    nw = len(e.wino24_table.jobs) + (len(e.wino_table.jobs) if e.wino_table is not None else 0)
+    assert nw == 2 * len(wino_units)
+    assert len(jobs) + nw == 18 * 3 - 1 + 5 * 3
     assert e.pack_table.nblocks == sum(((j[3] + 31) // 32) * ((j[4] + 31) // 32) for j in jobs)
     assert C.cpad(3) == 32 and C.cpad(21) == 32 and C.cpad(1024) == 1024
 

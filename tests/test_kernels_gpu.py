@@ -420,6 +420,86 @@ def test_conv3x3_winograd_fp32(C, shape):
     assert rel_l2(gw.cpu().numpy(), rgw) < 2e-5
 
 
+W24_SHAPES = [  # B, Cin segs, Cout, H, W (H even, W % 4 == 0)
+    (1, [(64, 64)], 64, 16, 16),              # 16x16-pixel workgroup tile (images narrower than 32)
+    (1, [(64, 64)], 64, 8, 32),               # exactly one 8x32 tile
+    (2, [(20, 32), (20, 32)], 130, 40, 64),   # concat input, three Cout slabs with a ragged last one
+    (2, [(5, 32)], 7, 8, 12),                 # image smaller than a tile, heavy channel padding
+    (1, [(128, 128)], 96, 34, 20),            # ragged in both directions, narrow tile
+    (3, [(32, 32)], 64, 64, 96),              # 72 workgroups
+    (2, [(256, 256)], 64, 24, 72),            # long K, ragged columns with the wide tile
+]
+
+
+def _random_w24_shapes(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        B = int(rng.integers(1, 4))
+        H, W = 2 * int(rng.integers(2, 30)), 4 * int(rng.integers(1, 24))
+        cout = int(rng.integers(1, 200))
+        if rng.random() < 0.4:
+            c1, c2 = int(rng.integers(1, 80)), int(rng.integers(1, 80))
+            pp = max(32, 1 << (max(c1, c2) - 1).bit_length())
+            segs = [(c1, pp), (c2, pp)]
+        else:
+            c = int(rng.integers(1, 150))
+            segs = [(c, max(32, 1 << (c - 1).bit_length()))]
+        out.append((B, segs, cout, H, W))
+    return out
+
+
+@pytest.mark.parametrize('shape', W24_SHAPES + _random_w24_shapes(int(os.environ.get('WINO_SWEEP', '8')), 77),
+                         ids=lambda sh: f'{sh[0]}x{"+".join(str(a) for a, _ in sh[1])}->{sh[2]}@{sh[3]}x{sh[4]}')
+def test_conv3x3_winograd24_fp32(C, shape):
+    """Hybrid Winograd F(2x4,3x3) (wino24.hip): forward (+bias, ReLU, BN statistics rows) and data gradient, fp32, against
+    the oracle's direct convolution at the SAME 2e-5 bound as the direct and F(2x2) kernels; bit-identical activations and
+    statistics rows under every scheduling choice; bit-reproducible."""
+    B, segs, cout, H, W = shape
+    rng = np.random.default_rng(23)
+    cin = sum(s[0] for s in segs)
+    x = rnd(rng, B, cin, H, W)
+    w = rnd(rng, cout, cin, 3, 3) * (1.0 / np.sqrt(9 * cin))
+    b = rnd(rng, cout)
+    cin_p, cout_p = sum(s[1] for s in segs), C.ops.cpad(cout)
+    xt = nhwc_with_segs(C, x, segs, 0)
+    wt, bt = dev(w), dev(b)
+    wf = torch.zeros(24 * cout_p * cin_p, device='cuda')
+    wd = torch.zeros(24 * cin_p * cout_p, device='cuda')
+    bp = torch.zeros(cout_p, device='cuda')
+    tab = C.ops.WinoPackTable(24); tab.conv3x3(wt, wf, wd, segs, cout); tab.finalize('cuda').run()
+    pt = C.ops.PackTable(0); pt.vector(bt, bp, cout); pt.finalize('cuda').run(0)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    y = torch.full((B, H, W, cout_p), 7.0, device='cuda')
+    stats, rows = stat_buf(C, lib.OP_CONV3X3_WINOGRAD24, B, H, W, cin_p, cout_p, 0)
+    lib.call('clamd_conv3x3_winograd24', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), rows, B, H, W, cin_p, cout_p, 1, None, s)
+    gz = rnd(rng, B, cout, H, W)
+    gzt = C.ops.to_nhwc(dev(gz), 0)
+    gx = torch.full((B, H, W, cin_p), 3.0, device='cuda')
+    lib.call('clamd_conv3x3_winograd24', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, 0, B, H, W, cout_p, cin_p, 0, None, s)
+    sync()
+    ref = O.relu_fwd(O.conv3x3_fwd(x, w, b))
+    assert rel_l2(C.ops.from_nhwc(y, cout, 0).cpu().numpy(), ref) < TOL[0]
+    st = stats.double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(st[1, :cout], (ref ** 2).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    assert float(y[..., cout:].abs().max()) == 0.0 if cout < cout_p else True
+    rgx = O.conv3x3_bwd(x, w, gz)[0]
+    pm = phys_map(segs)
+    got_gx = gx.cpu().numpy().transpose(0, 3, 1, 2)
+    assert rel_l2(got_gx[:, [p_ for p_, l in enumerate(pm) if l >= 0]], rgx) < TOL[0]
+    pad = [p_ for p_, l in enumerate(pm) if l < 0]
+    assert not pad or float(np.abs(got_gx[:, pad]).max()) == 0.0
+    for key, val in (('wino_band', 1), ('wino_band', 32), ('wino_persist', 0), ('cu_reserve', 37), ('wino_persist', 1)):
+        tn = lib.Tuning(**{key: val})
+        y2 = torch.full((B, H, W, cout_p), 7.0, device='cuda')
+        stats2, rows2 = stat_buf(C, lib.OP_CONV3X3_WINOGRAD24, B, H, W, cin_p, cout_p, 0, tuning=tn)
+        lib.call('clamd_conv3x3_winograd24', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y2), cout_p, ptr(stats2), rows2, B, H, W, cin_p, cout_p, 1,
+                 tn.ref(), s)
+        sync()
+        assert rows2 == rows and torch.equal(y, y2) and torch.equal(stats, stats2), (key, val)
+
+
 def _random_conv_shapes(n, seed):
     """Seeded random problem sizes that hit ragged tiles, several channel slabs, K-step pairs / fours / odd counts and
     the split-K tail of every 3x3 kernel."""
