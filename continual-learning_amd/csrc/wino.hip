@@ -56,6 +56,11 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
     constexpr int WN_LDS = (NST * WN_STAGE * 16 > 2 * MT * WN_EXB * 4 ? NST * WN_STAGE * 16 : 2 * MT * WN_EXB * 4) / 16;
     static_assert(WN_LDS * 16 <= 160 * 1024, "LDS budget");
     __shared__ uint4 smem[WN_LDS];
+    // Statistics rows: one per pixel tile when every tile has its own workgroup; one per WORKGROUP of a persistent grid,
+    // zeroed here and accumulated tile after tile by the same thread with plain loads and stores (see wino24.hip).
+    const bool per_wg_rows = p.stats != nullptr && gridDim.x < (unsigned)p.nblk;
+    if (per_wg_rows && threadIdx.x < 128)        // thread (k, c) zeroes exactly the words it later accumulates into
+        for (int n = threadIdx.x & 63; n < p.Np; n += 64) p.stats[((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * p.Np + n] = 0.f;
 
     // Persistent: workgroup g walks the tiles g, g + grid, ... (same XCD every round).  The output stores and the
     // statistics row of a tile drain while the next tile is loaded and multiplied; a workgroup per tile instead waits for
@@ -318,7 +323,16 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
             if (tid < 128) {
                 const int k = tid >> 6, c = tid & 63;
                 const float t = sb[(0 * 2 + k) * 64 + c] + sb[(1 * 2 + k) * 64 + c] + sb[(2 * 2 + k) * 64 + c] + sb[(3 * 2 + k) * 64 + c];
-                if (n0 + c < p.Np) p.stats[((size_t)tm * 2 + k) * p.Np + n0 + c] = t;      // row = pixel tile: independent of the grid
+                if (n0 + c < p.Np) {
+                    float* dst = p.stats + ((size_t)(per_wg_rows ? (int)blockIdx.x : tm) * 2 + k) * p.Np + n0 + c;
+                    if (per_wg_rows) {
+                        // same thread, same address as in this workgroup's earlier tiles of the slab (and as its zero fill):
+                        // drain the wave's memory counter so that store has reached L2, then read it back from L2 (sc1)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        const float old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst, old + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else *dst = t;
+                }
             }
         }
 
@@ -398,8 +412,13 @@ static bool wino_mt2(int B, int H, int W, int Cout_p, const clamd_tuning& tn) {
     const long long nblk1 = (long long)B * ((H + 7) / 8) * ((W + 15) / 16) * ntn;
     return tn.wino_mt ? tn.wino_mt == 2 : (nblk2 >= 192 || nblk1 == nblk2);
 }
-long long clamd_winograd_stat_rows(int B, int H, int W, int Cout_p, const clamd_tuning& tn) {
+static long long wino_tiles(int B, int H, int W, int Cout_p, const clamd_tuning& tn) {
     return (long long)B * ((H + (wino_mt2(B, H, W, Cout_p, tn) ? 15 : 7)) / (wino_mt2(B, H, W, Cout_p, tn) ? 16 : 8)) * ((W + 15) / 16);
+}
+// rows of a launch: one per pixel tile (one workgroup per tile), or one per workgroup of the persistent grid
+long long clamd_winograd_stat_rows(int B, int H, int W, int Cout_p, const clamd_tuning& tn) {
+    const long long tiles = wino_tiles(B, H, W, Cout_p, tn), nblk = tiles * ((Cout_p + 63) / 64);
+    return (tn.wino_persist && nblk > clamd_usable_cus(tn)) ? clamd_usable_cus(tn) : tiles;
 }
 
 extern "C" {
@@ -429,7 +448,8 @@ int clamd_conv3x3_winograd(const float* x, int x_ldc, const float* w_wino, const
     const bool mt2 = wino_mt2(B, H, W, Cout_p, tn);
     p.band = wino_band((mt2 ? nblk2 : nblk1) / ntn, ntn, (double)B * H * W * Cin_p, 16.0 * Cin_p * Cout_p, tn.wino_band);
     p.nblk = (int)(mt2 ? nblk2 : nblk1);
-    if (stats && stat_rows != p.nblk / ntn) return clamd_fail("conv3x3_winograd: stat_rows does not match clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD, ...)");
+    if (stats && stat_rows != clamd_winograd_stat_rows(B, H, W, Cout_p, tn))
+        return clamd_fail("conv3x3_winograd: stat_rows does not match clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD, ...)");
     const unsigned grid = tn.wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_usable_cus(tn)) : (unsigned)p.nblk;
     const bool ragged = (H % (mt2 ? 16 : 8)) != 0 || (W % 16) != 0 || (Cout_p % 64) != 0;
 #define WN_LAUNCH(MT_, RG_) hipLaunchKernelGGL((wino_kernel<MT_, RG_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p)

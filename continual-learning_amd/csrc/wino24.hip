@@ -46,6 +46,14 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
     static_assert(LDS * 16 <= 160 * 1024, "LDS budget");
     __shared__ uint4 smem[LDS];
 
+    // Statistics rows.  One workgroup per tile (gridDim.x == nblk): row = pixel tile, written once.  Persistent grid: row =
+    // this workgroup, zeroed here and accumulated tile after tile by the SAME thread per (kind, channel) with plain loads and
+    // stores -- the tile -> workgroup map is static, so the sums are bit-reproducible, and bn_finalize adds <= 256 rows
+    // instead of one per tile (4096 at 64 channels x 256^2: 35 us per finalize launch).
+    const bool per_wg_rows = p.stats != nullptr && gridDim.x < (unsigned)p.nblk;
+    if (per_wg_rows && threadIdx.x < 128)        // thread (k, c) zeroes exactly the words it later accumulates into
+        for (int n = threadIdx.x & 63; n < p.Np; n += 64) p.stats[((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * p.Np + n] = 0.f;
+
     for (int v = blockIdx.x; v < p.nblk; v += gridDim.x) {
         // re-derived per tile from an opaque copy of the thread id (see wino.hip: hoisted constants would spill)
         int tid = threadIdx.x;
@@ -261,7 +269,16 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
             if (tid < 128) {
                 const int k = tid >> 6, c = tid & 63;
                 const float t = sb[(0 * 2 + k) * 64 + c] + sb[(1 * 2 + k) * 64 + c] + sb[(2 * 2 + k) * 64 + c] + sb[(3 * 2 + k) * 64 + c];
-                if (n0 + c < p.Np) p.stats[((size_t)tm * 2 + k) * p.Np + n0 + c] = t;      // row = pixel tile: independent of the grid
+                if (n0 + c < p.Np) {
+                    float* dst = p.stats + ((size_t)(per_wg_rows ? (int)blockIdx.x : tm) * 2 + k) * p.Np + n0 + c;
+                    if (per_wg_rows) {
+                        // same thread, same address as in this workgroup's earlier tiles of the slab (and as its zero fill):
+                        // drain the wave's memory counter so that store has reached L2, then read it back from L2 (sc1)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        const float old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst, old + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else *dst = t;
+                }
             }
         }
         __syncthreads();                                                   // exchange / statistics blocks are free again
@@ -342,18 +359,25 @@ namespace clamd {
 // workgroup tile: 8 x 32 pixels, or 16 x 16 for images narrower than 32
 static inline void w24_tile(int W, int& ph, int& pw) { if (W >= 32) { ph = 8; pw = 32; } else { ph = 16; pw = 16; } }
 
-long long clamd_winograd24_stat_rows(int B, int H, int W) {
+static long long w24_tiles(int B, int H, int W) {
     int ph, pw;
     w24_tile(W, ph, pw);
     return (long long)B * ((H + ph - 1) / ph) * ((W + pw - 1) / pw);
 }
 
+// rows of a launch: one per pixel tile (one workgroup per tile), or one per workgroup of the persistent grid
+long long clamd_winograd24_stat_rows(int B, int H, int W, int Cout_p, const clamd_tuning& tn) {
+    const long long tiles = w24_tiles(B, H, W), nblk = tiles * ((Cout_p + 63) / 64);
+    return (tn.wino_persist && nblk > clamd_usable_cus(tn)) ? clamd_usable_cus(tn) : tiles;
+}
+
 int launch_wino24(WinoParams p, const clamd_tuning& tn, int stat_rows, hipStream_t stream) {
     int ph, pw;
     w24_tile(p.W, ph, pw);
-    const long long ntn = (p.Np + 63) / 64, tiles = clamd_winograd24_stat_rows(p.B, p.H, p.W);
-    if (tiles * ntn > 0x7fffffff) return clamd_fail("conv3x3_winograd: grid out of range");
-    if (p.stats && stat_rows != tiles) return clamd_fail("conv3x3_winograd: stat_rows does not match clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD, ...)");
+    const long long ntn = (p.Np + 63) / 64, tiles = w24_tiles(p.B, p.H, p.W);
+    if (tiles * ntn > 0x7fffffff) return clamd_fail("conv3x3_winograd24: grid out of range");
+    if (p.stats && stat_rows != clamd_winograd24_stat_rows(p.B, p.H, p.W, p.Np, tn))
+        return clamd_fail("conv3x3_winograd24: stat_rows does not match clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD24, ...)");
     p.band = wino_band(tiles, ntn, (double)p.B * p.H * p.W * p.Kp, 24.0 * p.Kp * p.Np, tn.wino_band);
     p.nblk = (int)(tiles * ntn);
     const unsigned grid = tn.wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_usable_cus(tn)) : (unsigned)p.nblk;

@@ -37,7 +37,7 @@ __device__ inline int wn_phys2log(int p, int seg0, int seg0p, int L) {
 int wino_band(long long tiles, long long slabs, double x_elems, double f_elems, int forced);
 
 // wino24.hip
-long long clamd_winograd24_stat_rows(int B, int H, int W);
+long long clamd_winograd24_stat_rows(int B, int H, int W, int Cout_p, const clamd_tuning& tn);
 int launch_wino24(WinoParams p, const clamd_tuning& tn, int stat_rows, hipStream_t stream);
 
 }  // namespace clamd

@@ -50,11 +50,7 @@ class GradSync:
         self.launches = 0
         model.grad_sync = self
         # RCCL's channel workgroups hold CUs for the duration of a collective, and our MFMA kernels need a whole CU per
-        # workgroup: a statically strided persistent grid sized to the CU count would then run two full rounds, while the
-        # hardware dispatcher spreads one-workgroup-per-tile grids over whatever CUs are free (persistent is worth 0.3 %).
-        # This is a field of THIS model's tuning (passed per call): nothing process-wide is touched, results are unchanged
-        # (the statistics rows of the Winograd kernel are per tile either way).
-        model.tuning.wino_persist = 0
+        # workgroup.  Nothing process-wide is touched: the reserve below is a field of THIS model's tuning (passed per call).
         # grids sized to the chip (persistent conv kernel, split-K weight gradients) leave the CUs of the RCCL channels free
         if cu_reserve is None:
             nccl = dist.get_backend(process_group) == 'nccl' and self.world > 1

@@ -85,8 +85,12 @@ def test_stat_rows_and_tuning_are_per_call(C):
     assert L.stat_rows(L.OP_CONV3X3, 16, 128, 128, 128, 128, L.BF16) == 128
     assert L.stat_rows(L.OP_CONV3X3, 16, 256, 256, 64, 64, L.BF16, tuning=L.Tuning(igemm_pws=0, igemm_ws=1)) == 16 * 32 * 8
     assert L.stat_rows(L.OP_CONV3X3, 16, 256, 256, 64, 64, L.F32, fused_bn=True) == 16 * 32 * 8     # pws declines fp32 + fused sums
-    assert L.stat_rows(L.OP_CONV3X3_WINOGRAD, 16, 256, 256, 64, 64, L.F32) == 16 * 16 * 16
+    # Winograd kernels: one row per workgroup of the persistent grid, one per pixel tile when every tile has its own workgroup
+    assert L.stat_rows(L.OP_CONV3X3_WINOGRAD, 16, 256, 256, 64, 64, L.F32) == 256
     assert L.stat_rows(L.OP_CONV3X3_WINOGRAD, 16, 256, 256, 64, 64, L.F32, tuning=L.Tuning(wino_persist=0)) == 16 * 16 * 16
+    assert L.stat_rows(L.OP_CONV3X3_WINOGRAD24, 16, 256, 256, 64, 64, L.F32, tuning=L.Tuning(cu_reserve=8)) == 248
+    assert L.stat_rows(L.OP_CONV3X3_WINOGRAD24, 16, 256, 256, 64, 64, L.F32, tuning=L.Tuning(wino_persist=0)) == 16 * 32 * 8
+    assert L.stat_rows(L.OP_CONV3X3_WINOGRAD24, 1, 16, 16, 64, 64, L.F32) == 1                       # fewer tiles than CUs
     assert L.stat_rows(L.OP_CONV1X1, 2, 64, 64, 32, 64, L.F32) == 2 * 8 * 2
     assert L.stat_rows(L.OP_BN_BWD_REDUCE, 16, 256, 256, 0, 64, L.BF16) == 1024
     assert L.stat_rows(L.OP_BN_BWD_REDUCE, 16, 16, 16, 0, 1024, L.BF16) == 256
