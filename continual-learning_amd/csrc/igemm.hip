@@ -262,6 +262,30 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
             }
 
     if constexpr (EPI == EPI_NCHW) {
+        if (p.pred) {
+            // arg-max fused into the head (trainer.py:279 `torch.max(outputs, 1)`): lane = class, register = pixel; a butterfly
+            // over the 32 lanes of a half-wave on (value, class) pairs, ties to the LOWER class (first maximum, as torch).
+            // Only the first 64-class slab takes part (num_classes <= 64 is checked by the launcher; tn == 0 here).
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v0 = (n0 + r < p.aux) ? acc[mt][0][e] : -__builtin_inff();
+                    float v1 = (n0 + 32 + r < p.aux) ? acc[mt][1][e] : -__builtin_inff();
+                    int i0 = n0 + r;
+                    if (v1 > v0) { v0 = v1; i0 = n0 + 32 + r; }
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) {
+                        const float ov = __shfl_xor(v0, o);
+                        const int oi = __shfl_xor(i0, o);
+                        if (ov > v0 || (ov == v0 && oi < i0)) { v0 = ov; i0 = oi; }
+                    }
+                    const int m = 64 * wave + 32 * mt + acc_row(e, h);
+                    const int yy = y0 + m / TW, xx = x0 + m % TW;
+                    if (r == ((mt * 16 + e) & 31) && yy < p.H && xx < p.W) p.pred[((long long)b * p.H + yy) * p.W + xx] = i0;
+                }
+            if (!p.y) return;
+        }
         // logits: lane = class, 4 consecutive accumulator registers = 4 consecutive pixels along W
         float* out = (float*)p.y;
 #pragma unroll
@@ -560,6 +584,15 @@ int clamd_conv1x1_logits(const void* x, int x_ldc, const void* w_packed, const f
     IgemmParams p{x, x_ldc, w_packed, bias, logits_nchw, 8, nullptr, B, H, W, Cin_p, Cout_p, 0, num_classes, 0, nullptr, nullptr};
     if (int e = check_common(p, "conv1x1_logits")) return e;
     if (num_classes > Cout_p) return clamd_fail("conv1x1_logits: num_classes > padded Cout");
+    return launch<MODE_PW, EPI_NCHW>(p, dtype, (hipStream_t)stream);
+}
+
+int clamd_conv1x1_argmax(const void* x, int x_ldc, const void* w_packed, const float* bias, long long* pred, float* logits_nchw,
+                         int B, int H, int W, int Cin_p, int Cout_p, int num_classes, int dtype, void* stream) {
+    IgemmParams p{x, x_ldc, w_packed, bias, logits_nchw, 8, nullptr, B, H, W, Cin_p, Cout_p, 0, num_classes, 0, nullptr, nullptr, pred};
+    if (int e = check_common(p, "conv1x1_argmax")) return e;
+    if (!pred) return clamd_fail("conv1x1_argmax: pred is null");
+    if (num_classes < 1 || num_classes > Cout_p || num_classes > 64) return clamd_fail("conv1x1_argmax: num_classes must be in [1, min(64, padded Cout)]");
     return launch<MODE_PW, EPI_NCHW>(p, dtype, (hipStream_t)stream);
 }
 

@@ -25,6 +25,9 @@ struct IgemmParams {
     // bn_y = that unit's saved post-ReLU activation [B,H,W,Np] (dense pitch Np), bn_sums = partial rows [row][5][Np].
     const void* bn_y;
     float* bn_sums;
+    // EPI_NCHW only: arg-max over the logical classes per pixel (first maximum wins, as torch.max), int64 [B,H,W]; y may
+    // then be null (eval forward, trainer.py:279: the logits are never materialised)
+    long long* pred;
 };
 
 template <int MODE, int TW> struct Geo {

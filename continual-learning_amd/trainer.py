@@ -130,6 +130,23 @@ class Trainer:
         self.optim.step()
         return outputs, loss
 
+    @torch.no_grad()
+    def test(self, data_loader):
+        """trainer.py:270-284: pixel accuracy (%) of the eval-mode model over a loader.  The arg-max of trainer.py:279 runs
+        inside the head kernel (UNet.predict).  Unlike the reference (which never calls .train() again) the
+        model's mode is restored afterwards."""
+        was_training = self.model.training
+        self.model.eval()
+        correct = torch.zeros((), dtype=torch.int64, device=self.device)
+        total = 0
+        for images, masks in data_loader:
+            labels = masks.to(self.device, non_blocking=True)
+            predicted = self.model.predict(images.to(self.device, non_blocking=True))
+            total += labels.numel()
+            correct += (predicted == labels).sum()
+        self.model.train(was_training)
+        return 100.0 * float(correct) / max(total, 1)
+
     def train_epoch(self, epoch):
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')          # torch warns that scheduler.step() precedes optim.step(); the

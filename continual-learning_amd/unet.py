@@ -138,6 +138,23 @@ class UNet(nn.Module):
         params = [p for p in self.parameters()]
         return _UNetFn.apply(x.contiguous().float(), eng, *params)
 
+    @torch.no_grad()
+    def predict(self, x):
+        """``torch.max(self(x), 1)[1]`` (trainer.py:279) without materialising the logits: the arg-max over classes runs
+        in the epilogue of the head kernel.  int64 [B,H,W]; BatchNorm follows ``self.training``."""
+        if not x.is_cuda:
+            raise RuntimeError('continual-learning_amd.UNet runs only on an MI355X GPU tensor: there is no CPU fallback')
+        if x.dim() != 4 or x.shape[1] != self.in_dim:
+            raise ValueError(f'expected input [B,{self.in_dim},H,W], got {tuple(x.shape)}')
+        B, _, H, W = x.shape
+        assert H % 16 == 0 and W % 16 == 0, 'input size(H, W) must be a multiple of 16 (four 2x2 pools and matching skip concats)'
+        key = (B, H, W, x.device.index)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = _Engine(self, B, H, W, x.device)
+            self._engines = {key: eng}
+        return eng.forward(x.contiguous().float(), [p for p in self.parameters()], predict=True)
+
     def extra_repr(self):
         return f'num_classes={self.num_classes}, in_dim={self.in_dim}, conv_dim={self.conv_dim}, compute={self.compute_dtype}'
 
@@ -410,7 +427,7 @@ class _Engine:
             self._build_pack_table()
 
     # ------------------------------------------------------------------------------------------ forward
-    def forward(self, x, params):
+    def forward(self, x, params, predict=False):
         m = self.model
         training = m.training
         self.fwd_training = training
@@ -440,6 +457,10 @@ class _Engine:
             if t.kind == 'convT':
                 call('clamd_convT2x2_fwd', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(t.y_slice), t.y_ldc,
                      B, h, w, t.cin_p, t.cout_p, dc, s)
+            elif predict:      # arg-max fused into the head's epilogue: the logits never reach HBM
+                logits = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
+                call('clamd_conv1x1_argmax', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(logits), None, B, h, w,
+                     t.cin_p, t.cout_p, self.K, dc, s)
             else:
                 logits = torch.empty(B, self.K, H, W, dtype=torch.float32, device=self.dev)
                 call('clamd_conv1x1_logits', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(logits), B, h, w,

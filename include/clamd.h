@@ -123,6 +123,10 @@ int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* b
 /* the head nn.Conv2d(conv_dim, num_classes, k1) (unet.py:72): logits written as fp32 NCHW [B,num_classes,H,W]. */
 int clamd_conv1x1_logits(const void* x, int x_ldc, const void* w_packed, const float* bias, float* logits_nchw,
                          int B, int H, int W, int Cin_p, int Cout_p, int num_classes, int dtype, void* stream);
+/* The head with the arg-max over classes fused into its epilogue (eval forward, trainer.py:279 `torch.max(outputs, 1)`;
+ * SURVEY.md §8f row 4): pred int64 [B,H,W], first maximum wins; logits_nchw may be NULL (the logits are then never written). */
+int clamd_conv1x1_argmax(const void* x, int x_ldc, const void* w_packed, const float* bias, long long* pred, float* logits_nchw,
+                         int B, int H, int W, int Cin_p, int Cout_p, int num_classes, int dtype, void* stream);
 /* nn.ConvTranspose2d(k2,s2)+bias (unet.py:34): x [B,h,w,Cin_p] -> y [B,2h,2w,(ldc)] channels [0,Cout_p) of the
  * slice y points at.  w_packed [4][Cout_p][Cin_p] (tap q = 2*dy+dx). */
 int clamd_convT2x2_fwd(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc, int B,

@@ -309,7 +309,7 @@ def main():
     ref_unet = _load('ref_unet', os.path.join(REF, 'models', 'unet.py'))
     ref_metrics = _load('ref_metrics', os.path.join(REF, 'metrics.py'))
     synth = _synth()
-    which = sys.argv[1:] or ['ops', 'metrics', 'voc', 'small', 'mid', 'full', 'c5', 'miou64']
+    which = sys.argv[1:] or ['ops', 'metrics', 'voc', 'small', 'mid', 'c1', 'full', 'c5', 'miou64']
     if 'voc' in which:
         capture_voc()
     if 'ops' in which:
@@ -320,6 +320,8 @@ def main():
         capture_model(ref_unet, ref_metrics, synth, 'cd4_c2_32', 2, 4, 2, 32, 3, 1e-3, store_weights=True)
     if 'mid' in which:       # config-1-like: 64x64 bs2, 21 classes, conv_dim 8
         capture_model(ref_unet, ref_metrics, synth, 'cd8_c21_64', 21, 8, 2, 64, 3, 1e-3, store_weights=False)
+    if 'c1' in which:        # BASELINE.json configs[0] exactly: UNet(2,3,64) 64x64 bs2, 3 steps (CPU-runnable plumbing config)
+        capture_model(ref_unet, ref_metrics, synth, 'cd64_c2_64', 2, 64, 2, 64, 3, 1e-4, store_weights=False, store_grads=False)
     if 'full' in which:      # config 2: the real thing, 256x256 bs16 conv_dim 64 (about 1 minute of CPU)
         capture_model(ref_unet, ref_metrics, synth, 'cd64_c21_256', 21, 64, 16, 256, 2, 1e-4,
                       store_weights=False, logits_stride=997, store_grads=False)

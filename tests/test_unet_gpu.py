@@ -113,6 +113,40 @@ def test_train_steps_vs_reference_golden(C, golden, fixture, nc, cd, size, dtype
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'bf16x3'])
+def test_config1_exact_vs_reference_golden(C, golden, dtype):
+    """BASELINE.json configs[0] exactly -- UNet(num_classes=2, conv_dim=64) at 64x64, batch 2 (the reference's CPU-runnable
+    plumbing configuration) -- 3 train steps against the capture from the reference: full logits, loss sequence, per-tensor
+    gradient norms, arg-max histogram, metrics."""
+    g = golden('unet_cd64_c2_64.npz')
+    assert (int(g['num_classes']), int(g['conv_dim']), int(g['batch']), int(g['size'])) == (2, 64, 2, 64)
+    fp32 = dtype != 'bf16'
+    model = C.UNet(2, 3, 64, compute_dtype=dtype)
+    load_closed_form(C, model)
+    model = model.cuda().train()
+    x = torch.from_numpy(C.synth.images(1234, 2, 3, 64, 64)).cuda()
+    y = torch.from_numpy(C.synth.labels(1234, 2, 64, 64, 2)).cuda()
+    opt = C.FusedAdam(model.parameters(), lr=float(g['lr']), betas=[0.5, 0.99])
+    crit = C.CrossEntropyLoss()
+    losses = []
+    for s in range(3):
+        out = model(x); opt.zero_grad(); loss = crit(out, y); loss.backward()
+        if s == 0:
+            lg = out.detach().cpu().numpy()
+            tol = 1e-3 if fp32 else 6e-2
+            assert rel_l2(lg, g['logits']) < tol and maxrel(lg, g['logits']) < tol * (1 if fp32 else 2)
+            gn = np.array([float(p.grad.double().norm()) for p in model.parameters()])
+            big = g['grad_norms'] > 1e-4 * g['grad_norms'].max()
+            np.testing.assert_allclose(gn[big], g['grad_norms'][big], rtol={'fp32': 1e-2, 'bf16x3': 3e-2, 'bf16': 0.4}[dtype])
+            m = C.eval_metrics(y, out.detach(), 2)
+            np.testing.assert_allclose([float(v) for v in m], g['metrics'], rtol=1e-5 if fp32 else 0.2, atol=0 if fp32 else 0.1)
+            if fp32:
+                assert np.array_equal(np.bincount(out.detach().argmax(1).cpu().numpy().reshape(-1), minlength=2), g['pred_hist'])
+        opt.step()
+        losses.append(float(loss.detach()))
+    np.testing.assert_allclose(losses, g['losses'], rtol=5e-4 if fp32 else 5e-2)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'bf16x3'])
 def test_full_size_config2_vs_reference_golden(C, golden, dtype):
     """BASELINE.json configs[1]/[2] shape: UNet(21,3,64), 256x256, bs16 -- logits subsample, loss, per-tensor gradient
     norms, arg-max histogram and mIoU captured from the reference's CPU path."""
@@ -275,6 +309,44 @@ def test_eval_mode_and_state_dict_roundtrip(C):
     for k, v in ref.state_dict().items():
         assert rel_l2(sd[k].double().numpy(), v.double().numpy()) < 1e-4 or k.endswith('num_batches_tracked'), k
     assert int(sd['last.5.num_batches_tracked']) == 2
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_predict_fuses_argmax_into_the_head(C, dtype):
+    """UNet.predict == torch.max(model(x), 1)[1] (trainer.py:279) with the arg-max in the head kernel's
+    epilogue (no logits in HBM), in eval and in train mode, odd class counts, ties to the lower class; Trainer.test() =
+    the reference's pixel accuracy (trainer.py:270-284)."""
+    for nc, cd, B, H, W in ((21, 8, 2, 64, 96), (2, 4, 3, 32, 32), (40, 8, 1, 48, 64)):
+        torch.manual_seed(nc)
+        m = C.UNet(nc, 3, cd, compute_dtype=dtype).cuda()
+        x = torch.from_numpy(C.synth.images(5, B, 3, H, W)).cuda()
+        for mode in (True, False):
+            m.train(mode)
+            with torch.no_grad():
+                want = m(x).argmax(1)
+            if mode:                     # a train-mode forward moves the running statistics; predict() must see the same ones
+                bufs = {k: v.clone() for k, v in m.state_dict().items()}
+            got = m.predict(x)
+            assert got.dtype == torch.int64 and tuple(got.shape) == (B, H, W)
+            if mode:
+                assert torch.equal(got, want)      # batch statistics of the same batch
+                m.load_state_dict(bufs)
+            else:
+                assert torch.equal(got, want)
+    # ties: a head with all-zero weights and equal biases -> every class equal -> class 0
+    with torch.no_grad():
+        m.last[6].weight.zero_(); m.last[6].bias.fill_(0.25)
+    assert int(m.eval().predict(x).abs().max()) == 0
+    cfg = C.default_config(n_iters=2, lr=1e-3, num_classes=5, conv_dim=4, compute_dtype=dtype, stats_every=1)
+    data = [(torch.from_numpy(C.synth.images(3, 2, 3, 32, 32, first_image=2 * i)), torch.from_numpy(C.synth.labels(3, 2, 32, 32, 5, first_image=2 * i)))
+            for i in range(2)]
+    tr = C.Trainer(data, cfg)
+    tr.train_val(epochs=1)
+    acc = tr.test(data)
+    tr.model.eval()
+    with torch.no_grad():
+        ref = 100.0 * sum(int((tr.model(a.cuda()).argmax(1) == b.cuda()).sum()) for a, b in data) / sum(b.numel() for _, b in data)
+    assert acc == pytest.approx(ref, abs=1e-9) and tr.model.training is False
 
 
 def test_misuse_errors(C):
