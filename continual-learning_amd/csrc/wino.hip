@@ -61,6 +61,16 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
     const bool per_wg_rows = p.stats != nullptr && gridDim.x < (unsigned)p.nblk;
     if (per_wg_rows && threadIdx.x < 128)        // thread (k, c) zeroes exactly the words it later accumulates into
         for (int n = threadIdx.x & 63; n < p.Np; n += 64) p.stats[((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * p.Np + n] = 0.f;
+    float racc = 0.f;                            // running sum of this thread's (kind, channel) over the tiles of one slab
+    int rslab = -1;
+    auto flush_row = [&]() {                     // threads < 128 only; wave-uniform call sites (see wino24.hip)
+        if (rslab >= 0 && rslab * 64 + (int)(threadIdx.x & 63) < p.Np) {
+            float* dst = p.stats + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * p.Np + rslab * 64 + (threadIdx.x & 63);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst, old + racc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
 
     // Persistent: workgroup g walks the tiles g, g + grid, ... (same XCD every round).  The output stores and the
     // statistics row of a tile drain while the next tile is loaded and multiplied; a workgroup per tile instead waits for
@@ -323,21 +333,18 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
             if (tid < 128) {
                 const int k = tid >> 6, c = tid & 63;
                 const float t = sb[(0 * 2 + k) * 64 + c] + sb[(1 * 2 + k) * 64 + c] + sb[(2 * 2 + k) * 64 + c] + sb[(3 * 2 + k) * 64 + c];
-                if (n0 + c < p.Np) {
-                    float* dst = p.stats + ((size_t)(per_wg_rows ? (int)blockIdx.x : tm) * 2 + k) * p.Np + n0 + c;
-                    if (per_wg_rows) {
-                        // same thread, same address as in this workgroup's earlier tiles of the slab (and as its zero fill):
-                        // drain the wave's memory counter so that store has reached L2, then read it back from L2 (sc1)
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        const float old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(dst, old + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else *dst = t;
+                if (!per_wg_rows) {
+                    if (n0 + c < p.Np) p.stats[((size_t)tm * 2 + k) * p.Np + n0 + c] = t;          // row = pixel tile
+                } else {
+                    if (tn != rslab) { flush_row(); rslab = tn; racc = 0.f; }                      // wave-uniform
+                    racc += t;
                 }
             }
         }
 
         __syncthreads();                                                   // exchange / statistics blocks are free again
     }
+    if (per_wg_rows && threadIdx.x < 128) flush_row();
 }
 
 // ---- filter transform ---------------------------------------------------------------------------------------------

@@ -26,6 +26,16 @@
 
 namespace clamd {
 
+#ifdef CLAMD_DIAG
+// diagnostic build only (python build.py --diag; tools/w24_diag.py): cycles per phase of a tile, summed over workgroups (wave 0)
+__device__ unsigned long long g_w24_diag[8];
+#define W24_T() __builtin_amdgcn_s_memtime()
+#define W24_ADD(i_, v_) do { if (threadIdx.x == 0) atomicAdd(&g_w24_diag[i_], (unsigned long long)(v_)); } while (0)
+#else
+#define W24_T() 0ull
+#define W24_ADD(i_, v_) do { } while (0)
+#endif
+
 constexpr int W24_WG = 66;                                    // padded rows per (xi, group)
 constexpr int W24_WT_SLOTS = 24 * 2 * W24_WG;
 constexpr int W24_EXP = 36;                                   // row pitch (floats) of the epilogue exchange block
@@ -47,17 +57,31 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
     __shared__ uint4 smem[LDS];
 
     // Statistics rows.  One workgroup per tile (gridDim.x == nblk): row = pixel tile, written once.  Persistent grid: row =
-    // this workgroup, zeroed here and accumulated tile after tile by the SAME thread per (kind, channel) with plain loads and
-    // stores -- the tile -> workgroup map is static, so the sums are bit-reproducible, and bn_finalize adds <= 256 rows
-    // instead of one per tile (4096 at 64 channels x 256^2: 35 us per finalize launch).
+    // this workgroup; thread (kind, channel) keeps its running sum in a REGISTER across the tiles of one output slab and adds
+    // it to its word of the row (zeroed here; plain load + store by the one thread that owns the word) when the slab changes
+    // and at the end -- a read-modify-write per tile would drain the wave's memory counter behind the tile's output stores
+    // (5k cycles per tile, measured).  The tile -> workgroup map is static, so the sums are bit-reproducible, and bn_finalize
+    // adds <= 256 rows instead of one per tile (4096 at 64 channels x 256^2: 35 us per finalize launch).
     const bool per_wg_rows = p.stats != nullptr && gridDim.x < (unsigned)p.nblk;
     if (per_wg_rows && threadIdx.x < 128)        // thread (k, c) zeroes exactly the words it later accumulates into
         for (int n = threadIdx.x & 63; n < p.Np; n += 64) p.stats[((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * p.Np + n] = 0.f;
+    float racc = 0.f;
+    int rslab = -1;
+    auto flush_row = [&]() {          // threads < 128 only; wave-uniform call sites
+        if (rslab >= 0 && rslab * 64 + (int)(threadIdx.x & 63) < p.Np) {
+            float* dst = p.stats + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * p.Np + rslab * 64 + (threadIdx.x & 63);
+            // this thread's own earlier store to the word (zero fill or an earlier flush) must have reached L2: drain, read from L2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst, old + racc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
 
     for (int v = blockIdx.x; v < p.nblk; v += gridDim.x) {
         // re-derived per tile from an opaque copy of the thread id (see wino.hip: hoisted constants would spill)
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
+        const unsigned long long dt0 = W24_T(); (void)dt0;
         const int lane = tid & 63, w = tid >> 6;
         const int r = lane & 31, h = lane >> 5;
         const int tiles_x = (p.W + PW - 1) / PW, tiles_y = (p.H + PH - 1) / PH;
@@ -72,7 +96,11 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
 
         // ---- staging descriptors --------------------------------------------------------------------------------------
         const unsigned img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc * 4u;
+#ifdef W24_ABLATE_SAMETILE   // measurement only: every workgroup stages the same input tile (all loads hit the caches)
+        const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x, img);
+#else
         const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x + (size_t)b * img, img);
+#endif
         const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.w, (unsigned)(24u * p.Np * p.Kp * 4u));
         const __amdgpu_buffer_rsrc_t xrs_dead = make_rsrc(p.x, 0u), wrs_dead = make_rsrc(p.w, 0u);
         unsigned in_vo[NJI];
@@ -83,7 +111,11 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
             if (piece >= 2 * PIX) piece -= 2 * PIX;
             const int g = piece & 1, pix = piece >> 1;
             const int hy = pix / HW_, hx = pix - hy * HW_;
+#ifdef W24_ABLATE_SAMETILE
+            const int yy = hy - 1, xx = hx - 1;
+#else
             const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+#endif
             in_vo[j] = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? (unsigned)(((yy * p.W + xx) * p.x_ldc + 4 * g) * 4) : BUF_OOB;
             in_slot[j] = g * PIXP + hy * HW_ + hx + (hy >> 1);
         }
@@ -173,9 +205,11 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
             lds_store_from(0, ri0, rw0);
             lds_store_from(1, ri1, rw1);
         }
+        const unsigned long long dt1 = W24_T(); (void)dt1;
         __syncthreads();
         frags(0);
         __syncthreads();                                                      // stage 0 is free again
+        const unsigned long long dt2 = W24_T(); (void)dt2;
         for (int k = 0; k < nk; ++k) {
             uint4 Ac[6], Bc[6][2];
 #pragma unroll
@@ -196,6 +230,7 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
 
         // ---- epilogue: Y = A4^T M A6, A6^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]] in-lane (j -> q),
         // A4^T = [[1,1,1,0],[0,1,-1,-1]] across the four waves through LDS -------------------------------------------------
+        const unsigned long long dt3 = W24_T(); (void)dt3;
         float* const ex = reinterpret_cast<float*>(smem);
         const int tl = tid >> 3, ng = tid & 7;                                // reader: tile, 4-channel group
         float st1[2][4], st2[2][4];
@@ -218,6 +253,7 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
             }
         }
         __syncthreads();
+        const unsigned long long dt4 = W24_T(); (void)dt4;
         const int oty = tl / TXN, otx = tl % TXN;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -244,7 +280,9 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
                     o.z = fmaxf(o.z + bias4.z, relu_lo); o.w = fmaxf(o.w + bias4.w, relu_lo);
                     const int yy = y0 + 2 * oty + pp, xx = x0 + 4 * otx + q;
                     if (!RAGGED || (yy < p.H && xx < p.W && n < p.Np)) {
+#ifndef W24_ABLATE_ST
                         *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = o;
+#endif
                         st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
                         st2[nt][0] = fmaf(o.x, o.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, o.y, st2[nt][1]);
                         st2[nt][2] = fmaf(o.z, o.z, st2[nt][2]); st2[nt][3] = fmaf(o.w, o.w, st2[nt][3]);
@@ -252,6 +290,7 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
                 }
             }
         }
+        const unsigned long long dt5 = W24_T(); (void)dt5;
         if (p.stats) {
             // threads with equal (tid & 7) own the same channels: fold the 8 tiles of a wave (lane bits 3-5), then the 4 waves
             __syncthreads();                                                   // every wave has read its exchange blocks
@@ -269,20 +308,21 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
             if (tid < 128) {
                 const int k = tid >> 6, c = tid & 63;
                 const float t = sb[(0 * 2 + k) * 64 + c] + sb[(1 * 2 + k) * 64 + c] + sb[(2 * 2 + k) * 64 + c] + sb[(3 * 2 + k) * 64 + c];
-                if (n0 + c < p.Np) {
-                    float* dst = p.stats + ((size_t)(per_wg_rows ? (int)blockIdx.x : tm) * 2 + k) * p.Np + n0 + c;
-                    if (per_wg_rows) {
-                        // same thread, same address as in this workgroup's earlier tiles of the slab (and as its zero fill):
-                        // drain the wave's memory counter so that store has reached L2, then read it back from L2 (sc1)
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        const float old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(dst, old + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else *dst = t;
+                if (!per_wg_rows) {
+                    if (n0 + c < p.Np) p.stats[((size_t)tm * 2 + k) * p.Np + n0 + c] = t;          // row = pixel tile
+                } else {
+                    if (tn != rslab) { flush_row(); rslab = tn; racc = 0.f; }                      // wave-uniform
+                    racc += t;
                 }
             }
         }
         __syncthreads();                                                   // exchange / statistics blocks are free again
+        // [0] setup + first loads + first stores  [1] wait first stage + first fragments  [2] K loop  [3] exchange writes + barrier
+        // [4] read-back, output transform, stores  [5] statistics  [6] tiles  [7] K chunks
+        W24_ADD(0, dt1 - dt0); W24_ADD(1, dt2 - dt1); W24_ADD(2, dt3 - dt2); W24_ADD(3, dt4 - dt3); W24_ADD(4, dt5 - dt4);
+        W24_ADD(5, W24_T() - dt5); W24_ADD(6, 1); W24_ADD(7, nk);
     }
+    if (per_wg_rows && threadIdx.x < 128) flush_row();
 }
 
 // ---- filter transform: dst[(k/8)*24 + 6i + j][n][k%8] = (G4 g G6^T)[i][j], row 2 negated (jobs as in wino.hip) ---------
@@ -338,6 +378,14 @@ int clamd_wino24_pack(const void* jobs_dev, int njobs, int total_blocks, void* s
     hipLaunchKernelGGL(wino24_pack_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const WinoPackJob*)jobs_dev, njobs);
     return clamd_check_launch("wino24_pack");
 }
+
+#ifdef CLAMD_DIAG
+int clamd_debug_w24_diag(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(clamd::g_w24_diag), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(clamd::g_w24_diag), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 int clamd_conv3x3_winograd24(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
                              float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
