@@ -23,9 +23,23 @@ for dt in DT:
     shutil.copy(f'{G}/{src}_prof_{dt}/{src}_kernel_stats.csv', f'{P}/{dst}_{dt}_kernel_stats.csv')
     shutil.copy(f'{G}/{src}_bench_{dt}_under_rocprof.json', f'{P}/{dst}_bench_{dt}_under_rocprof.json')
     out = subprocess.run([sys.executable, f'{ROOT}/tools/pmc_summary.py', f'{G}/{src}_pmc_{dt}_FETCH_SIZE',
-                          f'{G}/{src}_pmc_{dt}_WRITE_SIZE', dt, str(STEPS_PMC)], capture_output=True, text=True, check=True).stdout
+                          f'{G}/{src}_pmc_{dt}_WRITE_SIZE', dt, str(STEPS_PMC), '256', '16', '64'], capture_output=True, text=True, check=True).stdout
     open(f'{P}/{dst}_traffic_{dt}.json', 'w').write(out)
 
+# SQ counters of the fp32 step (three --pmc passes), held-CU rehearsal, per-layer tables
+sq = []
+for i in (1, 2, 3):
+    d = f'{G}/{src}_sq{i}_fp32'
+    if os.path.isdir(d):
+        sq.append(subprocess.run([sys.executable, f'{ROOT}/tools/pmc_sq.py', d, 'wino'], capture_output=True, text=True, check=True).stdout)
+if sq:
+    open(f'{P}/{dst}_sq_counters_fp32_winograd.txt', 'w').write(
+        "# rocprofv3 --pmc passes (one counter set per run) of: python3 bench.py --steps 1 --warmup 1 --dtype fp32 --no-cpu-baseline --also '' --no-kernel-timing\n"
+        '# per-kernel means over launches (tools/pmc_sq.py); SQ_VALU_MFMA_BUSY_CYCLES is summed over the 4 SIMDs of a CU: pipe utilisation = MFMA_BUSY / (4 x BUSY_CU)\n'
+        + ''.join(sq))
+for f in ('cu_steal.jsonl', 'layers_fp32.txt', 'layers_bf16.txt', 'layers_bf16x3.txt'):
+    if os.path.exists(f'{G}/{src}_{f}'):
+        shutil.copy(f'{G}/{src}_{f}', f'{P}/{dst}_{f}')
 c5 = None
 if os.path.exists(f'{G}/{src}_bench_config5_bf16.json'):
     shutil.copy(f'{G}/{src}_bench_config5_bf16.json', f'{P}/{dst}_bench_config5_bf16.json')
@@ -42,7 +56,7 @@ L.append(f'| `{dst}_traffic_<dtype>.json` | per-kernel HBM bytes from two separa
 L.append('## Headline (un-profiled run)\n')
 L.append('| dtype | images/s | ms/step | step FLOP/s ÷ MFMA peak | conv3x3 fwd+dgrad kernels | conv3x3 wgrad (+reduce) |\n|---|---|---|---|---|---|')
 r, w = b['roofline'], b['roofline_wgrad']
-L.append(f"| f32 (exact fp32 MFMA) — default | {b['value']} | {b['ms_per_step']} | {b['step_frac_of_mfma_peak']} of {r['peak']} TF | {r['achieved']} TF/s = {r['frac']} | {w['achieved']} TF/s = {w['frac']} |")
+L.append(f"| f32 (exact fp32 MFMA, Winograd) — default | {b['value']} | {b['ms_per_step']} | {b['step_frac_of_mfma_peak']} executed of {r['peak']} TF ({b['step_algorithmic_tflops']} algorithmic TF/s) | {r['achieved']} executed TF/s = {r['frac']} ({r.get('algorithmic_tflops')} algorithmic) | {w['achieved']} executed TF/s = {w['frac']} ({w.get('algorithmic_tflops')} algorithmic) |")
 PK = {'bf16x3': 833.3, 'bf16': 2500.0}
 for a in b.get('also', []):
     key = 'bf16x3' if a['dtype'].startswith('bf16x3') else 'bf16'
