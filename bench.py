@@ -45,7 +45,7 @@ def parse():
     return ap.parse_args()
 
 
-def run(args, dtype, rank, world, device, timing=True):
+def run(args, dtype, rank, world, device, timing=True, dist_on=False):
     import continual_learning_amd as C
     from continual_learning_amd import unet as U
     torch.manual_seed(1234)
@@ -53,7 +53,7 @@ def run(args, dtype, rank, world, device, timing=True):
     opt = C.FusedAdam(model.parameters(), lr=1e-4, betas=[0.5, 0.99])
     crit = C.CrossEntropyLoss()
     sync = None
-    if world > 1:
+    if dist_on:
         C.ddp.broadcast_parameters(model)
         sync = C.ddp.GradSync(model, opt, timing=True)
     x = torch.from_numpy(C.synth.images(1234, args.batch, 3, args.size, args.size, first_image=rank * args.batch)).to(device)
@@ -74,19 +74,19 @@ def run(args, dtype, rank, world, device, timing=True):
     if sync is not None:
         sync.exposed_ms()               # drop the warm-up's wait events
         sync.launches = 0
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     comm = None
-    if world > 1:
+    if dist_on:
         exposed = sync.exposed_ms() / args.steps
         t = torch.tensor([dt, exposed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -160,14 +160,17 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    if world > 1:
+    # CLAMD_BENCH_FORCE_DIST=1: rehearse the N > 1 code path (RCCL communicator with the channel cap, GradSync, comm record)
+    # with ONE rank on a one-GPU box; the driver's runs never set it
+    dist_on = world > 1 or bool(os.environ.get('CLAMD_BENCH_FORCE_DIST'))
+    if dist_on:
         if backend == 'nccl':
             import continual_learning_amd as C
             C.ddp.init_rccl(device)                             # "nccl" IS RCCL on ROCm; caps the channel count
         else:
             dist.init_process_group(backend)
 
-    dt, loss, kern, comm = run(args, args.dtype, rank, world, device, timing=not args.no_kernel_timing)
+    dt, loss, kern, comm = run(args, args.dtype, rank, world, device, timing=not args.no_kernel_timing, dist_on=dist_on)
     images = args.batch * world * args.steps
     value = images / dt
     scale = (args.size / 256.0) ** 2 * (args.conv_dim / 64.0) ** 2
@@ -234,7 +237,7 @@ def main():
                 out['roofline_wgrad']['algorithmic_tflops'] = round(alg, 2)
                 out['roofline_wgrad']['algorithmic_speedup'] = round(flops / xflops, 4)
     # further dtypes: by default on the single-GPU run only (the N-GPU scaling runs measure the headline dtype and nothing else)
-    also = args.also if args.also is not None else ('bf16x3,bf16' if world == 1 else '')
+    also = args.also if args.also is not None else ('bf16x3,bf16' if not dist_on else '')
     for other in [d for d in also.split(',') if d and d != args.dtype]:
         dt2, loss2, k2, _ = run(args, other, rank, world, device, timing=not args.no_kernel_timing)
         v2 = images / dt2
@@ -250,7 +253,7 @@ def main():
         if sec > 0:
             o['conv3x3_wgrad_tflops'] = round(flops / sec / 1e12, 1)
         out.setdefault('also', []).append(o)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not dist_on and not args.no_cpu_baseline:
         from oracle import torch_cpu as TC                       # the checker timed as the reported CPU baseline
         xb = x_cpu = None
         import continual_learning_amd as C
@@ -265,7 +268,7 @@ def main():
                                'kind': 'port', 'sample': cb['sample']}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -38,6 +38,27 @@ def test_bench_two_ranks_on_one_gpu():
     assert c['cu_reserve'] == 0                                                               # gloo holds no CUs
 
 
+def test_bench_rccl_code_path_with_one_rank():
+    """The N > 1 code path of bench.py with the REAL backend -- ddp.init_rccl (channel cap in the environment), RCCL
+    communicator, per-stage all-reduces on the side stream, exposed-communication timing, the `comm` record -- rehearsed
+    with the one rank a one-GPU box allows (CLAMD_BENCH_FORCE_DIST)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CLAMD_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('NCCL_MAX_NCHANNELS', None); env.pop('NCCL_MIN_NCHANNELS', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
+           '--size', '128', '--batch', '4']
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    c = d['comm']
+    assert c['backend'] == 'nccl' and c['rccl_ranks'] == 1 and c['NCCL_MAX_NCHANNELS'] == '8' and c['NCCL_MIN_NCHANNELS'] == '4'
+    assert c['collectives_per_step'] >= 1 and c['exposed_comm_ms_per_step'] >= 0.0 and c['cu_reserve'] == 0
+    assert 'roofline' in d and d['n_gpus'] == 1
+
+
 @pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
 def test_step_survives_stolen_cus(dtype):
     """SURVEY.md §8e ('cap RCCL channels/CUs'), rehearsed on one GPU: a dummy kernel holds 8 CUs for the whole measurement,
