@@ -14,10 +14,14 @@ import torch
 import torch.distributed as dist
 
 # RCCL runs one workgroup per channel and a channel workgroup keeps its CU for the whole collective.  The MFMA kernels of
-# this library want a whole CU per workgroup, so the channel count is capped and exactly that many CUs are left out of
-# every grid that is sized to the chip (clamd_tuning::cu_reserve): a collective in flight then costs cu_reserve/256 of the
-# convolution throughput instead of a second round of workgroups.  8 channels move the 124 MB of fp32 gradients of a step
-# in a few ms over xGMI -- far inside the >= 16 ms (fp32) / 4.5 ms (bf16) backward pass they are overlapped with.
+# this library want a whole CU per workgroup, so the channel count is capped: at most 8 CUs are ever taken away, and 8
+# channels move the 124 MB of fp32 gradients of a step in a few ms over xGMI -- far inside the >= 16 ms (fp32) / 4.5 ms
+# (bf16) backward pass they are overlapped with.  Optionally exactly that many CUs can be left out of every grid that is
+# sized to the chip (clamd_tuning::cu_reserve, GradSync(cu_reserve=...) or CLAMD_CU_RESERVE): measured on one GPU with 8 CUs
+# held by a dummy kernel for the WHOLE step (tools/cu_steal.py), the reserve turns 1.69x (fp32) / 1.36x (bf16) into 1.18x /
+# 1.12x -- but it costs those 1.18x / 1.12x ALSO while no collective is in flight (the deep layers have 256-512 equal work
+# items: 248 CUs need an extra round).  It pays when collectives are resident for more than ~26 % (fp32) / ~32 % (bf16) of
+# the step; the estimate for this model is ~10 % / ~34 %, so the default is no reserve.
 RCCL_MAX_CHANNELS = 8
 
 
@@ -51,10 +55,9 @@ class GradSync:
         model.grad_sync = self
         # RCCL's channel workgroups hold CUs for the duration of a collective, and our MFMA kernels need a whole CU per
         # workgroup.  Nothing process-wide is touched: the reserve below is a field of THIS model's tuning (passed per call).
-        # grids sized to the chip (persistent conv kernel, split-K weight gradients) leave the CUs of the RCCL channels free
+        # optional: grids sized to the chip leave CUs free for the RCCL channels (see the break-even above)
         if cu_reserve is None:
-            nccl = dist.get_backend(process_group) == 'nccl' and self.world > 1
-            cu_reserve = int(os.environ.get('NCCL_MAX_NCHANNELS', '0') or 0) if nccl else 0
+            cu_reserve = int(os.environ.get('CLAMD_CU_RESERVE', '0') or 0)
         model.tuning.cu_reserve = max(0, min(128, int(cu_reserve)))
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world

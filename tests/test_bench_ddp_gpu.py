@@ -62,11 +62,11 @@ def test_bench_rccl_code_path_with_one_rank():
 @pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
 def test_step_survives_stolen_cus(dtype):
     """SURVEY.md §8e ('cap RCCL channels/CUs'), rehearsed on one GPU: a dummy kernel holds 8 CUs for the whole measurement,
-    as 8 RCCL channel workgroups would during a collective.  With clamd_tuning::cu_reserve = 8 (what ddp.GradSync sets from
-    NCCL_MAX_NCHANNELS) the grids sized to the chip fit beside the held CUs: measured 1.11x (bf16) / 1.22x (fp32) of the
-    undisturbed step with the CUs held for the WHOLE step, against 1.37x / 1.72x without the reserve.  (The remainder is
-    quantisation: the deep layers have 256-512 equal work items, which take an extra round on 248 CUs whatever the
-    schedule.  Real collectives are in flight for 10-30 % of a step)"""
+    as 8 RCCL channel workgroups would during a collective.  With clamd_tuning::cu_reserve = 8 the grids sized to the chip fit
+    beside the held CUs: measured 1.12x (bf16) / 1.18x (fp32) of the undisturbed step with the CUs held for the WHOLE step,
+    against 1.36x / 1.69x with the default grids.  (The remainder is quantisation: the deep layers have 256-512 equal work
+    items, which take an extra round on 248 CUs whatever the schedule; for the same reason the reserve is opt-in -- it
+    costs its 1.12-1.18x also while nothing is held.  DESIGN.md §5 has the break-even.)"""
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import cu_steal
     r = cu_steal.measure(dtype, held=8, steps=5)

@@ -21,21 +21,23 @@ import torch  # noqa: E402
 import continual_learning_amd as C  # noqa: E402
 
 
-def measure(dtype='bf16', held=8, steps=6, size=256, batch=16, conv_dim=64, nc=21):
+def measure(dtype='bf16', held=8, steps=6, size=256, batch=16, conv_dim=64, nc=21, extra=None):
     dev = torch.device('cuda', 0)
     lib = C._lib.load()
     x = torch.from_numpy(C.synth.images(1234, batch, 3, size, size)).to(dev)
     y = torch.from_numpy(C.synth.labels(1234, batch, size, size, nc)).to(dev)
     side = torch.cuda.Stream()
     out = {}
-    for name, hold, reserve in (('base', 0, 0), ('stolen', held, 0), ('reserved', held, held)):
+    variants = [('base', 0, {}), ('stolen', held, {}), ('reserved', held, dict(cu_reserve=held)),
+                ('pertile', held, dict(wino_persist=0)), ('pertile_base', 0, dict(wino_persist=0))]
+    variants += extra or []
+    for name, hold, knobs in variants:
         torch.manual_seed(0)
         model = C.UNet(nc, 3, conv_dim, compute_dtype=dtype).to(dev).train()
         opt = C.FusedAdam(model.parameters(), lr=1e-4, betas=[0.5, 0.99])
         crit = C.CrossEntropyLoss()
-        if reserve:
-            model.tuning.cu_reserve = reserve
-            model.tuning.wino_persist = 0
+        for k_, v_ in knobs.items():
+            setattr(model.tuning, k_, v_)
 
         def step():
             o = model(x); opt.zero_grad(); l = crit(o, y); l.backward(); opt.step()
@@ -60,10 +62,15 @@ def measure(dtype='bf16', held=8, steps=6, size=256, batch=16, conv_dim=64, nc=2
     out = {k: round(v, 3) for k, v in out.items()}
     out.update(dtype=dtype, held_cus=held, steps=steps, workload=f'UNet({nc},3,{conv_dim}) {size}x{size} bs{batch}',
                stolen_over_base=round(out['stolen'] / out['base'], 4), reserved_over_base=round(out['reserved'] / out['base'], 4),
+               pertile_over_base=round(out['pertile'] / out['base'], 4),
                proportional_share=round(256 / (256 - held), 4), unit='ms per train step')
     return out
 
 
 if __name__ == '__main__':
     a = sys.argv[1:]
-    print(json.dumps(measure(a[0] if a else 'bf16', int(a[1]) if len(a) > 1 else 8, int(a[2]) if len(a) > 2 else 6)))
+    dt = a[0] if a else 'bf16'
+    held = int(a[1]) if len(a) > 1 else 8
+    extra = [('nopws', held, dict(igemm_pws=0)), ('nopws_base', 0, dict(igemm_pws=0)), ('wgrad448', held, dict(wgrad_blocks=448 * 2 if False else 512)),
+             ] if dt != 'fp32' else []
+    print(json.dumps(measure(dt, held, int(a[2]) if len(a) > 2 else 6, extra=extra)))
