@@ -28,7 +28,7 @@ int clamd_check_tuning(const clamd_tuning* t) {
     if (t->igemm_variant < 0 || t->igemm_variant > 2) return clamd_fail("tuning: igemm_variant 0..2 (3..6 are timing ablations of the diagnostic build)");
 #endif
     if (t->wgrad_dma < 0 || t->wgrad_dma > 2) return clamd_fail("tuning: wgrad_dma 0..2");
-    if (t->wgrad_blocks < 1 || t->wgrad_blocks > 512) return clamd_fail("tuning: wgrad_blocks 1..512");
+    if (t->wgrad_blocks < 1 || t->wgrad_blocks > 1024) return clamd_fail("tuning: wgrad_blocks 1..1024");
     if (t->wino_band < 0 || t->wino_band > 32) return clamd_fail("tuning: wino_band 0..32");
     if (t->wino_mt < 0 || t->wino_mt > 2) return clamd_fail("tuning: wino_mt 0..2");
     if (t->bn_reduce_blocks < 0 || t->bn_reduce_blocks > 65535) return clamd_fail("tuning: bn_reduce_blocks 0..65535");

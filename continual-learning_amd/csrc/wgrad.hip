@@ -531,7 +531,7 @@ size_t clamd_wgrad_workspace_bytes(int mode, int B, int H, int W, int Rp, int Cp
     // upper bound used by callers to size the slab buffer: nsplit is capped at 512 blocks total (see below)
     const int NT = mode == WG_CONV3 ? 9 : (mode == WG_UP2 ? 4 : 1);
     const int rt = (Rp + 63) / 64, ct = (Cp + 63) / 64;
-    int nsplit = 512 / (rt * ct);      // upper bound over every value the tuning knob may take
+    int nsplit = 1024 / (rt * ct);     // upper bound over every value the tuning knob may take
     if (nsplit < 1) nsplit = 1;
     (void)B; (void)H; (void)W; (void)dtype;
     return (size_t)nsplit * NT * Rp * Cp * sizeof(float);

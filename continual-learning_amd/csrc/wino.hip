@@ -794,7 +794,7 @@ int clamd_debug_ww_diag(unsigned long long* out4, int reset) {
 #endif
 
 size_t clamd_wgrad_winograd_workspace_bytes(int Rp, int Cp) {
-    int nsplit = clamd_num_cus() / (((Rp + 63) / 64) * ((Cp + 63) / 64));
+    int nsplit = 512 / (((Rp + 63) / 64) * ((Cp + 63) / 64));      // upper bound over every value of wgrad_blocks (<= 1024)
     if (nsplit < 1) nsplit = 1;
     return (size_t)nsplit * 16 * Rp * Cp * sizeof(float);
 }
@@ -810,7 +810,10 @@ int clamd_wgrad_winograd(const float* gz, int gz_ldc, const float* x, int x_ldc,
     if ((long long)H * W * gz_ldc * 4 >= (1ll << 30) || (long long)H * W * x_ldc * 4 >= (1ll << 30)) return clamd_fail("wgrad_winograd: one image exceeds 2^30 bytes");
     const int rt = (Rp + 63) / 64, ct = (Cp + 63) / 64;
     const int ntiles = ((W + 2 * WW_TX - 1) / (2 * WW_TX)) * ((H + 2 * WW_TY - 1) / (2 * WW_TY)) * B;
-    int nsplit = clamd_usable_cus(clamd_tune(tune)) / (rt * ct);          // one workgroup per CU the grid may occupy
+    // one workgroup per CU the grid may occupy by default (wgrad_blocks = 512 counts two per CU, as for the direct kernels);
+    // a larger target trades split-K slab traffic for smaller work items (robust when RCCL channels hold CUs)
+    const clamd_tuning& tn = clamd_tune(tune);
+    int nsplit = (int)((long long)(tn.wgrad_blocks / 2) * clamd_usable_cus(tn) / clamd_num_cus()) / (rt * ct);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > ntiles) nsplit = ntiles;
     const int per = (ntiles + nsplit - 1) / nsplit;

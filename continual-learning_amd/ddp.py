@@ -55,6 +55,12 @@ class GradSync:
         model.grad_sync = self
         # RCCL's channel workgroups hold CUs for the duration of a collective, and our MFMA kernels need a whole CU per
         # workgroup.  Nothing process-wide is touched: the reserve below is a field of THIS model's tuning (passed per call).
+        # More than one rank: one workgroup per Winograd tile instead of the persistent grid.  A statically strided persistent
+        # grid runs two full rounds when RCCL holds a few CUs, while the hardware dispatcher spreads 4096 tile workgroups over
+        # whatever is free (held-CU rehearsal, fp32: 1.41x instead of 1.69x while 8 CUs are held, +1 % otherwise).  A field of
+        # THIS model's tuning; one rank keeps the persistent grid (bit-identical to the plain step).
+        if self.world > 1:
+            model.tuning.wino_persist = 0
         # optional: grids sized to the chip leave CUs free for the RCCL channels (see the break-even above)
         if cu_reserve is None:
             cu_reserve = int(os.environ.get('CLAMD_CU_RESERVE', '0') or 0)

@@ -49,7 +49,7 @@ int clamd_bn_bwd_nsums(void);
  *   igemm_variant  0|1|2   baseline kernel prefetch variants
  *   pws_wres       0|1     persistent kernel: filter slab kept in LDS across tiles when a tile has two K-steps
  *   wgrad_ws 0|1, wgrad_dma 0|1|2 (LDS-DMA staging: never | heuristic | always), wgrad_xcd 0|1,
- *   wgrad_blocks 1..512 (split-K target), wgrad_tw16 0|1
+ *   wgrad_blocks 1..1024 (split-K target in workgroups on a whole chip, two per CU = 512 by default), wgrad_tw16 0|1
  *   wino_band      0 (per-launch choice) | 1..32 output-channel slabs per band of the Winograd block order
  *   wino_persist   0|1     one workgroup per tile | persistent tile loop
  *   wino_mt        0|1|2   tile height: per-launch choice | 8 | 16 pixels

@@ -71,6 +71,6 @@ if __name__ == '__main__':
     a = sys.argv[1:]
     dt = a[0] if a else 'bf16'
     held = int(a[1]) if len(a) > 1 else 8
-    extra = [('nopws', held, dict(igemm_pws=0)), ('nopws_base', 0, dict(igemm_pws=0)), ('wgrad448', held, dict(wgrad_blocks=448 * 2 if False else 512)),
-             ] if dt != 'fp32' else []
+    extra = [('fine', held, dict(wino_persist=0, wgrad_blocks=896)), ('fine_base', 0, dict(wino_persist=0, wgrad_blocks=896)),
+             ('fine2', held, dict(wino_persist=0, wgrad_blocks=1024)), ('fine2_base', 0, dict(wino_persist=0, wgrad_blocks=1024))]
     print(json.dumps(measure(dt, held, int(a[2]) if len(a) > 2 else 6, extra=extra)))
