@@ -28,17 +28,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _train(model_dtype, shard, ddp):
-    """K train steps (trainer.py:172-176 order) on shard `shard`; returns (losses, flat parameter vector)."""
+def _train(model_dtype, shard, ddp, per_tile=False):
+    """K train steps (trainer.py:172-176 order) on shard `shard`; returns (losses, flat parameter vector).  per_tile: the
+    Winograd grid GradSync selects when there is more than one rank (one workgroup per tile: other partial rows of the
+    BatchNorm statistics than the persistent grid -- each bit-reproducible, not bit-identical to each other)."""
     import continual_learning_amd as C
     dev = torch.device('cuda', 0)
     torch.manual_seed(7)
     model = C.UNet(CFG['num_classes'], 3, CFG['conv_dim'], compute_dtype=model_dtype).to(dev).train()
     opt = C.FusedAdam(model.parameters(), lr=1e-3, betas=[0.5, 0.99])
     crit = C.CrossEntropyLoss()
+    if per_tile:
+        model.tuning.wino_persist = 0
     if ddp:
         C.ddp.broadcast_parameters(model)
         C.ddp.GradSync(model, opt, min_bucket_bytes=16 << 10)      # small buckets: several collectives per backward
+        assert model.tuning.wino_persist == (1 if dist.get_world_size() == 1 else 0)
     b, s = CFG['batch'], CFG['size']
     x = torch.from_numpy(C.synth.images(99, b, 3, s, s, first_image=shard * b)).to(dev)
     y = torch.from_numpy(C.synth.labels(99, b, s, s, CFG['num_classes'], first_image=shard * b)).to(dev)
@@ -86,7 +91,7 @@ def _run_world2(dtype, same_shard):
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_ddp_identical_shards_reproduce_single_process(dtype):
-    ref_losses, ref_flat, ref_grad = _train(dtype, 0, ddp=False)
+    ref_losses, ref_flat, ref_grad = _train(dtype, 0, ddp=False, per_tile=True)     # the grid the two-rank runs use
     for rank, losses, flat, grad0 in _run_world2(dtype, same_shard=True):
         g = torch.from_numpy(grad0)
         assert torch.equal(g, 2 * ref_grad), f'rank {rank}: summed gradient is not exactly 2x the local gradient ' \
