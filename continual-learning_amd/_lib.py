@@ -78,6 +78,8 @@ SIGNATURES = {
     'clamd_sizeof_wino_pack_job': (_I, []),
     'clamd_wino_pack': (_I, [_P, _I, _I, _P]),
     'clamd_wgrad_winograd_workspace_bytes': (_SZ, [_I, _I]),
+    'clamd_wgrad_winograd24_workspace_bytes': (_SZ, [_I, _I]),
+    'clamd_wgrad_winograd24': (_I, [_P, _I, _P, _I, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_wgrad_winograd': (_I, [_P, _I, _P, _I, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_conv3x3_winograd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_wino24_pack': (_I, [_P, _I, _I, _P]),

@@ -29,6 +29,10 @@ WINOGRAD = True
 # ... and, where the image width is a multiple of 4, by the hybrid F(2x4,3x3) (csrc/wino24.hip): 3 instead of 4 multiply-adds
 # per output (1.17x faster launches, error vs fp64 1e-6).  False = F(2x2,3x3) everywhere.
 WINOGRAD24 = True
+# ... and the weight gradient too (csrc/wino24_wgrad.hip) where it measures faster: 'auto' = images of at least 64x64
+# (tools/wino24_wgrad_ab.py: 1.02-1.04x there, 0.88-1.00x on the deep layers -- both operands are transformed in the loop,
+# 3.5 transform VALU per MFMA, so the 25 % fewer MFMAs buy little); True = everywhere it applies; False = F(2x2,3x3).
+WINOGRAD24_WGRAD = 'auto'
 
 # bench.py sets this to a list to get per-launch HIP-event timings of the MFMA kernels:
 # entries (tag, algorithmic_flops, start_event, end_event, algorithmic_bytes), recorded on the stream the kernel is
@@ -248,6 +252,7 @@ class _Engine:
             # Winograd tiles are 2x2 outputs inside 8x16 / 16x16-pixel workgroup tiles: nothing to gain below 8x8 images
             u.wino = self.wino and not u.im2col and (u.h | u.w_) % 2 == 0 and min(u.h, u.w_) >= 8
             u.w24 = u.wino and bool(WINOGRAD24) and u.w_ % 4 == 0          # forward / data gradient by F(2x4,3x3)
+            u.w24g = u.w24 and (min(u.h, u.w_) >= 64 if WINOGRAD24_WGRAD == 'auto' else bool(WINOGRAD24_WGRAD))   # ... weight gradient
             ntap = 1 if u.im2col else ((24 if u.w24 else 16) if u.wino else 9)   # Winograd: [Cin_p/8][16|24][Cout_p][8] transformed filters
             u.wf = torch.zeros(ntap * u.cout_p * u.cin_p, dtype=T, device=dev)
             u.wd = None if first_of_net else torch.zeros(ntap * u.cin_p * u.cout_p, dtype=T, device=dev)
@@ -336,6 +341,8 @@ class _Engine:
             ws = max(ws, lib.clamd_channel_sum_workspace_bytes(u.cout_p))
             if u.wino:
                 ws = max(ws, lib.clamd_wgrad_winograd_workspace_bytes(u.cout_p, u.cin_p))
+            if u.w24g:
+                ws = max(ws, lib.clamd_wgrad_winograd24_workspace_bytes(u.cout_p, u.cin_p))
         for s in self.stages:
             t = s.get('tail')
             if t is not None:
@@ -474,7 +481,7 @@ class _Engine:
         """Multiply-adds the kernel executes per algorithmic (direct-convolution) multiply-add of unit u."""
         if not u.wino:
             return 1.0
-        return 24.0 / 72.0 if (u.w24 and direction != 'wgrad') else 16.0 / 36.0
+        return 24.0 / 72.0 if (u.w24g if direction == 'wgrad' else u.w24) else 16.0 / 36.0
 
     def executed_flop_deficit(self):
         """Algorithmic minus executed FLOPs of one train step (3x3 convolutions by Winograd), for bench.py."""
@@ -599,7 +606,7 @@ class _Engine:
         _TIMED_UNIT[:] = [u.name + ' wgrad', self.executed_fraction(u, 'wgrad')]
         if u.wino:
             _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
-                   'clamd_wgrad_winograd', ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
+                   'clamd_wgrad_winograd24' if u.w24g else 'clamd_wgrad_winograd', ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
                    g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, tp, s)
         else:
             _timed('wgrad_conv3x3', flops, self._conv_bytes(u),

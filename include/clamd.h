@@ -108,6 +108,12 @@ int clamd_wino24_pack(const void* jobs_dev, int njobs, int total_blocks, void* s
 int clamd_conv3x3_winograd24(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
                              float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
                              const clamd_tuning* tune, void* stream);
+/* Weight gradient of the same convolution by the hybrid F(2x4,3x3) (fp32; H even, W a multiple of 4): 24 instead of 32
+ * (F(2x2)) or 72 (direct) multiply-adds per 8 output pixels; arguments as clamd_wgrad_winograd (wino24_wgrad.hip). */
+size_t clamd_wgrad_winograd24_workspace_bytes(int Rp, int Cp);
+int clamd_wgrad_winograd24(const float* gz, int gz_ldc, const float* x, int x_ldc, float* workspace, size_t ws_bytes, float* out,
+                           int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p,
+                           const clamd_tuning* tune, void* stream);
 /* Weight gradient of the same convolution by Winograd (fp32, H and W even): out [R][C][3][3] = G^T (sum over tiles of
  * (A dY A^T) x (B^T d B)) G; arguments as clamd_wgrad(CLAMD_WGRAD_CONV3, ...) (gz = d loss / d conv output, x = conv input). */
 size_t clamd_wgrad_winograd_workspace_bytes(int Rp, int Cp);

@@ -490,6 +490,20 @@ def test_conv3x3_winograd24_fp32(C, shape):
     assert rel_l2(got_gx[:, [p_ for p_, l in enumerate(pm) if l >= 0]], rgx) < TOL[0]
     pad = [p_ for p_, l in enumerate(pm) if l < 0]
     assert not pad or float(np.abs(got_gx[:, pad]).max()) == 0.0
+    # weight gradient by the same hybrid form (wino24_wgrad.hip): fixed-order split-K, bit-reproducible
+    wsb = lib.load().clamd_wgrad_winograd24_workspace_bytes(cout_p, cin_p)
+    ws = torch.empty(wsb // 4 + 4, device='cuda')
+    c_seg0, c_seg0p = (segs[0][0], segs[0][1]) if len(segs) == 2 else (cin, cin_p)
+    rgw = O.conv3x3_bwd(x, w, gz)[1]
+    for tn in (None, lib.Tuning(wgrad_blocks=64), lib.Tuning(cu_reserve=37), lib.Tuning(wgrad_blocks=1024)):
+        gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
+        gw2 = torch.full((cout, cin, 3, 3), 6.0, device='cuda')
+        for o_ in (gw, gw2):
+            lib.call('clamd_wgrad_winograd24', ptr(gzt), cout_p, ptr(xt), cin_p, ptr(ws), wsb, ptr(o_), B, H, W, cout_p, cin_p, cout, cin,
+                     cout, cout_p, c_seg0, c_seg0p, tn.ref() if tn else None, s)
+        sync()
+        assert torch.equal(gw, gw2)
+        assert rel_l2(gw.cpu().numpy(), rgw) < 2e-5
     for key, val in (('wino_band', 1), ('wino_band', 32), ('wino_persist', 0), ('cu_reserve', 37), ('wino_persist', 1)):
         tn = lib.Tuning(**{key: val})
         y2 = torch.full((B, H, W, cout_p), 7.0, device='cuda')
