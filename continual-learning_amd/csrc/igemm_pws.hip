@@ -106,6 +106,31 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
         // Input chunks are fetched in PAIRS (two back-to-back 64-byte pieces = one full 128-byte line per pixel), see
         // igemm_ws.hip; nk is even, so a pair never straddles two tiles.
         uint4 rinA[NJ], rinB[NJ], rw[NT];
+#ifdef PWS_PROTO_BNLOAD
+        // MEASUREMENT PROTOTYPE (never in the shipped build: -DPWS_PROTO_BNLOAD): the VALU cost of applying the producer's
+        // BatchNorm affine while staging the consumer's input -- per 16-byte piece 8 fma + unpack/pack (bf16) and the
+        // post-affine zero-padding predicate -- with opaque register coefficients (a LOWER bound: the real form also loads 16
+        // per-channel coefficients per K-step).  Results are unchanged (scale 1, shift 0).
+        float proto_sc = 1.f, proto_sh = 0.f;
+        asm volatile("" : "+v"(proto_sc), "+v"(proto_sh));
+        auto proto_affine = [&](const uint4& v, unsigned vo) -> uint4 {
+            if constexpr (sizeof(T) == 2) {
+                const float m = vo != BUF_OOB ? 1.f : 0.f;
+                float f[8] = {__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u),
+                              __uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u)};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] = fmaf(f[i], proto_sc, proto_sh) * m;
+                return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+            } else {
+                const float m = vo != BUF_OOB ? 1.f : 0.f;
+                return make_uint4(__float_as_uint(fmaf(__uint_as_float(v.x), proto_sc, proto_sh) * m), __float_as_uint(fmaf(__uint_as_float(v.y), proto_sc, proto_sh) * m),
+                                  __float_as_uint(fmaf(__uint_as_float(v.z), proto_sc, proto_sh) * m), __float_as_uint(fmaf(__uint_as_float(v.w), proto_sc, proto_sh) * m));
+            }
+        };
+#define PWS_PROTO_AFFINE(v_, vo_) proto_affine(v_, vo_)
+#else
+#define PWS_PROTO_AFFINE(v_, vo_) (v_)
+#endif
 #define PWS_GLOAD_IN2(kp_)                                                                                        \
     do {                                                                                                          \
         const unsigned so_ = (unsigned)(2 * (kp_) * KC * ESZ);                                                    \
@@ -125,7 +150,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                          \
             const int pix_ = slot_pix(j);                                                                         \
             if constexpr (!SPLIT) {                                                                               \
-                sm_[g4 * NPIXP + pix_] = RIN[j];                                                                  \
+                sm_[g4 * NPIXP + pix_] = PWS_PROTO_AFFINE(RIN[j], in_vo[j]);                                      \
             } else {                                                                                              \
                 uint2 hi_, lo_;                                                                                   \
                 split4(RIN[j], hi_, lo_);                                                                         \
@@ -190,6 +215,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
 #undef PWS_STORE
 #undef PWS_STORE_IN
 #undef PWS_STORE_W
+#undef PWS_PROTO_AFFINE
     } else {
         // ------------------------------------------------------------------ consumers: LDS fragments -> MFMA -> epilogue
         int apix[MT];
