@@ -1,4 +1,4 @@
-"""bn_bwd_reduce_kernel: time per launch for several grid caps (clamd_set_tuning 'bn_reduce_blocks'), UNet layer shapes."""
+"""bn_bwd_reduce_kernel (+ its fixed-order finalize): time per launch for several grid caps (clamd_tuning::bn_reduce_blocks), UNet layer shapes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,11 +11,12 @@ lib = C._lib.load(); s = C._lib.stream_ptr(); B = 16
 caps = [0, 256, 512, 1024, 2048]
 for ch, hw in [(64, 256), (128, 128), (256, 64), (512, 32), (1024, 16)]:
     g = torch.randn(B, hw, hw, ch, device='cuda').to(T); y = torch.randn(B, hw, hw, ch, device='cuda').to(T)
-    sums = torch.zeros(lib.clamd_stat_replicas(), 5, ch, device='cuda')
     out = []
     for cap in caps:
-        lib.clamd_set_tuning(b'bn_reduce_blocks', cap)
-        f = lambda: call('clamd_bn_bwd_reduce', ptr(g), ch, None, 0, ptr(y), ch, None, None, ptr(sums), B, hw, hw, ch, dc, s)
+        tn = C._lib.Tuning(bn_reduce_blocks=cap)
+        rows = C._lib.stat_rows(C._lib.OP_BN_BWD_REDUCE, B, hw, hw, 0, ch, dc, tuning=tn)
+        sums = torch.empty(rows, 5, ch, device='cuda')
+        f = lambda: call('clamd_bn_bwd_reduce', ptr(g), ch, None, 0, ptr(y), ch, None, None, ptr(sums), rows, B, hw, hw, ch, dc, tn.ref(), s)
         f(); best = 1e9
         for _ in range(4):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -26,14 +27,14 @@ for ch, hw in [(64, 256), (128, 128), (256, 64), (512, 32), (1024, 16)]:
         out.append(f'{cap}: {best:6.1f}us')
     nb = 2 * g.numel() * g.element_size()
     print(f'{dt} C={ch:5d} @{hw:3d} ({nb / 1e6:6.1f} MB)  ' + '  '.join(out))
-lib.clamd_set_tuning(b'bn_reduce_blocks', 0)
 print('channel_sum:')
 for ch, hw in [(32, 256), (64, 256), (128, 128), (256, 64), (512, 32)]:
     g = torch.randn(B, hw, hw, ch, device='cuda').to(T); o = torch.zeros(ch, device='cuda')
     out = []
-    for cap in [64, 128, 256, 512, 1024, 2048]:
-        lib.clamd_set_tuning(b'chsum_blocks', cap)
-        f = lambda: call('clamd_channel_sum', ptr(g), ch, ptr(o), B * hw * hw, ch, ch, dc, s)
+    csb = lib.clamd_channel_sum_workspace_bytes(ch); cws = torch.empty(csb // 4, device='cuda')
+    for cap in [64, 128, 256, 512, 1024]:
+        tn = C._lib.Tuning(chsum_blocks=cap)
+        f = lambda: call('clamd_channel_sum', ptr(g), ch, ptr(o), B * hw * hw, ch, ch, dc, ptr(cws), csb, tn.ref(), s)
         f(); best = 1e9
         for _ in range(4):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -43,4 +44,3 @@ for ch, hw in [(32, 256), (64, 256), (128, 128), (256, 64), (512, 32)]:
             best = min(best, e0.elapsed_time(e1) / 10 * 1e3)
         out.append(f'{cap}: {best:6.1f}us')
     print(f'{dt} C={ch:5d} @{hw:3d} ({g.numel() * g.element_size() / 1e6:6.1f} MB)  ' + '  '.join(out))
-lib.clamd_set_tuning(b'chsum_blocks', 0)

@@ -6,7 +6,7 @@ import continual_learning_amd as C
 from continual_learning_amd._lib import call, ptr
 dt = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
 variants = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else '0,1,2').split(',')]
-key = (sys.argv[3] if len(sys.argv) > 3 else 'igemm_variant').encode()
+key = sys.argv[3] if len(sys.argv) > 3 else 'igemm_variant'      # a field of clamd_tuning, passed per call
 dc = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[dt]
 T = C.ops.TORCH_DT[dc]
 B, iters, rounds = 16, 10, 5
@@ -21,18 +21,20 @@ for cin, cout, hw in layers:
     wf = torch.zeros(9 * cout * cin, dtype=T, device='cuda')
     bias = torch.zeros(cout, device='cuda')
     tab = C.ops.PackTable(dc); tab.conv3x3(w, wf, None, [(cin, cin)], cout); tab.finalize('cuda').run(dc)
-    y = torch.empty(B, hw, hw, cout, dtype=T, device='cuda'); stats = torch.zeros(16, 2, cout, device='cuda')
+    y = torch.empty(B, hw, hw, cout, dtype=T, device='cuda')
+    tun = {v: C._lib.Tuning(**{key: v}) for v in variants}
+    rows = {v: C._lib.stat_rows(C._lib.OP_CONV3X3, B, hw, hw, cin, cout, dc, tuning=tun[v]) for v in variants}
+    stats = torch.empty(max(rows.values()), 2, cout, device='cuda')
     mf = 1 if 9 * cout > B * hw * hw else 0
     best = {v: 1e9 for v in variants}
     ref = None
     for rd in range(rounds):
         for v in variants:
-            lib.clamd_set_tuning(key, v)
-            call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, B, hw, hw, cin, cout, 1, mf, dc, s)
+            call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, rows[v], B, hw, hw, cin, cout, 1, mf, dc, tun[v].ref(), s)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
-                call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, B, hw, hw, cin, cout, 1, mf, dc, s)
+                call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, rows[v], B, hw, hw, cin, cout, 1, mf, dc, tun[v].ref(), s)
             e1.record(); torch.cuda.synchronize()
             best[v] = min(best[v], e0.elapsed_time(e1) / iters * 1e-3)
             if rd == 0:
@@ -42,4 +44,3 @@ for cin, cout, hw in layers:
     print(f'{cin:5d}->{cout:5d} @{hw:3d}: ' + '  '.join(f'v{v} {best[v]*1e6:7.1f}us {fl/best[v]/1e12:7.1f}TF' for v in variants))
     for v in variants: tot[v][0] += fl; tot[v][1] += best[v]
 print(dt, 'aggregate: ' + '  '.join(f'v{v} {tot[v][0]/tot[v][1]/1e12:.1f} TF/s' for v in variants))
-lib.clamd_set_tuning(key, 0)

@@ -24,15 +24,16 @@ for cin, cout, hw in layers:
     bias = torch.zeros(cout, device='cuda')
     tab = C.ops.PackTable(dc); tab.conv3x3(w, wf, wd, [(cin, cin)], cout); tab.finalize('cuda').run(dc)
     y = torch.empty(B, hw, hw, cout, dtype=T, device='cuda')
-    stats = torch.zeros(16, 2, cout, device='cuda')
+    rows = C._lib.stat_rows(C._lib.OP_CONV3X3, B, hw, hw, cin, cout, dc)
+    stats = torch.empty(rows, 2, cout, device='cuda')
     mf = 1 if 9 * cout > B * hw * hw else 0
     def fwd():
-        call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, B, hw, hw, cin, cout, 1, mf, dc, s)
+        call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, rows, B, hw, hw, cin, cout, 1, mf, dc, None, s)
     wsb = lib.clamd_wgrad_workspace_bytes(0, B, hw, hw, cout, cin, dc)
     ws = torch.empty(wsb // 4 + 4, device='cuda'); gw = torch.empty_like(w)
     g = torch.randn(B, hw, hw, cout, device='cuda').to(T)
     def wgr():
-        call('clamd_wgrad', 0, ptr(g), cout, ptr(x), cin, ptr(ws), wsb, ptr(gw), B, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, dc, s)
+        call('clamd_wgrad', 0, ptr(g), cout, ptr(x), cin, ptr(ws), wsb, ptr(gw), B, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, dc, None, s)
     res = []
     for fn in (fwd, wgr):
         for _ in range(3): fn()

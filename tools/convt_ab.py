@@ -1,5 +1,5 @@
 """Interleaved A/B of the ConvTranspose2d(k2,s2) kernels (forward GEMM + pixel-shuffle store, data gradient) on the
-four UNet decoder shapes.     python tools/convt_ab.py fp32 0,1 <tuning key>"""
+four UNet decoder shapes.     python tools/convt_ab.py fp32 0,1   (the variants are repeat labels: these kernels have no structure knob)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,7 +7,6 @@ import continual_learning_amd as C
 from continual_learning_amd._lib import call, ptr
 dt = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
 variants = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else '0').split(',')]
-key = (sys.argv[3] if len(sys.argv) > 3 else 'igemm_variant').encode()
 dc = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[dt]
 T = C.ops.TORCH_DT[dc]
 B, iters, rounds = 16, 10, 4
@@ -22,11 +21,10 @@ for cin, cout, hw in [(1024, 512, 16), (512, 256, 32), (256, 128, 64), (128, 64,
     y = torch.empty(B, 2 * hw, 2 * hw, cout, dtype=T, device='cuda')
     gx = torch.empty(B, hw, hw, cin, dtype=T, device='cuda')
     def fwd(): call('clamd_convT2x2_fwd', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, B, hw, hw, cin, cout, dc, s)
-    def bwd(): call('clamd_convT2x2_dgrad', ptr(y), cout, ptr(wd), ptr(gx), cin, None, None, B, hw, hw, cin, cout, dc, s)
+    def bwd(): call('clamd_convT2x2_dgrad', ptr(y), cout, ptr(wd), ptr(gx), cin, None, None, 0, B, hw, hw, cin, cout, dc, s)
     best = {(v, n): 1e9 for v in variants for n in 'fb'}
     for rd in range(rounds):
         for v in variants:
-            lib.clamd_set_tuning(key, v)
             for n, f in (('f', fwd), ('b', bwd)):
                 f()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,7 +1,7 @@
 """Interleaved A/B of whole train steps in ONE process: two models that differ in an engine switch.
 
     python tools/step_ab.py bf16 FUSE_BN_SUMS False auto        # module attribute of continual_learning_amd.unet
-    python tools/step_ab.py bf16 tuning:wgrad_dma 0 1           # clamd_set_tuning key (one model, switch per timed block)
+    python tools/step_ab.py bf16 tuning:wgrad_dma 0 1           # field of the model's clamd_tuning (model.tuning), one model per value
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,12 +19,12 @@ runs = []
 tuning = attr.startswith('tuning:')
 lib = C._lib.load()
 for v in vals:
-    if tuning:
-        lib.clamd_set_tuning(attr[7:].encode(), int(v))
-    else:
+    if not tuning:
         setattr(U, attr, v)
     torch.manual_seed(1234)
     m = C.UNet(21, 3, 64, compute_dtype=dtype).to(dev).train()
+    if tuning:
+        setattr(m.tuning, attr[7:], int(v))
     o = C.FusedAdam(m.parameters(), lr=1e-4, betas=[0.5, 0.99])
 
     def step(m=m, o=o):
@@ -35,8 +35,6 @@ for v in vals:
 best = {str(v): 1e9 for v, _ in runs}
 for rd in range(5):
     for v, step in runs:
-        if tuning:
-            lib.clamd_set_tuning(attr[7:].encode(), int(v)); step()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): loss = step()
         torch.cuda.synchronize()

@@ -18,7 +18,7 @@ for cin, cout, hw in [(64, 64, 256), (256, 256, 64), (512, 512, 32), (1024, 1024
     ws = torch.empty(wsb // 4 + 4, device='cuda'); gw = torch.empty(cout, cin, 3, 3, device='cuda')
     s = C._lib.stream_ptr()
     def run():
-        call('clamd_wgrad', 0, ptr(g), cout, ptr(x), cin, ptr(ws), wsb, ptr(gw), B, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, dc, s)
+        call('clamd_wgrad', 0, ptr(g), cout, ptr(x), cin, ptr(ws), wsb, ptr(gw), B, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, dc, None, s)
     for _ in range(300): run()
     torch.cuda.synchronize(); lib.clamd_debug_wg_diag(out, 1)
     run(); torch.cuda.synchronize(); lib.clamd_debug_wg_diag(out, 1)

@@ -11,8 +11,7 @@ layers = [(64, 64, 256), (128, 64, 256), (64, 128, 128), (128, 128, 128), (256, 
 if os.environ.get('CONV_LAYERS'):
     layers = [tuple(int(v) for v in l.split(',')) for l in os.environ['CONV_LAYERS'].split(';')]
 s = C._lib.stream_ptr()
-for kv in filter(None, os.environ.get('TUNING', '').split(',')):        # TUNING=wino_stagger=32,wino_band=0
-    k, v = kv.split('='); C._lib.load().clamd_set_tuning(k.encode(), int(v))
+tn = C._lib.Tuning(**{kv.split('=')[0]: int(kv.split('=')[1]) for kv in filter(None, os.environ.get('TUNING', '').split(','))})   # TUNING=wino_band=4,wino_persist=0
 tot = [0.0, 0.0, 0.0]
 for cin, cout, hw in layers:
     x = torch.randn(B, hw, hw, cin, device='cuda')
@@ -21,9 +20,11 @@ for cin, cout, hw in layers:
     bias = torch.zeros(cout, device='cuda')
     t1 = C.ops.PackTable(0); t1.conv3x3(w, wf, None, [(cin, cin)], cout); t1.finalize('cuda').run(0)
     t2 = C.ops.WinoPackTable(); t2.conv3x3(w, ww, None, [(cin, cin)], cout); t2.finalize('cuda').run()
-    y1 = torch.empty(B, hw, hw, cout, device='cuda'); y2 = torch.empty_like(y1); stats = torch.zeros(16, 2, cout, device='cuda')
-    def direct(): call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y1), cout, ptr(stats), None, None, B, hw, hw, cin, cout, 1, 0, 0, s)
-    def wino(): call('clamd_conv3x3_winograd', ptr(x), cin, ptr(ww), ptr(bias), ptr(y2), cout, ptr(stats), B, hw, hw, cin, cout, 1, s)
+    y1 = torch.empty(B, hw, hw, cout, device='cuda'); y2 = torch.empty_like(y1)
+    r1 = C._lib.stat_rows(C._lib.OP_CONV3X3, B, hw, hw, cin, cout, 0, tuning=tn); r2 = C._lib.stat_rows(C._lib.OP_CONV3X3_WINOGRAD, B, hw, hw, cin, cout, 0, tuning=tn)
+    stats = torch.empty(max(r1, r2), 2, cout, device='cuda')
+    def direct(): call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y1), cout, ptr(stats), None, None, r1, B, hw, hw, cin, cout, 1, 0, 0, tn.ref(), s)
+    def wino(): call('clamd_conv3x3_winograd', ptr(x), cin, ptr(ww), ptr(bias), ptr(y2), cout, ptr(stats), r2, B, hw, hw, cin, cout, 1, tn.ref(), s)
     best = [1e9, 1e9]
     for rd in range(rounds):
         for i, f in enumerate((direct, wino)):

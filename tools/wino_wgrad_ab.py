@@ -13,8 +13,8 @@ for cin, cout, hw in layers:
     x = torch.randn(B, hw, hw, cin, device='cuda'); g = torch.randn(B, hw, hw, cout, device='cuda')
     wsb = max(lib.clamd_wgrad_workspace_bytes(0, B, hw, hw, cout, cin, 0), lib.clamd_wgrad_winograd_workspace_bytes(cout, cin))
     ws = torch.empty(wsb // 4 + 4, device='cuda'); g1 = torch.empty(cout, cin, 3, 3, device='cuda'); g2 = torch.empty_like(g1)
-    def direct(): call('clamd_wgrad', 0, ptr(g), cout, ptr(x), cin, ptr(ws), wsb, ptr(g1), B, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, 0, s)
-    def wino(): call('clamd_wgrad_winograd', ptr(g), cout, ptr(x), cin, ptr(ws), wsb, ptr(g2), B, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, s)
+    def direct(): call('clamd_wgrad', 0, ptr(g), cout, ptr(x), cin, ptr(ws), wsb, ptr(g1), B, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, 0, None, s)
+    def wino(): call('clamd_wgrad_winograd', ptr(g), cout, ptr(x), cin, ptr(ws), wsb, ptr(g2), B, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, None, s)
     best = [1e9, 1e9]
     for rd in range(rounds):
         for i, f in enumerate((direct, wino)):

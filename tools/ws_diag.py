@@ -11,8 +11,7 @@ pws = len(sys.argv) > 3 and sys.argv[3] == 'pws'      # persistent kernel: consu
 dc = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[dt]
 T = C.ops.TORCH_DT[dc]
 B = 16
-C._lib.load().clamd_set_tuning(b'igemm_ws', mode)
-C._lib.load().clamd_set_tuning(b'igemm_pws', 2 if pws else 0)
+tn = C._lib.Tuning(igemm_ws=mode, igemm_pws=2 if pws else 0)
 diag = lib.clamd_debug_pws_diag if pws else lib.clamd_debug_ws_diag
 out = (ctypes.c_ulonglong * 8)()
 for cin, cout, hw in [(64, 64, 256), (128, 64, 256), (128, 128, 128), (256, 256, 64), (1024, 512, 32)]:
@@ -20,12 +19,13 @@ for cin, cout, hw in [(64, 64, 256), (128, 64, 256), (128, 128, 128), (256, 256,
     w = torch.randn(cout, cin, 3, 3, device='cuda') / (3 * cin ** 0.5)
     wf = torch.zeros(9 * cout * cin, dtype=T, device='cuda'); bias = torch.zeros(cout, device='cuda')
     tab = C.ops.PackTable(dc); tab.conv3x3(w, wf, None, [(cin, cin)], cout); tab.finalize('cuda').run(dc)
-    y = torch.empty(B, hw, hw, cout, dtype=T, device='cuda'); stats = torch.zeros(16, 2, cout, device='cuda')
+    y = torch.empty(B, hw, hw, cout, dtype=T, device='cuda')
+    rows = C._lib.stat_rows(C._lib.OP_CONV3X3, B, hw, hw, cin, cout, dc, tuning=tn); stats = torch.empty(rows, 2, cout, device='cuda')
     s = C._lib.stream_ptr()
     for _ in range(2):
-        call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, B, hw, hw, cin, cout, 1, 0, dc, s)
+        call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, rows, B, hw, hw, cin, cout, 1, 0, dc, tn.ref(), s)
     torch.cuda.synchronize(); diag(out, 1)
-    call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, B, hw, hw, cin, cout, 1, 0, dc, s)
+    call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, rows, B, hw, hw, cin, cout, 1, 0, dc, tn.ref(), s)
     torch.cuda.synchronize(); diag(out, 1)
     v = list(out); nb = max(v[7], 1)
     if pws:

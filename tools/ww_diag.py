@@ -10,7 +10,7 @@ for cin, cout, hw in [(64, 64, 256), (512, 512, 32)]:
     x = torch.randn(16, hw, hw, cin, device='cuda'); g = torch.randn(16, hw, hw, cout, device='cuda')
     wsb = l.clamd_wgrad_winograd_workspace_bytes(cout, cin)
     ws = torch.empty(wsb // 4 + 4, device='cuda'); gw = torch.empty(cout, cin, 3, 3, device='cuda')
-    def run(): call('clamd_wgrad_winograd', ptr(g), cout, ptr(x), cin, ptr(ws), wsb, ptr(gw), 16, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, s)
+    def run(): call('clamd_wgrad_winograd', ptr(g), cout, ptr(x), cin, ptr(ws), wsb, ptr(gw), 16, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, None, s)
     for _ in range(200): run()
     torch.cuda.synchronize(); lib.clamd_debug_ww_diag(out, 1)
     run(); torch.cuda.synchronize(); lib.clamd_debug_ww_diag(out, 1)
