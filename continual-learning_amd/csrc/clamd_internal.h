@@ -21,6 +21,16 @@ inline const clamd_tuning& clamd_tune(const clamd_tuning* t) { return t ? *t : c
 // 0 or a negative status with the reason recorded
 int clamd_check_tuning(const clamd_tuning* t);
 
+// bf16x3 (CLAMD_SPLIT) activations live in hi/lo planes per 16-channel group (common.hip.h, Vec8<split_t>): the kernels
+// find a group from the address bits, so a tensor (or a channel slice of one) must start on 64 bytes and have a pitch
+// that is a whole number of groups.  0, or a negative status with the reason recorded; other dtypes always pass.
+inline int clamd_check_split(int dtype, const void* p, int ldc) {
+    if (dtype != CLAMD_SPLIT || !p) return 0;
+    if (((unsigned long long)p & 63ull) || ldc % 16)
+        return clamd_fail("bf16x3 tensors need a 64-byte aligned base and a pitch that is a multiple of 16 channels");
+    return 0;
+}
+
 // CU count of the current device (a device fact, not state: every MI355X answers 256).
 inline int clamd_query_cus() {
     int dev = 0, n = 0;

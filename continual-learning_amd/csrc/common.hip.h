@@ -11,9 +11,12 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 struct bf16_t { uint16_t v; };   // storage type tag for bf16 tensors
-// "split" compute type: tensors are STORED as fp32; the MFMA kernels split every operand x into bf16 hi = rne(x) and
-// lo = rne(x - hi) at LDS-staging time and accumulate hi*hi + hi*lo + lo*hi in fp32 with three bf16 MFMAs
-// (relative product error ~2^-17 instead of bf16's 2^-9, at 3/16 of the fp32-MFMA cost).
+// "split" compute type (bf16x3): every value x is STORED as the bf16 pair hi = rne(x), lo = rne(x - hi) -- 4 bytes per
+// element, laid out in hi/lo planes per 16-channel group (see Vec8<split_t>) so that the MFMA kernels stage activations
+// with plain 16-byte copies, as they do the packed weights -- and multiplied as hi*hi + hi*lo + lo*hi in fp32 with three
+// bf16 MFMAs (relative product error ~2^-17 instead of bf16's 2^-9, at 3/16 of the fp32-MFMA cost).  The producer of a
+// tensor splits it ONCE in its epilogue; round 1 stored fp32 and re-split in every consumer's staging loop (3-10x per
+// element), which cost the convolutions 10-16% (tools ablation).
 struct split_t { float v; };
 
 // ---- dtype traits -------------------------------------------------------------------------------
@@ -77,20 +80,37 @@ template <> struct Vec8<bf16_t> {
     }
 };
 
+// split_t tensors: every 16-channel group of a pixel is 64 bytes, [16 x bf16 hi][16 x bf16 lo] (the element index
+// (pixel * ldc + c) keeps its fp32 meaning, so ldc, offsets and sizes are those of an fp32 tensor).  Needs a 64-byte
+// aligned base and ldc % 16 == 0 (channel counts are padded to 32).  The 8 channels c..c+7 (c % 8 == 0) of element
+// address a live at hi = (a & ~63) + ((a >> 1) & 16), lo = hi + 32.
+__device__ inline void split8(const float (&v)[8], uint4& hi, uint4& lo) {
+    hi = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+    lo.x = pack2bf(v[0] - __uint_as_float(hi.x << 16), v[1] - __uint_as_float(hi.x & 0xffff0000u));
+    lo.y = pack2bf(v[2] - __uint_as_float(hi.y << 16), v[3] - __uint_as_float(hi.y & 0xffff0000u));
+    lo.z = pack2bf(v[4] - __uint_as_float(hi.z << 16), v[5] - __uint_as_float(hi.z & 0xffff0000u));
+    lo.w = pack2bf(v[6] - __uint_as_float(hi.w << 16), v[7] - __uint_as_float(hi.w & 0xffff0000u));
+}
 template <> struct Vec8<split_t> {
-    __device__ static inline void load(const split_t* p, float (&v)[8]) { Vec8<float>::load(reinterpret_cast<const float*>(p), v); }
-    __device__ static inline void store(split_t* p, const float (&v)[8]) { Vec8<float>::store(reinterpret_cast<float*>(p), v); }
+    __device__ static inline void load(const split_t* p, float (&v)[8]) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        const char* b = reinterpret_cast<const char*>((a & ~(uintptr_t)63) + ((a >> 1) & 16));
+        const uint4 h = *reinterpret_cast<const uint4*>(b), l = *reinterpret_cast<const uint4*>(b + 32);
+        v[0] = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16); v[1] = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
+        v[2] = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16); v[3] = __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
+        v[4] = __uint_as_float(h.z << 16) + __uint_as_float(l.z << 16); v[5] = __uint_as_float(h.z & 0xffff0000u) + __uint_as_float(l.z & 0xffff0000u);
+        v[6] = __uint_as_float(h.w << 16) + __uint_as_float(l.w << 16); v[7] = __uint_as_float(h.w & 0xffff0000u) + __uint_as_float(l.w & 0xffff0000u);
+    }
+    __device__ static inline void store(split_t* p, const float (&v)[8]) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        char* b = reinterpret_cast<char*>((a & ~(uintptr_t)63) + ((a >> 1) & 16));
+        uint4 h, l;
+        split8(v, h, l);
+        *reinterpret_cast<uint4*>(b) = h;
+        *reinterpret_cast<uint4*>(b + 32) = l;
+    }
 };
 
-// fp32 x4 -> bf16 hi x4 and bf16 lo x4 (lo = rne(x - float(hi)))
-__device__ inline void split4(const uint4& x, uint2& hi, uint2& lo) {
-    const float f0 = __uint_as_float(x.x), f1 = __uint_as_float(x.y), f2 = __uint_as_float(x.z), f3 = __uint_as_float(x.w);
-    const uint16_t h0 = f2bf(f0), h1 = f2bf(f1), h2 = f2bf(f2), h3 = f2bf(f3);
-    hi.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
-    hi.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
-    lo.x = pack2bf(f0 - bf2f(h0), f1 - bf2f(h1));
-    lo.y = pack2bf(f2 - bf2f(h2), f3 - bf2f(h3));
-}
 __device__ inline void mma_bf16(const uint4& a, const uint4& b, f32x16& acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
@@ -101,6 +121,19 @@ template <> __device__ inline float ld1<bf16_t>(const bf16_t* p) { return bf2f(p
 template <typename T> __device__ inline void st1(T* p, float v);
 template <> __device__ inline void st1<float>(float* p, float v) { *p = v; }
 template <> __device__ inline void st1<bf16_t>(bf16_t* p, float v) { p->v = f2bf(v); }
+// single element of a split_t tensor: channel k = (a / 4) % 16 of its 64-byte group -> hi at 2k, lo at 32 + 2k
+template <> __device__ inline float ld1<split_t>(const split_t* p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>((a & ~(uintptr_t)63) + ((a & 63) >> 1));
+    return bf2f(b[0]) + bf2f(b[16]);
+}
+template <> __device__ inline void st1<split_t>(split_t* p, float v) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    uint16_t* b = reinterpret_cast<uint16_t*>((a & ~(uintptr_t)63) + ((a & 63) >> 1));
+    const uint16_t h = f2bf(v);
+    b[0] = h;
+    b[16] = f2bf(v - bf2f(h));
+}
 
 // ---- MFMA step on one 16-byte A group and one 16-byte B group ------------------------------------
 // bf16: 8 k-values per lane -> one 32x32x16 MFMA.
@@ -152,6 +185,14 @@ __device__ inline void buf_st16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsign
 template <typename T> __device__ inline void buf_st8(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const float (&v)[8]) {
     if constexpr (sizeof(T) == 2) {
         buf_st16(rs, voff, soff, make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])));
+    } else if constexpr (__is_same(T, split_t)) {
+        // hi/lo planes (Vec8<split_t>); soff is a whole number of pixels, so the group remap applies to voff alone,
+        // and BUF_OOB stays out of range
+        const unsigned vs = (voff & ~63u) + ((voff >> 1) & 16u);
+        uint4 h, l;
+        split8(v, h, l);
+        buf_st16(rs, vs, soff, h);
+        buf_st16(rs, vs, soff + 32, l);
     } else {
         buf_st16(rs, voff, soff, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
         buf_st16(rs, voff, soff + 16, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])));

@@ -458,13 +458,17 @@ int clamd_bn_apply(const void* y, int y_ldc, const float* scale, const float* sh
                    void* pooled, int p_ldc, int B, int H, int W, int Cp, int dtype, void* stream) {
     if (!pow2_channels(Cp)) return clamd_fail("bn_apply: physical channels must be a power of two in [32,2048]");
     if (pooled && ((H | W) & 1)) return clamd_fail("bn_apply: pooling needs even H, W");
+    if (int e = clamd_check_split(dtype, y, y_ldc)) return e;
+    if (int e = clamd_check_split(dtype, out, out_ldc)) return e;
+    if (int e = clamd_check_split(dtype, pooled, p_ldc)) return e;
     const long long nitem = (pooled ? (long long)B * (H / 2) * (W / 2) : (long long)B * H * W) * (Cp / 8);
     dim3 g(ew_grid(nitem, 8192)), b(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(T, P) hipLaunchKernelGGL((bn_apply_kernel<T, P>), g, b, 0, s, (const T*)y, y_ldc, scale, shift, \
                                         (T*)out, out_ldc, (T*)pooled, p_ldc, B, H, W, Cp)
     if (dtype == CLAMD_BF16) { if (pooled) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
-    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT) { if (pooled) LAUNCH(float, true); else LAUNCH(float, false); }
+    else if (dtype == CLAMD_F32) { if (pooled) LAUNCH(float, true); else LAUNCH(float, false); }
+    else if (dtype == CLAMD_SPLIT) { if (pooled) LAUNCH(split_t, true); else LAUNCH(split_t, false); }
     else return clamd_fail("bn_apply: bad dtype");
 #undef LAUNCH
     return clamd_check_launch("bn_apply");
@@ -475,6 +479,9 @@ int clamd_bn_bwd_reduce(const void* ga, int ga_ldc, const void* gp, int gp_ldc, 
                         int dtype, const clamd_tuning* tune, void* stream) {
     if (!pow2_channels(Cp)) return clamd_fail("bn_bwd_reduce: physical channels must be a power of two in [32,2048]");
     if (!gp && !ga) return clamd_fail("bn_bwd_reduce: no gradient source");
+    if (int e = clamd_check_split(dtype, ga, ga_ldc)) return e;
+    if (int e = clamd_check_split(dtype, gp, gp_ldc)) return e;
+    if (int e = clamd_check_split(dtype, y, y_ldc)) return e;
     if (int e = clamd_check_tuning(tune)) return e;
     const long long nrows = clamd_bn_bwd_reduce_rows(B, H, W, Cp, gp != nullptr, clamd_tune(tune));
     if (sum_rows != nrows) return clamd_fail("bn_bwd_reduce: sum_rows does not match clamd_stat_rows(CLAMD_OP_BN_BWD_REDUCE, ...)");
@@ -483,7 +490,8 @@ int clamd_bn_bwd_reduce(const void* ga, int ga_ldc, const void* gp, int gp_ldc, 
 #define LAUNCH(T, P) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, P>), g, b, 0, s, (const T*)ga, ga_ldc, \
                                         (const T*)gp, gp_ldc, (const T*)y, y_ldc, scale, shift, sums, B, H, W, Cp)
     if (dtype == CLAMD_BF16) { if (gp) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
-    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT) { if (gp) LAUNCH(float, true); else LAUNCH(float, false); }
+    else if (dtype == CLAMD_F32) { if (gp) LAUNCH(float, true); else LAUNCH(float, false); }
+    else if (dtype == CLAMD_SPLIT) { if (gp) LAUNCH(split_t, true); else LAUNCH(split_t, false); }
     else return clamd_fail("bn_bwd_reduce: bad dtype");
 #undef LAUNCH
     return clamd_check_launch("bn_bwd_reduce");
@@ -503,13 +511,18 @@ int clamd_bn_bwd_apply(const void* ga, int ga_ldc, const void* gp, int gp_ldc, c
                        const float* scale, const float* shift, const float* k012, void* gz, int gz_ldc, int B,
                        int H, int W, int Cp, int dtype, void* stream) {
     if (!pow2_channels(Cp)) return clamd_fail("bn_bwd_apply: physical channels must be a power of two in [32,2048]");
+    if (int e = clamd_check_split(dtype, ga, ga_ldc)) return e;
+    if (int e = clamd_check_split(dtype, gp, gp_ldc)) return e;
+    if (int e = clamd_check_split(dtype, y, y_ldc)) return e;
+    if (int e = clamd_check_split(dtype, gz, gz_ldc)) return e;
     const long long nitem = (gp ? (long long)B * (H / 2) * (W / 2) : (long long)B * H * W) * (Cp / 8);
     dim3 g(ew_grid(nitem, 8192)), b(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(T, P) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, P>), g, b, 0, s, (const T*)ga, ga_ldc, \
                                         (const T*)gp, gp_ldc, (const T*)y, y_ldc, scale, shift, k012, (T*)gz, gz_ldc, B, H, W, Cp)
     if (dtype == CLAMD_BF16) { if (gp) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
-    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT) { if (gp) LAUNCH(float, true); else LAUNCH(float, false); }
+    else if (dtype == CLAMD_F32) { if (gp) LAUNCH(float, true); else LAUNCH(float, false); }
+    else if (dtype == CLAMD_SPLIT) { if (gp) LAUNCH(split_t, true); else LAUNCH(split_t, false); }
     else return clamd_fail("bn_bwd_apply: bad dtype");
 #undef LAUNCH
     return clamd_check_launch("bn_bwd_apply");
@@ -521,6 +534,7 @@ int clamd_channel_sum(const void* g, int ldc, float* out, long long npix, int Cp
                       size_t ws_bytes, const clamd_tuning* tune, void* stream) {
     if (!pow2_channels(Cp)) return clamd_fail("channel_sum: physical channels must be a power of two in [32,2048]");
     if (C > Cp || npix <= 0) return clamd_fail("channel_sum: bad sizes");
+    if (int e = clamd_check_split(dtype, g, ldc)) return e;
     if (int e = clamd_check_tuning(tune)) return e;
     const int rows = 256 / (Cp / 8) > 0 ? 256 / (Cp / 8) : 1;
     long long gb = (npix + rows - 1) / rows;
@@ -532,8 +546,10 @@ int clamd_channel_sum(const void* g, int ldc, float* out, long long npix, int Cp
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CLAMD_BF16)
         hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, gr, b, 0, s, (const bf16_t*)g, ldc, workspace, npix, Cp);
-    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT)
+    else if (dtype == CLAMD_F32)
         hipLaunchKernelGGL(channel_sum_kernel<float>, gr, b, 0, s, (const float*)g, ldc, workspace, npix, Cp);
+    else if (dtype == CLAMD_SPLIT)
+        hipLaunchKernelGGL(channel_sum_kernel<split_t>, gr, b, 0, s, (const split_t*)g, ldc, workspace, npix, Cp);
     else return clamd_fail("channel_sum: bad dtype");
     hipLaunchKernelGGL(channel_sum_final_kernel, dim3(Cp / 8), b, 0, s, workspace, (int)gb, out, Cp, C);
     return clamd_check_launch("channel_sum");
@@ -542,12 +558,15 @@ int clamd_channel_sum(const void* g, int ldc, float* out, long long npix, int Cp
 int clamd_nchw_to_nhwc(const float* src, void* dst, int ldc, int B, int C, int H, int W, int Cp, double mul,
                        int dtype, void* stream) {
     if (Cp % 8 || C > Cp) return clamd_fail("nchw_to_nhwc: bad channel counts");
+    if (dtype == CLAMD_SPLIT && Cp % 16) return clamd_fail("nchw_to_nhwc: bf16x3 needs Cp % 16 == 0");
+    if (int e = clamd_check_split(dtype, dst, ldc)) return e;
     const long long nitem = (long long)B * H * W;
     dim3 g(ew_grid(nitem, 8192)), b(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(T) hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, g, b, 0, s, src, (T*)dst, ldc, B, C, H, W, Cp, (float)mul)
     if (dtype == CLAMD_BF16) LAUNCH(bf16_t);
-    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT) LAUNCH(float);
+    else if (dtype == CLAMD_F32) LAUNCH(float);
+    else if (dtype == CLAMD_SPLIT) LAUNCH(split_t);
     else return clamd_fail("nchw_to_nhwc: bad dtype");
 #undef LAUNCH
     return clamd_check_launch("nchw_to_nhwc");
@@ -555,12 +574,15 @@ int clamd_nchw_to_nhwc(const float* src, void* dst, int ldc, int B, int C, int H
 
 int clamd_nchw_im2col3(const float* src, void* dst, int ldc, int B, int C, int H, int W, int Cp, int dtype, void* stream) {
     if (Cp % 8 || 9 * C > Cp) return clamd_fail("nchw_im2col3: needs 9*C <= Cp, Cp % 8 == 0");
+    if (dtype == CLAMD_SPLIT && Cp % 16) return clamd_fail("nchw_im2col3: bf16x3 needs Cp % 16 == 0");
+    if (int e = clamd_check_split(dtype, dst, ldc)) return e;
     const long long nitem = (long long)B * H * W;
     dim3 g(ew_grid(nitem, 8192)), b(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(T) hipLaunchKernelGGL(nchw_im2col3_kernel<T>, g, b, 0, s, src, (T*)dst, ldc, B, C, H, W, Cp)
     if (dtype == CLAMD_BF16) LAUNCH(bf16_t);
-    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT) LAUNCH(float);
+    else if (dtype == CLAMD_F32) LAUNCH(float);
+    else if (dtype == CLAMD_SPLIT) LAUNCH(split_t);
     else return clamd_fail("nchw_im2col3: bad dtype");
 #undef LAUNCH
     return clamd_check_launch("nchw_im2col3");
@@ -569,10 +591,13 @@ int clamd_nchw_im2col3(const float* src, void* dst, int ldc, int B, int C, int H
 int clamd_nhwc_to_nchw(const void* src, int ldc, float* dst, int B, int C, int H, int W, int dtype, void* stream) {
     const long long n = (long long)B * C * H * W;
     dim3 g(ew_grid(n, 8192)), b(256);
+    if (int e = clamd_check_split(dtype, src, ldc)) return e;
     if (dtype == CLAMD_BF16)
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, (const bf16_t*)src, ldc, dst, B, C, H, W);
-    else if (dtype == CLAMD_F32 || dtype == CLAMD_SPLIT)
+    else if (dtype == CLAMD_F32)
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, g, b, 0, (hipStream_t)stream, (const float*)src, ldc, dst, B, C, H, W);
+    else if (dtype == CLAMD_SPLIT)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<split_t>, g, b, 0, (hipStream_t)stream, (const split_t*)src, ldc, dst, B, C, H, W);
     else return clamd_fail("nhwc_to_nchw: bad dtype");
     return clamd_check_launch("nhwc_to_nchw");
 }

@@ -119,16 +119,8 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(const IgemmParams p) {
         _Pragma("unroll") for (int t = 0; t < NIN; ++t)                                                           \
             _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                      \
                 const int pix_ = slot_pix(j);                                                                     \
-                if constexpr (!SPLIT) {                                                                           \
-                    smem[t * 4 * NPIXP + g4 * NPIXP + pix_] = rin[t][j];                                          \
-                } else {                                                                                          \
-                    /* groups 0,1 = hi channels 0-7 / 8-15, groups 2,3 = lo; this thread owns 4 channels */       \
-                    uint2 hi_, lo_;                                                                               \
-                    split4(rin[t][j], hi_, lo_);                                                                  \
-                    char* b_ = reinterpret_cast<char*>(smem) + ((t * 4 + (g4 >> 1)) * NPIXP + pix_) * 16 + 8 * (g4 & 1); \
-                    *reinterpret_cast<uint2*>(b_) = hi_;                                                          \
-                    *reinterpret_cast<uint2*>(b_ + 2 * NPIXP * 16) = lo_;                                         \
-                }                                                                                                 \
+                /* split_t: the 64-byte K-chunk already is [hi 0-7][hi 8-15][lo 0-7][lo 8-15] = LDS slots 0..3 */ \
+                smem[t * 4 * NPIXP + g4 * NPIXP + pix_] = rin[t][j];                                              \
             }                                                                                                     \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) smem[G::IN_SLOTS + (t * 4 + g4) * G::WG + wco] = rw[t];    \
     } while (0)
@@ -502,8 +494,11 @@ static Conv3Plan plan_conv3x3(const IgemmParams& p, int dtype, const clamd_tunin
     return {0, 2, t > 0x7fffffff ? -1 : (int)t};
 }
 
-static int check_common(const IgemmParams& p, const char* who) {
+static int check_common(const IgemmParams& p, const char* who, int dtype, bool y_nhwc = true) {
     if (p.B <= 0 || p.H <= 0 || p.W <= 0) return clamd_fail("igemm: empty problem");
+    if (int e = clamd_check_split(dtype, p.x, p.x_ldc)) return e;
+    if (y_nhwc) if (int e = clamd_check_split(dtype, p.y, p.y_ldc)) return e;
+    if (p.bn_y) if (int e = clamd_check_split(dtype, p.bn_y, p.Np)) return e;
     if (p.Kp % 32 || p.Np % 32 || p.x_ldc % 8 || p.y_ldc % 8) return clamd_fail("igemm: channel counts/pitches must be padded (K,N %32, ldc %8)");
     // 32-bit element offsets inside the kernel
     // buffer descriptors address ONE image with 32-bit byte offsets (OOB marker = 2^31)
@@ -557,7 +552,7 @@ int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* b
                   float* stats, const void* bn_y, float* bn_sums, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p,
                   int relu, int m_fastest, int dtype, const clamd_tuning* tune, void* stream) {
     IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, m_fastest, bn_y, bn_sums};
-    if (int e = check_common(p, "conv3x3")) return e;
+    if (int e = check_common(p, "conv3x3", dtype)) return e;
     if (int e = clamd_check_tuning(tune)) return e;
     if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("conv3x3: bn_y and bn_sums go together");
     const clamd_tuning& tn = clamd_tune(tune);
@@ -573,7 +568,7 @@ int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* b
                   float* stats, const void* bn_y, float* bn_sums, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p,
                   int relu, int dtype, void* stream) {
     IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, 0, bn_y, bn_sums};
-    if (int e = check_common(p, "conv1x1")) return e;
+    if (int e = check_common(p, "conv1x1", dtype)) return e;
     if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("conv1x1: bn_y and bn_sums go together");
     if (int e = check_rows(p, stat_rows, (int)igemm_tiles(p), "conv1x1")) return e;
     return launch<MODE_PW, EPI_NHWC>(p, dtype, (hipStream_t)stream);
@@ -582,7 +577,7 @@ int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* b
 int clamd_conv1x1_logits(const void* x, int x_ldc, const void* w_packed, const float* bias, float* logits_nchw,
                          int B, int H, int W, int Cin_p, int Cout_p, int num_classes, int dtype, void* stream) {
     IgemmParams p{x, x_ldc, w_packed, bias, logits_nchw, 8, nullptr, B, H, W, Cin_p, Cout_p, 0, num_classes, 0, nullptr, nullptr};
-    if (int e = check_common(p, "conv1x1_logits")) return e;
+    if (int e = check_common(p, "conv1x1_logits", dtype, false)) return e;
     if (num_classes > Cout_p) return clamd_fail("conv1x1_logits: num_classes > padded Cout");
     return launch<MODE_PW, EPI_NCHW>(p, dtype, (hipStream_t)stream);
 }
@@ -590,7 +585,7 @@ int clamd_conv1x1_logits(const void* x, int x_ldc, const void* w_packed, const f
 int clamd_conv1x1_argmax(const void* x, int x_ldc, const void* w_packed, const float* bias, long long* pred, float* logits_nchw,
                          int B, int H, int W, int Cin_p, int Cout_p, int num_classes, int dtype, void* stream) {
     IgemmParams p{x, x_ldc, w_packed, bias, logits_nchw, 8, nullptr, B, H, W, Cin_p, Cout_p, 0, num_classes, 0, nullptr, nullptr, pred};
-    if (int e = check_common(p, "conv1x1_argmax")) return e;
+    if (int e = check_common(p, "conv1x1_argmax", dtype, false)) return e;
     if (!pred) return clamd_fail("conv1x1_argmax: pred is null");
     if (num_classes < 1 || num_classes > Cout_p || num_classes > 64) return clamd_fail("conv1x1_argmax: num_classes must be in [1, min(64, padded Cout)]");
     return launch<MODE_PW, EPI_NCHW>(p, dtype, (hipStream_t)stream);
@@ -599,14 +594,14 @@ int clamd_conv1x1_argmax(const void* x, int x_ldc, const void* w_packed, const f
 int clamd_convT2x2_fwd(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc, int B,
                        int h, int w, int Cin_p, int Cout_p, int dtype, void* stream) {
     IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, nullptr, B, h, w, Cin_p, 4 * Cout_p, 0, Cout_p, 0, nullptr, nullptr};
-    if (int e = check_common(p, "convT_fwd")) return e;
+    if (int e = check_common(p, "convT_fwd", dtype)) return e;
     return launch<MODE_PW, EPI_UP2>(p, dtype, (hipStream_t)stream);
 }
 
 int clamd_convT2x2_dgrad(const void* gy, int gy_ldc, const void* w_packed, void* gx, int gx_ldc, const void* bn_y,
                          float* bn_sums, int stat_rows, int B, int h, int w, int Cin_p, int Cout_p, int dtype, void* stream) {
     IgemmParams p{gy, gy_ldc, w_packed, nullptr, gx, gx_ldc, nullptr, B, h, w, 4 * Cout_p, Cin_p, 0, Cout_p, 0, bn_y, bn_sums};
-    if (int e = check_common(p, "up2_dgrad")) return e;
+    if (int e = check_common(p, "up2_dgrad", dtype)) return e;
     if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("convT2x2_dgrad: bn_y and bn_sums go together");
     if (int e = check_rows(p, stat_rows, (int)igemm_tiles(p), "convT2x2_dgrad")) return e;
     return launch<MODE_UP2, EPI_NHWC>(p, dtype, (hipStream_t)stream);

@@ -149,15 +149,8 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
         uint4* sm_ = smem + (st_) * STAGE;                                                                        \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                          \
             const int pix_ = slot_pix(j);                                                                         \
-            if constexpr (!SPLIT) {                                                                               \
-                sm_[g4 * NPIXP + pix_] = PWS_PROTO_AFFINE(RIN[j], in_vo[j]);                                      \
-            } else {                                                                                              \
-                uint2 hi_, lo_;                                                                                   \
-                split4(RIN[j], hi_, lo_);                                                                         \
-                char* b_ = reinterpret_cast<char*>(sm_) + ((g4 >> 1) * NPIXP + pix_) * 16 + 8 * (g4 & 1);         \
-                *reinterpret_cast<uint2*>(b_) = hi_;                                                              \
-                *reinterpret_cast<uint2*>(b_ + 2 * NPIXP * 16) = lo_;                                             \
-            }                                                                                                     \
+            /* split_t: the 64-byte K-chunk already is [hi 0-7][hi 8-15][lo 0-7][lo 8-15] = LDS slots 0..3 */     \
+            sm_[g4 * NPIXP + pix_] = PWS_PROTO_AFFINE(RIN[j], in_vo[j]);                                          \
         }                                                                                                         \
     } while (0)
 

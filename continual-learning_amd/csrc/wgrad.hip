@@ -163,10 +163,8 @@ __global__ void __launch_bounds__(WS ? 512 : 256, 2) wgrad_kernel(const WgradPar
             if constexpr (!SPLIT) {
                 *reinterpret_cast<uint4*>(sa + pix * STRIDE + g * 16) = ra[j];
             } else {
-                uint2 hi, lo;
-                split4(ra[j], hi, lo);
-                *reinterpret_cast<uint2*>(sa + pix * STRIDE + g * 8) = hi;
-                *reinterpret_cast<uint2*>(sa + LO + pix * STRIDE + g * 8) = lo;
+                // piece g of the pixel's four [16 hi][16 lo] groups: pieces 0,1 of a group go to the hi image, 2,3 to the lo image
+                *reinterpret_cast<uint4*>(sa + ((g & 2) ? LO : 0) + pix * STRIDE + (g >> 2) * 32 + (g & 1) * 16) = ra[j];
             }
         }
 #pragma unroll
@@ -178,10 +176,8 @@ __global__ void __launch_bounds__(WS ? 512 : 256, 2) wgrad_kernel(const WgradPar
             if constexpr (!SPLIT) {
                 *reinterpret_cast<uint4*>(sb + pix * STRIDE + g * 16) = rb[j];
             } else {
-                uint2 hi, lo;
-                split4(rb[j], hi, lo);
-                *reinterpret_cast<uint2*>(sb + pix * STRIDE + g * 8) = hi;
-                *reinterpret_cast<uint2*>(sb + LO + pix * STRIDE + g * 8) = lo;
+                // piece g of the pixel's four [16 hi][16 lo] groups: pieces 0,1 of a group go to the hi image, 2,3 to the lo image
+                *reinterpret_cast<uint4*>(sb + ((g & 2) ? LO : 0) + pix * STRIDE + (g >> 2) * 32 + (g & 1) * 16) = rb[j];
             }
         }
     };
@@ -545,6 +541,8 @@ int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, fl
     const clamd_tuning& tn = clamd_tune(tune);
     if (Rp % 32 || Cp % 32 || a_ldc % 8 || b_ldc % 8) return clamd_fail("wgrad: channel counts/pitches must be padded");
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("wgrad: empty problem");
+    if (int e = clamd_check_split(dtype, a, a_ldc)) return e;
+    if (int e = clamd_check_split(dtype, b, b_ldc)) return e;
     {   // buffer descriptors address one image with 32-bit byte offsets (OOB marker = 2^31)
         const long long sc = mode == WG_UP2 ? 4 : 1;
         if ((long long)H * W * a_ldc * 4 >= (1ll << 30) || sc * H * W * b_ldc * 4 >= (1ll << 30))

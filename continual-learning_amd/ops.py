@@ -144,6 +144,32 @@ def to_nhwc(x_nchw, dcode, cp=None):
     return out
 
 
+def split_encode(x):
+    """fp32 [..., Cp] (Cp % 16 == 0) -> the bf16x3 device layout of the same logical tensor: per 16-channel group
+    [16 x bf16 hi][16 x bf16 lo] with hi = rne_bf16(x), lo = rne_bf16(x - hi), held in a float32-typed container of the same
+    shape (csrc/common.hip.h Vec8<split_t>).  Host-side helper for tests and tools; the step itself never calls it."""
+    assert x.dtype == torch.float32 and x.shape[-1] % 16 == 0
+    g = x.contiguous().reshape(*x.shape[:-1], x.shape[-1] // 16, 16)
+    hi = g.to(torch.bfloat16)
+    lo = (g - hi.float()).to(torch.bfloat16)
+    return torch.stack((hi, lo), dim=-2).contiguous().view(torch.int16).reshape(*x.shape[:-1], 2 * x.shape[-1]) \
+        .view(torch.float32)
+
+
+def split_decode(t):
+    """Inverse of split_encode: the fp32 values hi + lo of a bf16x3 tensor (any 16-channel-aligned slice of one)."""
+    assert t.dtype == torch.float32 and t.shape[-1] % 16 == 0
+    raw = t.contiguous().view(torch.int16).reshape(*t.shape[:-1], t.shape[-1] // 16, 2, 16)
+    f = (raw.to(torch.int32) << 16).view(torch.float32)
+    return (f[..., 0, :] + f[..., 1, :]).reshape(t.shape)
+
+
+def randn_nhwc(dcode, *shape, device='cuda'):
+    """Standard-normal NHWC activation in the storage layout of compute dtype `dcode` (timing tools)."""
+    x = torch.randn(*shape, device=device)
+    return split_encode(x) if dcode == 2 else x.to(TORCH_DT[dcode])
+
+
 def from_nhwc(t, C, dcode):
     B, H, W, ldc = t.shape
     out = torch.empty(B, C, H, W, dtype=torch.float32, device=t.device)

@@ -16,8 +16,11 @@
  *     Physical channel counts (`*_p`) are padded to a power of two >= 32; padded channels hold zeros.
  *   - dtype: CLAMD_F32 computes with v_mfma_f32_32x32x2_f32 (exact fp32), CLAMD_BF16 stores activations and
  *     packed weights as bf16 and accumulates in fp32 (v_mfma_f32_32x32x16_bf16).  CLAMD_SPLIT ("bf16x3") stores
- *     activations as fp32 and splits every MFMA operand into bf16 hi+lo on the fly: hi*hi + hi*lo + lo*hi with fp32
- *     accumulation (~2^-17 relative product error); packed weights hold the hi/lo halves (4 bytes per element).
+ *     every activation and packed weight as the bf16 pair hi = rne(x), lo = rne(x - hi) (4 bytes per element) and
+ *     multiplies hi*hi + hi*lo + lo*hi with fp32 accumulation (~2^-17 relative product error).  Its tensors keep the
+ *     fp32 geometry (element counts, `ldc`, byte sizes), but each 16-channel group of a pixel is laid out as
+ *     [16 x bf16 hi][16 x bf16 lo]; tensor and channel-slice bases must be 64-byte aligned and `ldc` a multiple of
+ *     16 (checked on entry).  clamd_nchw_to_nhwc / clamd_nhwc_to_nchw convert at the boundary.
  */
 #ifndef CLAMD_H
 #define CLAMD_H

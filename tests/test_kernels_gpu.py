@@ -32,10 +32,26 @@ def dev(a, dtype=torch.float32):
 
 
 def rb(a, dcode):
-    """Round a numpy fp32 array to the compute dtype and back (identity for fp32)."""
-    if dcode != 1:
-        return a.astype(np.float32)
-    return torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+    """Round a numpy fp32 array to what the compute dtype stores and back: identity for fp32, rne bf16 for bf16,
+    hi + lo (two bf16, ~17 mantissa bits) for bf16x3."""
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    if dcode == 0:
+        return t.numpy()
+    hi = t.to(torch.bfloat16).to(torch.float32)
+    if dcode == 1:
+        return hi.numpy()
+    return (hi + (t - hi).to(torch.bfloat16).to(torch.float32)).numpy()
+
+
+def nf(C, t, dcode):
+    """Device NHWC activation (whole tensor or a 16-channel-aligned slice) -> fp32 torch tensor of its logical values."""
+    return C.ops.split_decode(t) if dcode == 2 else t.float()
+
+
+def nd(C, a, dcode):
+    """fp32 NHWC numpy array (padded channel count) -> device tensor in the storage layout of the compute dtype."""
+    t = dev(a)
+    return C.ops.split_encode(t) if dcode == 2 else t.to(C.ops.TORCH_DT[dcode])
 
 
 def rnd(rng, *shape):
@@ -75,7 +91,7 @@ def test_layout_roundtrip(C, name, dcode):
     assert t.shape == (2, 6, 10, 32)
     back = C.ops.from_nhwc(t, 5, dcode).cpu().numpy()
     assert np.array_equal(back, x)
-    assert float(t[..., 5:].float().abs().max()) == 0.0        # padded channels are zero
+    assert float(nf(C, t, dcode)[..., 5:].abs().max()) == 0.0        # padded channels are zero
 
 
 @pytest.mark.parametrize('name,dcode', DT)
@@ -204,7 +220,7 @@ def test_conv3x3_fwd_relu_stats(C, name, dcode, shape, m_fastest):
     st = stats.double().sum(0).cpu().numpy()
     np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=2e-3 if dcode == 1 else 1e-4, atol=1e-2 if dcode == 1 else 1e-3)
     np.testing.assert_allclose(st[1, :cout], (ref ** 2).sum((0, 2, 3)), rtol=4e-3 if dcode == 1 else 1e-4, atol=1e-2 if dcode == 1 else 1e-3)
-    assert float(y[..., cout:].float().abs().max()) == 0.0 if cout < cout_p else True
+    assert float(nf(C, y, dcode)[..., cout:].abs().max()) == 0.0 if cout < cout_p else True
 
 
 @pytest.mark.parametrize('name,dcode', DT)
@@ -235,7 +251,7 @@ def test_conv3x3_dgrad_and_wgrad(C, name, dcode, shape):
     sync()
     rgx, rgw, _ = O.conv3x3_bwd(x, w, gz)
     pm = phys_map(segs)
-    got_gx = gx.float().cpu().numpy().transpose(0, 3, 1, 2)[:, [p for p, l in enumerate(pm) if l >= 0]]
+    got_gx = nf(C, gx, dcode).cpu().numpy().transpose(0, 3, 1, 2)[:, [p for p, l in enumerate(pm) if l >= 0]]
     assert rel_l2(got_gx, rgx) < TOL[dcode]
     assert rel_l2(gw.cpu().numpy(), rgw) < (6e-5 if dcode == 2 else 2e-5)   # wgrad output is fp32 in every path
     ybr = rb(yb, dcode)
@@ -563,9 +579,9 @@ def test_conv3x3_random_shapes(C, name, dcode, shape):
     assert rel_l2(C.ops.from_nhwc(y, cout, dcode).cpu().numpy(), ref) < TOL[dcode]
     st = stats.double().sum(0).cpu().numpy()
     np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=2e-3 if dcode == 1 else 1e-4, atol=2e-2 if dcode == 1 else 1e-3)
-    assert float(y[..., cout:].float().abs().max()) == 0.0 if cout < cout_p else True
+    assert float(nf(C, y, dcode)[..., cout:].abs().max()) == 0.0 if cout < cout_p else True
     rgx, rgw, _ = O.conv3x3_bwd(x, w, gz)
-    assert rel_l2(gx.float().cpu().numpy().transpose(0, 3, 1, 2)[:, :cin], rgx) < TOL[dcode]
+    assert rel_l2(nf(C, gx, dcode).cpu().numpy().transpose(0, 3, 1, 2)[:, :cin], rgx) < TOL[dcode]
     assert rel_l2(gw.cpu().numpy(), rgw) < (6e-5 if dcode == 2 else 2e-5)
 
 
@@ -590,13 +606,14 @@ def test_convT2x2_fwd_dgrad_wgrad(C, name, dcode, shape):
     lib.call('clamd_convT2x2_fwd', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(ysl), 2 * cout_p, B, h, w_, cin_p, cout_p, dcode, s)
     sync()
     ref = O.convT2x2_fwd(x, w, b)
-    got = cat[..., cout_p:cout_p + cout].float().cpu().numpy().transpose(0, 3, 1, 2)
+    got = nf(C, cat[..., cout_p:], dcode)[..., :cout].cpu().numpy().transpose(0, 3, 1, 2)
     assert rel_l2(got, ref) < TOL[dcode]
-    assert float((cat[..., :cout_p].float() - 3.0).abs().max()) == 0.0
+    assert float((cat[..., :cout_p].float() - 3.0).abs().max()) == 0.0          # raw storage of the other half: untouched
     # backward: gradient arrives in the same slice
     gy = rb(rnd(rng, B, cout, 2 * h, 2 * w_), dcode)
-    gcat = torch.zeros(B, 2 * h, 2 * w_, 2 * cout_p, dtype=T, device='cuda')
-    gcat[..., cout_p:cout_p + cout] = dev(gy.transpose(0, 2, 3, 1)).to(T)
+    gfull = np.zeros((B, 2 * h, 2 * w_, 2 * cout_p), np.float32)
+    gfull[..., cout_p:cout_p + cout] = gy.transpose(0, 2, 3, 1)
+    gcat = nd(C, gfull, dcode)
     gsl = gcat[..., cout_p:]
     gx = torch.zeros(B, h, w_, cin_p, dtype=T, device='cuda')
     lib.call('clamd_convT2x2_dgrad', ptr(gsl), 2 * cout_p, ptr(wd), ptr(gx), cin_p, None, None, 0, B, h, w_, cin_p, cout_p, dcode, s)
@@ -722,7 +739,7 @@ def test_bn_fwd_bwd_pool(C, name, dcode, shape, pool):
     lib.call('clamd_bn_apply', ptr(yt), cp, ptr(vec[0]), ptr(vec[1]), ptr(cat), 2 * cp, ptr(pooled), cp, B, H, W, cp, dcode, s)
     sync()
     u_ref, cache, rm_ref, rv_ref = O.bn_train_fwd(y, gamma, beta, rm0, rv0)
-    got_u = cat[..., :Cc].float().cpu().numpy().transpose(0, 3, 1, 2)
+    got_u = nf(C, cat[..., :cp], dcode)[..., :Cc].cpu().numpy().transpose(0, 3, 1, 2)
     assert rel_l2(got_u, u_ref) < (1e-5 if dcode != 1 else 4e-3)
     assert float((cat[..., cp:].float() - 2.0).abs().max()) == 0.0
     np.testing.assert_allclose(rm.cpu().numpy(), rm_ref, rtol=1e-5, atol=1e-6)
@@ -734,11 +751,12 @@ def test_bn_fwd_bwd_pool(C, name, dcode, shape, pool):
         sh = vec[1, :Cc].cpu().numpy().astype(np.float64).reshape(1, -1, 1, 1)
         u32 = (y.astype(np.float64) * sc + sh).astype(np.float32)
         p_ref, idx = O.maxpool2x2_fwd(u32)
-        assert np.array_equal(pooled[..., :Cc].float().cpu().numpy().transpose(0, 3, 1, 2), rb(p_ref, dcode))
+        assert np.array_equal(nf(C, pooled, dcode)[..., :Cc].cpu().numpy().transpose(0, 3, 1, 2), rb(p_ref, dcode))
     # ---- backward ----
     ga = rb(rnd(rng, B, Cc, H, W), dcode)
-    gat = torch.zeros(B, H, W, 2 * cp, dtype=T, device='cuda')
-    gat[..., :Cc] = dev(ga.transpose(0, 2, 3, 1)).to(T)
+    gfull = np.zeros((B, H, W, 2 * cp), np.float32)
+    gfull[..., :Cc] = ga.transpose(0, 2, 3, 1)
+    gat = nd(C, gfull, dcode)
     gp = rb(rnd(rng, B, Cc, H // 2, W // 2), dcode) if pool else None
     gpt = C.ops.to_nhwc(dev(gp), dcode) if pool else None
     sums, srows = stat_buf(C, lib.OP_BN_BWD_REDUCE, B, H, W, 1 if pool else 0, cp, dcode, nk=NS)

@@ -16,7 +16,7 @@ if os.environ.get('CONV_LAYERS'):      # e.g. CONV_LAYERS='1024,512,16;512,1024,
 lib = C._lib.load(); s = C._lib.stream_ptr()
 tot = {v: [0.0, 0.0] for v in variants}
 for cin, cout, hw in layers:
-    x = torch.randn(B, hw, hw, cin, device='cuda').to(T)
+    x = C.ops.randn_nhwc(dc, B, hw, hw, cin)
     w = torch.randn(cout, cin, 3, 3, device='cuda') / (3 * cin ** 0.5)
     wf = torch.zeros(9 * cout * cin, dtype=T, device='cuda')
     bias = torch.zeros(cout, device='cuda')

@@ -18,7 +18,7 @@ s = C._lib.stream_ptr()
 lib = C._lib.load()
 tot_f, tot_t = 0.0, 0.0
 for cin, cout, hw in layers:
-    x = torch.randn(B, hw, hw, cin, device='cuda').to(T)
+    x = C.ops.randn_nhwc(dc, B, hw, hw, cin)
     w = torch.randn(cout, cin, 3, 3, device='cuda') / (3 * cin ** 0.5)
     wf = torch.zeros(9 * cout * cin, dtype=T, device='cuda'); wd = torch.zeros(9 * cin * cout, dtype=T, device='cuda')
     bias = torch.zeros(cout, device='cuda')
@@ -31,7 +31,7 @@ for cin, cout, hw in layers:
         call('clamd_conv3x3', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(stats), None, None, rows, B, hw, hw, cin, cout, 1, mf, dc, None, s)
     wsb = lib.clamd_wgrad_workspace_bytes(0, B, hw, hw, cout, cin, dc)
     ws = torch.empty(wsb // 4 + 4, device='cuda'); gw = torch.empty_like(w)
-    g = torch.randn(B, hw, hw, cout, device='cuda').to(T)
+    g = C.ops.randn_nhwc(dc, B, hw, hw, cout)
     def wgr():
         call('clamd_wgrad', 0, ptr(g), cout, ptr(x), cin, ptr(ws), wsb, ptr(gw), B, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, dc, None, s)
     res = []

@@ -13,7 +13,7 @@ B, iters, rounds = 16, 10, 4
 lib = C._lib.load(); s = C._lib.stream_ptr()
 tot = {v: [0.0, 0.0] for v in variants}
 for cin, cout, hw in [(1024, 512, 16), (512, 256, 32), (256, 128, 64), (128, 64, 128)]:
-    x = torch.randn(B, hw, hw, cin, device='cuda').to(T)
+    x = C.ops.randn_nhwc(dc, B, hw, hw, cin)
     w = torch.randn(cin, cout, 2, 2, device='cuda') / (cin ** 0.5)
     wf = torch.zeros(4 * cout * cin, dtype=T, device='cuda'); wd = torch.zeros(cin * 4 * cout, dtype=T, device='cuda')
     bias = torch.zeros(cout, device='cuda')

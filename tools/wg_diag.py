@@ -12,8 +12,8 @@ B = 16
 l = C._lib.load()
 out = (ctypes.c_ulonglong * 8)()
 for cin, cout, hw in [(64, 64, 256), (256, 256, 64), (512, 512, 32), (1024, 1024, 16)]:
-    x = torch.randn(B, hw, hw, cin, device='cuda').to(T)
-    g = torch.randn(B, hw, hw, cout, device='cuda').to(T)
+    x = C.ops.randn_nhwc(dc, B, hw, hw, cin)
+    g = C.ops.randn_nhwc(dc, B, hw, hw, cout)
     wsb = l.clamd_wgrad_workspace_bytes(0, B, hw, hw, cout, cin, dc)
     ws = torch.empty(wsb // 4 + 4, device='cuda'); gw = torch.empty(cout, cin, 3, 3, device='cuda')
     s = C._lib.stream_ptr()

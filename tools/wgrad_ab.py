@@ -14,8 +14,8 @@ layers = [(64, 64, 256), (128, 64, 256), (128, 128, 128), (256, 128, 128), (256,
 lib = C._lib.load(); s = C._lib.stream_ptr()
 tot = {v: [0.0, 0.0] for v in variants}
 for cin, cout, hw in layers:
-    x = torch.randn(B, hw, hw, cin, device='cuda').to(T)
-    g = torch.randn(B, hw, hw, cout, device='cuda').to(T)
+    x = C.ops.randn_nhwc(dc, B, hw, hw, cin)
+    g = C.ops.randn_nhwc(dc, B, hw, hw, cout)
     wsb = lib.clamd_wgrad_workspace_bytes(0, B, hw, hw, cout, cin, dc)
     ws = torch.empty(wsb // 4 + 4, device='cuda'); gw = torch.empty(cout, cin, 3, 3, device='cuda')
     best = {v: 1e9 for v in variants}

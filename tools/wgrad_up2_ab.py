@@ -12,8 +12,8 @@ T = C.ops.TORCH_DT[dc]
 B, iters, rounds = 16, 10, 4
 lib = C._lib.load(); s = C._lib.stream_ptr()
 for cin, cout, hw in [(1024, 512, 16), (512, 256, 32), (256, 128, 64), (128, 64, 128)]:
-    x = torch.randn(B, hw, hw, cin, device='cuda').to(T)
-    gy = torch.randn(B, 2 * hw, 2 * hw, cout, device='cuda').to(T)
+    x = C.ops.randn_nhwc(dc, B, hw, hw, cin)
+    gy = C.ops.randn_nhwc(dc, B, 2 * hw, 2 * hw, cout)
     wsb = lib.clamd_wgrad_workspace_bytes(2, B, hw, hw, cin, cout, dc)
     ws = torch.empty(wsb // 4 + 4, device='cuda'); gw = torch.empty(cin, cout, 2, 2, device='cuda')
     tun = {v: C._lib.Tuning(**{key: v}) for v in variants}

@@ -15,7 +15,7 @@ tn = C._lib.Tuning(igemm_ws=mode, igemm_pws=2 if pws else 0)
 diag = lib.clamd_debug_pws_diag if pws else lib.clamd_debug_ws_diag
 out = (ctypes.c_ulonglong * 8)()
 for cin, cout, hw in [(64, 64, 256), (128, 64, 256), (128, 128, 128), (256, 256, 64), (1024, 512, 32)]:
-    x = torch.randn(B, hw, hw, cin, device='cuda').to(T)
+    x = C.ops.randn_nhwc(dc, B, hw, hw, cin)
     w = torch.randn(cout, cin, 3, 3, device='cuda') / (3 * cin ** 0.5)
     wf = torch.zeros(9 * cout * cin, dtype=T, device='cuda'); bias = torch.zeros(cout, device='cuda')
     tab = C.ops.PackTable(dc); tab.conv3x3(w, wf, None, [(cin, cin)], cout); tab.finalize('cuda').run(dc)
