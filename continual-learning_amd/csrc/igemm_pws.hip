@@ -225,6 +225,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
         }
         float* const wbuf = reinterpret_cast<float*>(smem + 2 * STAGE) + cw * 32 * EPW;   // this wave's transposition block
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+        const bool plain = !p.relu && !p.bias && !p.stats;         // wave-uniform
         const unsigned y_img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.y_ldc * (unsigned)sizeof(T);
         const unsigned bn_img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.Np * (unsigned)sizeof(T);   // bn_y: dense pitch Np
         unsigned bn_vo[BN ? MT : 1][4];
@@ -346,6 +347,15 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             // MFMA loop, was 44 % of the consumer cycles of the 64-channel bf16 layers (tools/ws_diag.py ... pws):
             // ReLU is a max with 0 / -inf (no select), the stores are range-checked buffer stores whose per-lane offsets
             // are tile-relative constants (tile origin = scalar offset), edge masks exist only on ragged tiles.
+#if defined(PWS_ABLATE_EPI) && PWS_ABLATE_EPI == 1     // timing ablation (tools/pws_epi_ablate.sh, wrong results): no epilogue at all
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) asm volatile("" :: "v"(acc[mt][nt][e]));
+            continue;
+#endif
             const int tm = mg + ti * gm;
             const int x0 = (tm % tiles_x) * TW, y0 = ((tm / tiles_x) % tiles_y) * TH, b = tm / (tiles_x * tiles_y);
             const __amdgpu_buffer_rsrc_t yrs = make_rsrc((const char*)p.y + (size_t)b * y_img, y_img);
@@ -354,7 +364,15 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const unsigned long long e0 = PWD_T(); (void)e0;
-                if (full) {
+                if (plain) {
+                    // data-gradient launch (no bias, no ReLU, no statistics): the accumulators go straight to the transposition.
+                    // VALU instructions are not free next to the matrix pipe -- another wave's VALU stream overlaps only ~25 % of an
+                    // MFMA stream on the same SIMD (tools/ubench/mfma_valu_overlap.hip) -- so these 4 x 64 skipped per tile count
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) wbuf[acc_row(e, h) * EPW + 32 * nt + r] = acc[mt][nt][e];
+                } else if (full) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -397,7 +415,11 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                         const int m = 32 * MT * cw + 32 * mt + ps * 8 + (lane >> 3);
                         if (!(y0 + m / TW < p.H && x0 + m % TW < p.W)) vo = BUF_OOB;
                     }
+#if defined(PWS_ABLATE_EPI) && PWS_ABLATE_EPI == 2     // timing ablation (wrong results): everything but the global stores
+                    asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(vo));
+#else
                     buf_st8<T>(yrs, vo, y_so, v);
+#endif
                     if constexpr (BN) {
                         if (do_bn) {
                             float yv[8];

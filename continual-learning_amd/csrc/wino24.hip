@@ -237,6 +237,9 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { st1[i >> 2][i & 3] = 0.f; st2[i >> 2][i & 3] = 0.f; }
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+        // data-gradient launches have no bias, ReLU or statistics: 16 VALU per stored float4 less (the wave owns its SIMD, so
+        // every VALU instruction of the epilogue is time the matrix pipe idles)
+        const bool plain = !p.relu && !p.bias && !p.stats;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             float* const exb = ex + nt * EXB;
@@ -276,16 +279,20 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
                         o.x = R[1].x - R[2].x - R[3].x; o.y = R[1].y - R[2].y - R[3].y;
                         o.z = R[1].z - R[2].z - R[3].z; o.w = R[1].w - R[2].w - R[3].w;
                     }
-                    o.x = fmaxf(o.x + bias4.x, relu_lo); o.y = fmaxf(o.y + bias4.y, relu_lo);
-                    o.z = fmaxf(o.z + bias4.z, relu_lo); o.w = fmaxf(o.w + bias4.w, relu_lo);
+                    if (!plain) {
+                        o.x = fmaxf(o.x + bias4.x, relu_lo); o.y = fmaxf(o.y + bias4.y, relu_lo);
+                        o.z = fmaxf(o.z + bias4.z, relu_lo); o.w = fmaxf(o.w + bias4.w, relu_lo);
+                    }
                     const int yy = y0 + 2 * oty + pp, xx = x0 + 4 * otx + q;
                     if (!RAGGED || (yy < p.H && xx < p.W && n < p.Np)) {
 #ifndef W24_ABLATE_ST
                         *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = o;
 #endif
-                        st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
-                        st2[nt][0] = fmaf(o.x, o.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, o.y, st2[nt][1]);
-                        st2[nt][2] = fmaf(o.z, o.z, st2[nt][2]); st2[nt][3] = fmaf(o.w, o.w, st2[nt][3]);
+                        if (!plain) {
+                            st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
+                            st2[nt][0] = fmaf(o.x, o.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, o.y, st2[nt][1]);
+                            st2[nt][2] = fmaf(o.z, o.z, st2[nt][2]); st2[nt][3] = fmaf(o.w, o.w, st2[nt][3]);
+                        }
                     }
                 }
             }

@@ -540,6 +540,25 @@ def test_scheduling_knobs_do_not_change_results(C, dtype):
         assert float((a[1] - ref[1]).norm() / ref[1].norm()) < (1e-4 if dtype == 'fp32' else 2e-2), knob
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16x3', 'bf16'])
+def test_fused_bn_backward_sums_match_the_separate_reduction(C, dtype, monkeypatch):
+    """unet.FUSE_BN_SUMS: the five BatchNorm-backward sums taken in the epilogue of the data-gradient kernel that produces
+    the gradient (every direct-kernel dtype, forced on here; 'auto' uses it for the persistent bf16 kernel only) against
+    the stand-alone bn_bwd_reduce pass: the same sums over differently shaped partial rows -> the same step up to fp32
+    rounding of the rows, and each setting bit-identical to itself."""
+    from continual_learning_amd import unet as U
+    monkeypatch.setattr(U, 'WINOGRAD', False)               # the Winograd data-gradient kernel has no such epilogue
+    monkeypatch.setattr(U, 'FUSE_BN_SUMS', False)
+    ref = _one_step(C, dtype, 6, 16, 4, 64)
+    assert not any(u.fused_reduce for u in next(iter(ref[3]._engines.values())).convs)
+    monkeypatch.setattr(U, 'FUSE_BN_SUMS', True)
+    a, a2 = _one_step(C, dtype, 6, 16, 4, 64), _one_step(C, dtype, 6, 16, 4, 64)
+    assert sum(u.fused_reduce for u in next(iter(a[3]._engines.values())).convs) >= 13
+    assert torch.equal(a[1], a2[1]) and torch.equal(a[2], a2[2])
+    assert float((a[1] - ref[1]).norm() / ref[1].norm()) < (1e-4 if dtype != 'bf16' else 2e-2)
+    assert abs(float(a[0]) - float(ref[0])) < 1e-5 * abs(float(ref[0]))      # the forward pass is the same launches
+
+
 def test_gradsync_rccl_world1_on_gpu(C):
     """The RCCL code path of ddp.GradSync (side stream, per-stage buckets, optimiser hook) with a 1-rank "nccl"
     process group on the one GPU of the test box: a world-1 all-reduce is the identity, so loss, gradients and updated
