@@ -40,7 +40,8 @@ def rccl_settings():
 
 
 class GradSync:
-    def __init__(self, model, optimizer=None, process_group=None, min_bucket_bytes=4 << 20, cu_reserve=None, timing=False):
+    def __init__(self, model, optimizer=None, process_group=None, min_bucket_bytes=4 << 20, cu_reserve=None, timing=False,
+                 wino_per_tile=None):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         self.group = process_group
@@ -54,12 +55,15 @@ class GradSync:
         self.launches = 0
         model.grad_sync = self
         # RCCL's channel workgroups hold CUs for the duration of a collective, and our MFMA kernels need a whole CU per
-        # workgroup.  Nothing process-wide is touched: the reserve below is a field of THIS model's tuning (passed per call).
-        # More than one rank: one workgroup per Winograd tile instead of the persistent grid.  A statically strided persistent
-        # grid runs two full rounds when RCCL holds a few CUs, while the hardware dispatcher spreads 4096 tile workgroups over
-        # whatever is free (held-CU rehearsal, fp32: 1.41x instead of 1.69x while 8 CUs are held, +1 % otherwise).  A field of
-        # THIS model's tuning; one rank keeps the persistent grid (bit-identical to the plain step).
-        if self.world > 1:
+        # workgroup.  Nothing process-wide is touched: the knobs below are fields of THIS model's tuning (passed per call).
+        # Held-CU rehearsal with the weight gradients on their second stream (tools/cu_steal.py, fp32, 8 CUs held for the WHOLE
+        # step): persistent Winograd grid 23.0 -> 32.1 ms, one workgroup per tile 24.3 -> 27.9 ms.  The per-tile grid pays
+        # once collectives are resident for more than 24 % of the step; the estimate for this model is ~10 % (124 MB over 8
+        # channels against a 14 ms backward pass), so the persistent grid stays (one rank or many: the same kernels, so a
+        # 1-rank group is bit-identical to the plain step) and the per-tile grid is the opt-in (wino_per_tile / CLAMD_WINO_PER_TILE).
+        if wino_per_tile is None:
+            wino_per_tile = bool(int(os.environ.get('CLAMD_WINO_PER_TILE', '0') or 0))
+        if wino_per_tile and self.world > 1:
             model.tuning.wino_persist = 0
         # optional: grids sized to the chip leave CUs free for the RCCL channels (see the break-even above)
         if cu_reserve is None:
@@ -86,6 +90,8 @@ class GradSync:
             self._lo = (min(self._lo[0], lo), max(self._lo[1], hi))
         last = st is eng.stages[0]
         if (self._lo[1] - self._lo[0]) * 4 >= self.min_bucket or last:
+            # the weight gradients of the bucket are produced on the engine's second stream (unet.WGRAD_STREAM)
+            self._wg_stream = getattr(eng, 'wg_stream', None) if getattr(eng, '_wg_used', False) else None
             self._launch(eng.gflat[self._lo[0]:self._lo[1]])
             self._lo = None
 
@@ -95,6 +101,8 @@ class GradSync:
             if self._stream is None:
                 self._stream = torch.cuda.Stream()
             self._stream.wait_stream(torch.cuda.current_stream())
+            if getattr(self, '_wg_stream', None) is not None:
+                self._stream.wait_stream(self._wg_stream)
             with torch.cuda.stream(self._stream):
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             self._pending.append(None)

@@ -8,6 +8,9 @@ The child modules (nn.Conv2d, nn.BatchNorm2d, ...) are only PARAMETER CONTAINERS
 and backward are fixed schedules of C-ABI kernel launches on NHWC activations (fp32 or bf16) kept in buffers owned by
 PyTorch's allocator.  There is no CPU path: calling it with CPU tensors raises.
 """
+import os
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -33,6 +36,12 @@ WINOGRAD24 = True
 # (tools/wino24_wgrad_ab.py: 1.02-1.04x there, 0.88-1.00x on the deep layers -- both operands are transformed in the loop,
 # 3.5 transform VALU per MFMA, so the 25 % fewer MFMAs buy little); True = everywhere it applies; False = F(2x2,3x3).
 WINOGRAD24_WGRAD = 'auto'
+# Weight-gradient kernels (and the bias-gradient channel sums of the ConvTranspose / head layers) go to a second HIP stream:
+# they are off the critical chain of the backward pass (dgrad -> BatchNorm-backward reduce / finalize / apply -> dgrad ...),
+# and the HBM-bound BatchNorm passes of the NEXT unit fit beside a weight-gradient workgroup on the same CU (one wave per
+# SIMD, <= 64 registers, <= 8 KB LDS), so they run under the MFMA-bound kernel instead of after it.  Results are unchanged
+# (same kernels, same arguments); joined back before backward() returns.  Off while bench.py times single launches.
+WGRAD_STREAM = True
 
 # bench.py sets this to a list to get per-launch HIP-event timings of the MFMA kernels:
 # entries (tag, algorithmic_flops, start_event, end_event, algorithmic_bytes), recorded on the stream the kernel is
@@ -42,6 +51,21 @@ KERNEL_TIMING = None
 
 _TIMED_UNIT = ['', 1.0]   # conv unit being launched and the fraction of its algorithmic FLOPs the kernel executes (Winograd:
 #                         # 16/36 or 24/72); only read while KERNEL_TIMING is set (bench.py, tools/layer_table.py)
+
+
+_SECOND_STREAM = {}
+
+
+def _second_stream(dev):
+    """ONE second stream per device and process, shared by every engine: HIP multiplexes streams onto a handful of hardware
+    queues (4 by default) in creation order, and a kernel queues behind whatever shares its hardware queue -- a stream per
+    engine would sooner or later land on the queue RCCL's kernels use."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SECOND_STREAM:
+        # default priority: the device offers only (normal, high), and giving either stream the high one changed nothing
+        # measurable (tools/cu_steal.py, base and held-CU cases within 0.5 %)
+        _SECOND_STREAM[key] = torch.cuda.Stream(device=dev)
+    return _SECOND_STREAM[key]
 
 
 def _timed(tag, flops, nbytes, name, *args):
@@ -187,9 +211,14 @@ class _Conv:
 
 
 class _Engine:
+    @property
+    def model(self):
+        return self._model_ref()
+
     def __init__(self, model, B, H, W, device):
         lib = _lib.load()
-        self.model = model
+        self._model_ref = weakref.ref(model)      # the model owns its engines; a strong reference back would leave the
+        #                                           multi-GB activation buffers to the cyclic garbage collector
         self.B, self.H, self.W, self.dev = B, H, W, device
         self.dcode, self.tdtype = _DTYPES[model.compute_dtype]
         self.wino = bool(WINOGRAD) and self.dcode == _lib.F32
@@ -350,6 +379,9 @@ class _Engine:
                 rp, cp_ = (t.cin_p, t.cout_p) if t.kind == 'convT' else (t.cout_p, t.cin_p)
                 ws = max(ws, lib.clamd_wgrad_workspace_bytes(mode, B, H >> t.level, W >> t.level, rp, cp_, self.dcode))
         self.ws = torch.empty(ws // 4 + 16, dtype=torch.float32, device=dev)
+        self.wg_stream = _second_stream(dev) if (WGRAD_STREAM and dev.type == 'cuda') else None
+        self._wg_used = False
+        self._pack_pending = False
         self.ws_bytes = ws
         self._build_pack_table()
         self._ptrs = None
@@ -444,10 +476,17 @@ class _Engine:
         B, H, W, dc = self.B, self.H, self.W, self.dcode
         self._plan_stat_rows()
         self.pack_table.run(dc, s)
+        # the Winograd filter transforms (454 MB of HBM traffic per step at config 2) are first needed by the SECOND convolution:
+        # they run on the second stream under the first layer's im2col / pointwise conv / BatchNorm passes
+        self._pack_pending = False
+        sp = s
+        if self.wg_stream is not None and KERNEL_TIMING is None and (self.wino_table is not None or self.wino24_table is not None):
+            self.wg_stream.wait_stream(torch.cuda.current_stream())
+            sp, self._pack_pending = self.wg_stream.cuda_stream, True
         if self.wino_table is not None:
-            self.wino_table.run(s)
+            self.wino_table.run(sp)
         if self.wino24_table is not None:
-            self.wino24_table.run(s)
+            self.wino24_table.run(sp)
         if self.convs[0].im2col:
             call('clamd_nchw_im2col3', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
                  self.x_in.shape[-1], dc, s)
@@ -472,6 +511,9 @@ class _Engine:
                 logits = torch.empty(B, self.K, H, W, dtype=torch.float32, device=self.dev)
                 call('clamd_conv1x1_logits', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(logits), B, h, w,
                      t.cin_p, t.cout_p, self.K, dc, s)
+        if self._pack_pending:          # no Winograd layer ran (cannot happen with the shapes that build the tables; stay safe)
+            torch.cuda.current_stream().wait_stream(self.wg_stream)
+            self._pack_pending = False
         if training:
             torch._foreach_add_(self.nbts, 1)
         return logits
@@ -505,6 +547,9 @@ class _Engine:
             call('clamd_conv1x1', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
                  ptr(u.stats) if training else None, None, None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
         elif u.wino:
+            if self._pack_pending:
+                torch.cuda.current_stream().wait_stream(self.wg_stream)
+                self._pack_pending = False
             _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
                    'clamd_conv3x3_winograd24' if u.w24 else 'clamd_conv3x3_winograd', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
                    ptr(u.stats) if training else None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
@@ -519,9 +564,19 @@ class _Engine:
              ptr(u.pooled), u.pooled.shape[-1] if u.pooled is not None else 0, B, u.h, u.w_, u.cout_p, dc, s)
 
     # ------------------------------------------------------------------------------------------ backward
+    def _wg_stream_ptr(self):
+        """Stream for a parameter-gradient launch whose inputs have just been enqueued on the current stream."""
+        if self.wg_stream is None or KERNEL_TIMING is not None:
+            return _lib.stream_ptr()
+        self.wg_stream.wait_stream(torch.cuda.current_stream())
+        self._wg_used = True
+        return self.wg_stream.cuda_stream
+
     def backward(self, gout):
         m = self.model
         s = _lib.stream_ptr()
+        self._wg_used = False
+        self._pack_pending = False
         B, H, W, dc = self.B, self.H, self.W, self.dcode
         if not self.fwd_training:
             raise RuntimeError('UNet.backward after an eval-mode forward is not supported (BatchNorm backward uses batch statistics)')
@@ -548,20 +603,22 @@ class _Engine:
                 h, w = H >> t.level, W >> t.level
                 if t.kind == 'head':
                     call('clamd_nchw_to_nhwc', ptr(gout), ptr(self.dl), self.Kp, B, self.K, H, W, self.Kp, 1.0, dc, s)
+                    sw = self._wg_stream_ptr()
                     call('clamd_wgrad', _lib.WGRAD_PW, ptr(self.dl), self.Kp, ptr(t.x), t.x.shape[-1], ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cout_p, t.cin_p, t.cout, t.cin,
-                         t.cout, t.cout_p, t.cin, t.cin_p, dc, tp, s)
+                         t.cout, t.cout_p, t.cin, t.cin_p, dc, tp, sw)
                     call('clamd_channel_sum', ptr(self.dl), self.Kp, g[t.keys[1]], B * h * w, self.Kp, t.cout, dc,
-                         ptr(self.ws), self.ws_bytes, tp, s)
+                         ptr(self.ws), self.ws_bytes, tp, sw)
                     call('clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], None,
                          ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
                          t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cout_p, t.cin_p, 0, dc, s)
                 else:
+                    sw = self._wg_stream_ptr()
                     call('clamd_wgrad', _lib.WGRAD_UP2, ptr(t.x), t.x.shape[-1], ptr(t.gy_slice), t.y_ldc, ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cin_p, t.cout_p, t.cin, t.cout,
-                         t.cin, t.cin_p, t.cout, t.cout_p, dc, tp, s)
+                         t.cin, t.cin_p, t.cout, t.cout_p, dc, tp, sw)
                     call('clamd_channel_sum', ptr(t.gy_slice), t.y_ldc, g[t.keys[1]], B * 4 * h * w, t.cout_p,
-                         t.cout, dc, ptr(self.ws), self.ws_bytes, tp, s)
+                         t.cout, dc, ptr(self.ws), self.ws_bytes, tp, sw)
                     call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
                          ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
                          t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cin_p, t.cout_p, dc, s)
@@ -569,6 +626,8 @@ class _Engine:
                 self._conv_bwd(u, s)
             if sync is not None:
                 sync.stage_done(self, st)
+        if self._wg_used:
+            torch.cuda.current_stream().wait_stream(self.wg_stream)       # every gradient is complete for whoever comes next
         gf = self.gflat
         return [gf[o:o + k].view(self.gshape[n]) for n, (o, k) in ((n, self.goffset[n]) for n in self.param_names)]
 
@@ -599,19 +658,20 @@ class _Engine:
         else:
             c_seg0, c_seg0p = u.cin, u.cin_p
         flops = 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout
+        sw = self._wg_stream_ptr()
         if u.im2col:
             call('clamd_wgrad', _lib.WGRAD_PW, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
-                 g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, 9 * u.cin, u.cout, u.cout_p, 9 * u.cin, u.cin_p, dc, tp, s)
+                 g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, 9 * u.cin, u.cout, u.cout_p, 9 * u.cin, u.cin_p, dc, tp, sw)
             return
         _TIMED_UNIT[:] = [u.name + ' wgrad', self.executed_fraction(u, 'wgrad')]
         if u.wino:
             _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
                    'clamd_wgrad_winograd24' if u.w24g else 'clamd_wgrad_winograd', ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
-                   g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, tp, s)
+                   g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, tp, sw)
         else:
             _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
                    'clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
-                   g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, dc, tp, s)
+                   g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, dc, tp, sw)
         _TIMED_UNIT[:] = [u.name + ' dgrad', self.executed_fraction(u, 'dgrad')]
         if u.g_in is not None and u.wino:
             _timed('igemm_conv3x3', flops, self._conv_bytes(u),

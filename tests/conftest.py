@@ -26,6 +26,15 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _collect_garbage_between_gpu_tests(request):
+    """Full-size tests hold tens of GB each; whatever a test leaves in reference cycles is collected before the next one."""
+    yield
+    if 'gpu' in request.keywords:
+        import gc
+        gc.collect()
+
+
 @pytest.fixture(scope='session')
 def golden():
     def load(name):

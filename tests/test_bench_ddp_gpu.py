@@ -62,14 +62,15 @@ def test_bench_rccl_code_path_with_one_rank():
 @pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
 def test_step_survives_stolen_cus(dtype):
     """SURVEY.md §8e ('cap RCCL channels/CUs'), rehearsed on one GPU: a dummy kernel holds 8 CUs for the whole measurement,
-    as 8 RCCL channel workgroups would during a collective.  With clamd_tuning::cu_reserve = 8 the grids sized to the chip fit
-    beside the held CUs: measured 1.12x (bf16) / 1.18x (fp32) of the undisturbed step with the CUs held for the WHOLE step,
-    against 1.36x / 1.69x with the default grids.  (The remainder is quantisation: the deep layers have 256-512 equal work
-    items, which take an extra round on 248 CUs whatever the schedule; for the same reason the reserve is opt-in -- it
-    costs its 1.12-1.18x also while nothing is held.  DESIGN.md §5 has the break-even.)"""
+    as 8 RCCL channel workgroups would during a collective.  With the weight-gradient kernels on their second stream
+    (unet.WGRAD_STREAM) the workgroups of two kernels share whatever is free, and the default grids lose 1.19x (bf16) /
+    1.40x (fp32) while the CUs are held (one stream: 1.36x / 1.69x); the one-workgroup-per-tile Winograd grid loses 1.21x
+    (fp32) but costs 6 % when nothing is held.  DESIGN.md §5 has the break-even; here: the bounds, and that nothing
+    queues behind the holder (a step that waited for it would take > 10x)."""
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import cu_steal
     r = cu_steal.measure(dtype, held=8, steps=5)
     print(r)
-    assert r['reserved_over_base'] < (1.2 if dtype == 'bf16' else 1.35), r
-    assert r['reserved'] < 0.92 * r['stolen'], r      # the reserve removes most of the second rounds
+    bound = 1.3 if dtype == 'bf16' else 1.55
+    assert r['stolen_over_base'] < bound and r['reserved_over_base'] < bound, r
+    assert r['pertile_over_base'] < (1.3 if dtype == 'bf16' else 1.35), r

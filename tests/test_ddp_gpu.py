@@ -30,8 +30,8 @@ def _free_port():
 
 def _train(model_dtype, shard, ddp, per_tile=False):
     """K train steps (trainer.py:172-176 order) on shard `shard`; returns (losses, flat parameter vector).  per_tile: the
-    Winograd grid GradSync selects when there is more than one rank (one workgroup per tile: other partial rows of the
-    BatchNorm statistics than the persistent grid -- each bit-reproducible, not bit-identical to each other)."""
+    Winograd grid GradSync(wino_per_tile=True) selects when there is more than one rank (one workgroup per tile: other
+    partial rows of the BatchNorm statistics than the persistent grid -- each bit-reproducible, not bit-identical to each other)."""
     import continual_learning_amd as C
     dev = torch.device('cuda', 0)
     torch.manual_seed(7)
@@ -42,8 +42,8 @@ def _train(model_dtype, shard, ddp, per_tile=False):
         model.tuning.wino_persist = 0
     if ddp:
         C.ddp.broadcast_parameters(model)
-        C.ddp.GradSync(model, opt, min_bucket_bytes=16 << 10)      # small buckets: several collectives per backward
-        assert model.tuning.wino_persist == (1 if dist.get_world_size() == 1 else 0)
+        C.ddp.GradSync(model, opt, min_bucket_bytes=16 << 10, wino_per_tile=per_tile)      # small buckets: several collectives per backward
+        assert model.tuning.wino_persist == (0 if per_tile and dist.get_world_size() > 1 else 1)
     b, s = CFG['batch'], CFG['size']
     x = torch.from_numpy(C.synth.images(99, b, 3, s, s, first_image=shard * b)).to(dev)
     y = torch.from_numpy(C.synth.labels(99, b, s, s, CFG['num_classes'], first_image=shard * b)).to(dev)
@@ -64,22 +64,22 @@ def _train(model_dtype, shard, ddp, per_tile=False):
     return losses, flat, grad0
 
 
-def _worker(rank, world, port, dtype, same_shard, q):
+def _worker(rank, world, port, dtype, same_shard, q, per_tile=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        losses, flat, grad0 = _train(dtype, 0 if same_shard else rank, ddp=True)
+        losses, flat, grad0 = _train(dtype, 0 if same_shard else rank, ddp=True, per_tile=per_tile)
         q.put((rank, losses, flat.numpy(), grad0.numpy()))
     finally:
         dist.destroy_process_group()
 
 
-def _run_world2(dtype, same_shard):
+def _run_world2(dtype, same_shard, per_tile=False):
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, dtype, same_shard, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, dtype, same_shard, q, per_tile)) for r in range(world)]
     for p in ps:
         p.start()
     res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
@@ -89,10 +89,11 @@ def _run_world2(dtype, same_shard):
     return res
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
-def test_ddp_identical_shards_reproduce_single_process(dtype):
-    ref_losses, ref_flat, ref_grad = _train(dtype, 0, ddp=False, per_tile=True)     # the grid the two-rank runs use
-    for rank, losses, flat, grad0 in _run_world2(dtype, same_shard=True):
+@pytest.mark.parametrize('dtype,per_tile', [('fp32', False), ('bf16', False), ('fp32', True)])
+def test_ddp_identical_shards_reproduce_single_process(dtype, per_tile):
+    # per_tile: the opt-in one-workgroup-per-tile Winograd grid (GradSync(wino_per_tile=True)); the reference uses the same grid
+    ref_losses, ref_flat, ref_grad = _train(dtype, 0, ddp=False, per_tile=per_tile)
+    for rank, losses, flat, grad0 in _run_world2(dtype, same_shard=True, per_tile=per_tile):
         g = torch.from_numpy(grad0)
         assert torch.equal(g, 2 * ref_grad), f'rank {rank}: summed gradient is not exactly 2x the local gradient ' \
                                              f'(rel {float((g - 2 * ref_grad).norm() / (2 * ref_grad).norm()):.2e})'

@@ -559,6 +559,24 @@ def test_fused_bn_backward_sums_match_the_separate_reduction(C, dtype, monkeypat
     assert abs(float(a[0]) - float(ref[0])) < 1e-5 * abs(float(ref[0]))      # the forward pass is the same launches
 
 
+def test_engine_buffers_are_released_with_the_model(C):
+    """A model's engine (activations, gradients, workspaces: GBs at full size) must go when the model goes, by reference
+    counting -- not whenever the cyclic garbage collector next runs (a trainer that rebuilds models, or begin_task2's
+    snapshot, would otherwise pile up device memory)."""
+    import gc
+    gc.collect(); torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    gc.disable()
+    try:
+        for _ in range(3):
+            r = _one_step(C, 'fp32', 6, 16, 2, 64)
+            assert torch.cuda.memory_allocated() > base + (1 << 20)
+            del r
+            assert torch.cuda.memory_allocated() <= base + (64 << 10), torch.cuda.memory_allocated() - base
+    finally:
+        gc.enable()
+
+
 def test_gradsync_rccl_world1_on_gpu(C):
     """The RCCL code path of ddp.GradSync (side stream, per-stage buckets, optimiser hook) with a 1-rank "nccl"
     process group on the one GPU of the test box: a world-1 all-reduce is the identity, so loss, gradients and updated
