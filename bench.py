@@ -216,7 +216,8 @@ def main():
                                'launches': n, 'avg_launch_ms': round(sec / n * 1e3, 4),
                                'algorithmic_bytes_per_launch': round(nbytes / n),
                                'ms_per_step': round(sec / 2 * 1e3, 3),
-                               'timing': 'HIP events around every launch, 2 instrumented steps after the timed region'}
+                               'timing': ('HIP events around every launch, 2 instrumented steps after the timed region; those two steps '
+                                          'keep every kernel on one stream (unet.WGRAD_STREAM overlap off), so a launch is timed alone')}
             if wino:
                 # `achieved` / `frac` = EXECUTED multiply-adds (MFMA pipe utilisation); the algorithmic (direct-convolution)
                 # rate is reported beside it

@@ -41,7 +41,7 @@ WINOGRAD24_WGRAD = 'auto'
 # and the HBM-bound BatchNorm passes of the NEXT unit fit beside a weight-gradient workgroup on the same CU (one wave per
 # SIMD, <= 64 registers, <= 8 KB LDS), so they run under the MFMA-bound kernel instead of after it.  Results are unchanged
 # (same kernels, same arguments); joined back before backward() returns.  Off while bench.py times single launches.
-WGRAD_STREAM = True
+WGRAD_STREAM = os.environ.get('CLAMD_WGRAD_STREAM', '1') != '0'      # =0: everything on one stream (kernel-trace profiles)
 
 # bench.py sets this to a list to get per-launch HIP-event timings of the MFMA kernels:
 # entries (tag, algorithmic_flops, start_event, end_event, algorithmic_bytes), recorded on the stream the kernel is
@@ -604,24 +604,25 @@ class _Engine:
                 if t.kind == 'head':
                     call('clamd_nchw_to_nhwc', ptr(gout), ptr(self.dl), self.Kp, B, self.K, H, W, self.Kp, 1.0, dc, s)
                     sw = self._wg_stream_ptr()
+                    # data gradient first (see _conv_bwd)
+                    call('clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], None,
+                         ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
+                         t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cout_p, t.cin_p, 0, dc, s)
                     call('clamd_wgrad', _lib.WGRAD_PW, ptr(self.dl), self.Kp, ptr(t.x), t.x.shape[-1], ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cout_p, t.cin_p, t.cout, t.cin,
                          t.cout, t.cout_p, t.cin, t.cin_p, dc, tp, sw)
                     call('clamd_channel_sum', ptr(self.dl), self.Kp, g[t.keys[1]], B * h * w, self.Kp, t.cout, dc,
                          ptr(self.ws), self.ws_bytes, tp, sw)
-                    call('clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], None,
-                         ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
-                         t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cout_p, t.cin_p, 0, dc, s)
                 else:
                     sw = self._wg_stream_ptr()
+                    call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
+                         ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
+                         t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cin_p, t.cout_p, dc, s)
                     call('clamd_wgrad', _lib.WGRAD_UP2, ptr(t.x), t.x.shape[-1], ptr(t.gy_slice), t.y_ldc, ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cin_p, t.cout_p, t.cin, t.cout,
                          t.cin, t.cin_p, t.cout, t.cout_p, dc, tp, sw)
                     call('clamd_channel_sum', ptr(t.gy_slice), t.y_ldc, g[t.keys[1]], B * 4 * h * w, t.cout_p,
                          t.cout, dc, ptr(self.ws), self.ws_bytes, tp, sw)
-                    call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
-                         ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
-                         t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cin_p, t.cout_p, dc, s)
             for u in reversed(st['convs']):
                 self._conv_bwd(u, s)
             if sync is not None:
@@ -658,7 +659,25 @@ class _Engine:
         else:
             c_seg0, c_seg0p = u.cin, u.cin_p
         flops = 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout
-        sw = self._wg_stream_ptr()
+        sw = self._wg_stream_ptr()          # records "gz is ready" for the second stream (before the data gradient is enqueued)
+
+        def dgrad():
+            _TIMED_UNIT[:] = [u.name + ' dgrad', self.executed_fraction(u, 'dgrad')]
+            if u.g_in is not None and u.wino:
+                _timed('igemm_conv3x3', flops, self._conv_bytes(u),
+                       'clamd_conv3x3_winograd24' if u.w24 else 'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
+                       B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
+            elif u.g_in is not None:
+                _timed('igemm_conv3x3', flops, self._conv_bytes(u),
+                       'clamd_conv3x3', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
+                       ptr(u.consumer.y) if u.consumer is not None else None,
+                       ptr(u.consumer.sums) if u.consumer is not None else None,
+                       u.consumer.sum_rows if u.consumer is not None else 0,
+                       B, u.h, u.w_, u.cout_p, u.cin_p, 0, 1 if 9 * u.cin_p > B * u.h * u.w_ else 0, dc, tp, s)
+
+        # Issue order: data gradient (the critical chain) first; measured, the order makes no difference (693 vs 694 img/s) --
+        # the dispatcher interleaves the workgroups of the two queues either way.
+        dgrad()
         if u.im2col:
             call('clamd_wgrad', _lib.WGRAD_PW, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
                  g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, 9 * u.cin, u.cout, u.cout_p, 9 * u.cin, u.cin_p, dc, tp, sw)
@@ -672,15 +691,3 @@ class _Engine:
             _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
                    'clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
                    g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, dc, tp, sw)
-        _TIMED_UNIT[:] = [u.name + ' dgrad', self.executed_fraction(u, 'dgrad')]
-        if u.g_in is not None and u.wino:
-            _timed('igemm_conv3x3', flops, self._conv_bytes(u),
-                   'clamd_conv3x3_winograd24' if u.w24 else 'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
-                   B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
-        elif u.g_in is not None:
-            _timed('igemm_conv3x3', flops, self._conv_bytes(u),
-                   'clamd_conv3x3', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
-                   ptr(u.consumer.y) if u.consumer is not None else None,
-                   ptr(u.consumer.sums) if u.consumer is not None else None,
-                   u.consumer.sum_rows if u.consumer is not None else 0,
-                   B, u.h, u.w_, u.cout_p, u.cin_p, 0, 1 if 9 * u.cin_p > B * u.h * u.w_ else 0, dc, tp, s)

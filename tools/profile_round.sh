@@ -10,6 +10,11 @@ timeout -k 10 500 python bench.py --steps 10 --warmup 3 --also bf16x3,bf16 > gpu
 # BASELINE.json configs[4] on one GPU (512x512, bs32 per GPU, bf16)
 timeout -k 10 400 python bench.py --steps 5 --warmup 2 --dtype bf16 --also "" --no-cpu-baseline --size 512 --batch 32 > gpurun_out/${tag}_bench_config5_bf16.json 2> gpurun_out/${tag}_bench_config5_bf16.err || exit 1
 echo "bench done"
+# Kernel traces with every kernel on ONE stream (CLAMD_WGRAD_STREAM=0): the same kernels with the same arguments as the
+# two-stream step, but a kernel's begin-to-end time is its own (under the overlap it includes the time it shares the chip with
+# a kernel of the other stream), so the averages agree with the HIP-event timings bench.py takes live.  The fp32 trace is
+# repeated with the overlap on (<tag>_prof_fp32_overlap) to show the concurrency itself.
+export CLAMD_WGRAD_STREAM=0
 for dt in fp32 bf16x3 bf16; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_$dt -o $tag -- python3 bench.py --steps 6 --warmup 2 --dtype $dt --no-cpu-baseline --also "" > gpurun_out/${tag}_bench_${dt}_under_rocprof.json 2> gpurun_out/${tag}_prof_$dt.err || exit 2
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -17,6 +22,8 @@ for dt in fp32 bf16x3 bf16; do
   done
   echo "done $dt"
 done
+unset CLAMD_WGRAD_STREAM
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_fp32_overlap -o $tag -- python3 bench.py --steps 6 --warmup 2 --dtype fp32 --no-cpu-baseline --also "" > gpurun_out/${tag}_bench_fp32_overlap_under_rocprof.json 2> gpurun_out/${tag}_prof_fp32_overlap.err || exit 2
 i=0
 for set in "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS"; do
   i=$((i+1))
