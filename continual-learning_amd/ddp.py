@@ -15,13 +15,13 @@ import torch.distributed as dist
 
 # RCCL runs one workgroup per channel and a channel workgroup keeps its CU for the whole collective.  The MFMA kernels of
 # this library want a whole CU per workgroup, so the channel count is capped: at most 8 CUs are ever taken away, and 8
-# channels move the 124 MB of fp32 gradients of a step in a few ms over xGMI -- far inside the >= 16 ms (fp32) / 4.5 ms
+# channels move the 124 MB of fp32 gradients of a step in a few ms over xGMI -- far inside the >= 14 ms (fp32) / 4 ms
 # (bf16) backward pass they are overlapped with.  Optionally exactly that many CUs can be left out of every grid that is
-# sized to the chip (clamd_tuning::cu_reserve, GradSync(cu_reserve=...) or CLAMD_CU_RESERVE): measured on one GPU with 8 CUs
-# held by a dummy kernel for the WHOLE step (tools/cu_steal.py), the reserve turns 1.69x (fp32) / 1.36x (bf16) into 1.18x /
-# 1.12x -- but it costs those 1.18x / 1.12x ALSO while no collective is in flight (the deep layers have 256-512 equal work
-# items: 248 CUs need an extra round).  It pays when collectives are resident for more than ~26 % (fp32) / ~32 % (bf16) of
-# the step; the estimate for this model is ~10 % / ~34 %, so the default is no reserve.
+# sized to the chip (clamd_tuning::cu_reserve, GradSync(cu_reserve=...) or CLAMD_CU_RESERVE).  Held-CU rehearsal on one GPU
+# (tools/cu_steal.py, 8 CUs held by a dummy kernel for the WHOLE step): with the weight gradients on the
+# engine's second stream the default grids lose 1.39x (fp32) / 1.20x (bf16) while the CUs are held and the reserve changes
+# nothing (two kernels in flight oversubscribe 248 CUs like 256); on one stream it was 1.69x / 1.36x against 1.18x / 1.12x
+# with the reserve.  The default is no reserve.
 RCCL_MAX_CHANNELS = 8
 
 

@@ -50,7 +50,11 @@ L.append(f'# profiles/ — round evidence `{dst}` (MI355X, ROCm 7.2, one GPU)\n'
 L.append('All files come from one `gpurun` box: `bash tools/profile_round.sh <tag>` then `python tools/make_profiles.py <tag> ' + dst + '`.\n')
 L.append('| file | what |\n|---|---|')
 L.append(f'| `{dst}_bench_default.json` | `python bench.py --steps 10 --warmup 3` (the driver\'s command): fp32 headline + `also` bf16x3 / bf16 + `cpu_baseline` |')
-L.append(f'| `{dst}_<dtype>_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 6 --warmup 2 --dtype <dtype> --no-cpu-baseline --also ""` (8 steps + 2 instrumented steps) |')
+L.append(f'| `{dst}_<dtype>_kernel_stats.csv` | `CLAMD_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 6 --warmup 2 --dtype <dtype> --no-cpu-baseline --also ""` (8 steps + 2 instrumented steps).  One stream: the same kernels with the same arguments as the shipped two-stream step, but a kernel\'s begin-to-end time is its own, so the averages agree with the HIP-event timings `bench.py` takes live (its two instrumented steps are single-stream too) |')
+if os.path.exists(f'{G}/{src}_prof_fp32_overlap/{src}_kernel_stats.csv'):
+    shutil.copy(f'{G}/{src}_prof_fp32_overlap/{src}_kernel_stats.csv', f'{P}/{dst}_fp32_overlap_kernel_stats.csv')
+    shutil.copy(f'{G}/{src}_bench_fp32_overlap_under_rocprof.json', f'{P}/{dst}_bench_fp32_overlap_under_rocprof.json')
+    L.append(f'| `{dst}_fp32_overlap_kernel_stats.csv`, `{dst}_bench_fp32_overlap_under_rocprof.json` | the fp32 trace again with the shipped two-stream overlap (weight gradients + filter pack on the second stream): begin-to-end times of kernels that share the chip are longer, the step is shorter |')
 L.append(f'| `{dst}_bench_<dtype>_under_rocprof.json` | the JSON line that same profiled command printed (clocks are lower under the profiler) |')
 L.append(f'| `{dst}_traffic_<dtype>.json` | per-kernel HBM bytes from two separate `--pmc` passes (FETCH_SIZE, WRITE_SIZE), `tools/pmc_summary.py`; FETCH_SIZE doubled per the gfx950 rule in MI355X_MICROARCH.md §HBM |\n')
 L.append('## Headline (un-profiled run)\n')
@@ -68,7 +72,12 @@ if c5:
     L.append(f"BASELINE.json configs[4] on ONE GPU (`{dst}_bench_config5_bf16.json`: 512x512, bs32, bf16): {c5['value']} img/s, "
              f"{c5['ms_per_step']} ms/step, conv3x3 fwd+dgrad {c5['roofline']['achieved']} TF/s = {c5['roofline']['frac']}, "
              f"wgrad {c5['roofline_wgrad']['achieved']} TF/s = {c5['roofline_wgrad']['frac']} of the bf16 MFMA peak.\n")
-L.append('## Time per step by kernel (rocprofv3, 10 steps per profile)\n')
+ov = f'{P}/{dst}_bench_fp32_overlap_under_rocprof.json'
+if os.path.exists(ov):
+    o1, o0 = last_json(ov), last_json(f'{P}/{dst}_bench_fp32_under_rocprof.json')
+    L.append(f"Second stream (weight gradients + Winograd filter pack beside the BatchNorm passes), both under the profiler: "
+             f"{o0['ms_per_step']} ms/step on one stream, {o1['ms_per_step']} ms/step overlapped.\n")
+L.append('## Time per step by kernel (rocprofv3, 10 steps per profile, single-stream traces)\n')
 for dt in DT:
     rows = list(csv.DictReader(open(f'{P}/{dst}_{dt}_kernel_stats.csv')))
     tot = sum(float(x['TotalDurationNs']) for x in rows)
