@@ -603,8 +603,7 @@ class _Engine:
                 h, w = H >> t.level, W >> t.level
                 if t.kind == 'head':
                     call('clamd_nchw_to_nhwc', ptr(gout), ptr(self.dl), self.Kp, B, self.K, H, W, self.Kp, 1.0, dc, s)
-                    sw = self._wg_stream_ptr()
-                    # data gradient first (see _conv_bwd)
+                    sw = self._wg_stream_ptr()      # parameter gradients on the second stream (see _conv_bwd)
                     call('clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], None,
                          ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
                          t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cout_p, t.cin_p, 0, dc, s)
@@ -659,8 +658,6 @@ class _Engine:
         else:
             c_seg0, c_seg0p = u.cin, u.cin_p
         flops = 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout
-        sw = self._wg_stream_ptr()          # records "gz is ready" for the second stream (before the data gradient is enqueued)
-
         def dgrad():
             _TIMED_UNIT[:] = [u.name + ' dgrad', self.executed_fraction(u, 'dgrad')]
             if u.g_in is not None and u.wino:
@@ -675,8 +672,13 @@ class _Engine:
                        u.consumer.sum_rows if u.consumer is not None else 0,
                        B, u.h, u.w_, u.cout_p, u.cin_p, 0, 1 if 9 * u.cin_p > B * u.h * u.w_ else 0, dc, tp, s)
 
-        # Issue order: data gradient (the critical chain) first; measured, the order makes no difference (693 vs 694 img/s) --
-        # the dispatcher interleaves the workgroups of the two queues either way.
+        # The second stream's wait is recorded BEFORE the data gradient is enqueued: both gradients may start once gz is ready.
+        # Measured alternatives (tools/trace_gaps.py on the kernel trace): issue order of the two launches -- no difference, the
+        # dispatcher interleaves the workgroups of the two queues; weight gradient held back until the data gradient has
+        # finished -- fewer intervals without an MFMA kernel (1.80 instead of 2.16 ms per step) but the kernels that then share
+        # the chip with the BatchNorm passes run that much longer: 23.0 ms either way.  Starting early hands the gradients to
+        # RCCL sooner.
+        sw = self._wg_stream_ptr()
         dgrad()
         if u.im2col:
             call('clamd_wgrad', _lib.WGRAD_PW, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
