@@ -18,6 +18,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+    # Before the HIP runtime starts: streams are multiplexed onto this many hardware queues in creation order and a kernel
+    # waits behind whatever shares its queue.  A rank has the default stream, the engine's second stream, GradSync's stream
+    # and whatever RCCL creates; 8 queues keep RCCL's kernels off the two compute queues (no effect at N = 1: measured).
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -25,7 +30,7 @@ import torch.distributed as dist  # noqa: E402
 FLOP_PER_IMAGE_256 = 289_281_146_880          # train step, SURVEY.md §8d / BASELINE.md
 PEAK = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0 / 3}   # dense MFMA TFLOP/s (MI355X_MICROARCH.md:42-43); bf16x3
 #                                                              # issues 3 bf16 MFMAs per algorithmic multiply-add
-DTYPE_NAME = {'fp32': 'f32', 'bf16': 'bf16', 'bf16x3': 'bf16x3 (f32 storage, hi/lo-split bf16 MFMA, f32 accumulate)'}
+DTYPE_NAME = {'fp32': 'f32', 'bf16': 'bf16', 'bf16x3': 'bf16x3 (hi/lo bf16 pair storage, three bf16 MFMAs per product, f32 accumulate)'}
 
 
 def parse():
@@ -94,6 +99,7 @@ def run(args, dtype, rank, world, device, timing=True, dist_on=False):
         comm = dict(C.ddp.rccl_settings(), rccl_ranks=world, collectives_per_step=sync.launches // args.steps,
                     gradient_bytes_per_step=4 * sum(p.numel() for p in model.parameters()),
                     exposed_comm_ms_per_step=round(float(t[1]), 4), cu_reserve=model.tuning.cu_reserve,
+                    wino_persist=model.tuning.wino_persist, GPU_MAX_HW_QUEUES=os.environ.get('GPU_MAX_HW_QUEUES'),
                     note='exposed = HIP-event time the compute stream waits in GradSync.wait() before Adam, max over ranks')
     # Per-launch HIP-event timing of the MFMA kernels: a SEPARATE pass of 2 steps right after the timed region
     # (an event pair around each of ~54 launches per step costs ~5 ms of dispatch bubbles per fp32 step, which would

@@ -603,20 +603,20 @@ class _Engine:
                 h, w = H >> t.level, W >> t.level
                 if t.kind == 'head':
                     call('clamd_nchw_to_nhwc', ptr(gout), ptr(self.dl), self.Kp, B, self.K, H, W, self.Kp, 1.0, dc, s)
-                    sw = self._wg_stream_ptr()      # parameter gradients on the second stream (see _conv_bwd)
                     call('clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], None,
                          ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
                          t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cout_p, t.cin_p, 0, dc, s)
+                    sw = self._wg_stream_ptr()      # parameter gradients on the second stream, behind the data gradient (see _conv_bwd)
                     call('clamd_wgrad', _lib.WGRAD_PW, ptr(self.dl), self.Kp, ptr(t.x), t.x.shape[-1], ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cout_p, t.cin_p, t.cout, t.cin,
                          t.cout, t.cout_p, t.cin, t.cin_p, dc, tp, sw)
                     call('clamd_channel_sum', ptr(self.dl), self.Kp, g[t.keys[1]], B * h * w, self.Kp, t.cout, dc,
                          ptr(self.ws), self.ws_bytes, tp, sw)
                 else:
-                    sw = self._wg_stream_ptr()
                     call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
                          ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
                          t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cin_p, t.cout_p, dc, s)
+                    sw = self._wg_stream_ptr()
                     call('clamd_wgrad', _lib.WGRAD_UP2, ptr(t.x), t.x.shape[-1], ptr(t.gy_slice), t.y_ldc, ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cin_p, t.cout_p, t.cin, t.cout,
                          t.cin, t.cin_p, t.cout, t.cout_p, dc, tp, sw)
@@ -672,14 +672,14 @@ class _Engine:
                        u.consumer.sum_rows if u.consumer is not None else 0,
                        B, u.h, u.w_, u.cout_p, u.cin_p, 0, 1 if 9 * u.cin_p > B * u.h * u.w_ else 0, dc, tp, s)
 
-        # The second stream's wait is recorded BEFORE the data gradient is enqueued: both gradients may start once gz is ready.
-        # Measured alternatives (tools/trace_gaps.py on the kernel trace): issue order of the two launches -- no difference, the
-        # dispatcher interleaves the workgroups of the two queues; weight gradient held back until the data gradient has
-        # finished -- fewer intervals without an MFMA kernel (1.80 instead of 2.16 ms per step) but the kernels that then share
-        # the chip with the BatchNorm passes run that much longer: 23.0 ms either way.  Starting early hands the gradients to
-        # RCCL sooner.
-        sw = self._wg_stream_ptr()
+        # The weight gradient may start once the data gradient of the same unit has FINISHED (the second stream's wait is
+        # recorded behind it).  Started together, the dispatcher interleaves the workgroups of the two kernels, they end together
+        # and the next unit's BatchNorm passes run alone again; started behind it, the weight gradient is what runs beside those
+        # passes (tools/trace_gaps.py: 1.80 instead of 2.16 ms per fp32 step without an MFMA kernel).  A/B in one process:
+        # bf16 +0.7 %, bf16x3 +1.0 %, fp32 unchanged (the kernels that share the chip with the passes run that much longer).
+        # The issue ORDER of the two launches alone makes no difference.
         dgrad()
+        sw = self._wg_stream_ptr()
         if u.im2col:
             call('clamd_wgrad', _lib.WGRAD_PW, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
                  g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, 9 * u.cin, u.cout, u.cout_p, 9 * u.cin, u.cin_p, dc, tp, sw)
