@@ -76,6 +76,42 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
             __hip_atomic_store(dst, old + racc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
+    // Persistent grid: a thread's partial sums of its 4 + 4 channels stay in registers across the tiles of one output slab;
+    // the cross-lane / cross-wave fold (48 shuffles, two barriers, 3.6k cycles: 6 % of a 64-channel tile) runs once per slab
+    // and workgroup instead of once per tile.
+    float st1[2][4], st2[2][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { st1[i >> 2][i & 3] = 0.f; st2[i >> 2][i & 3] = 0.f; }
+    int cur_tn = -1, cur_tm = 0;                 // slab whose sums the registers hold (-1: none), last tile of it
+    // every thread of the workgroup; LDS must be free (called between tiles and after the last one)
+    auto fold_stats = [&]() {
+        // threads with equal (tid & 7) own the same channels: fold the 8 tiles of a wave (lane bits 3-5), then the 4 waves
+        float* sb = reinterpret_cast<float*>(smem);                            // [wave][2][64]
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = st1[nt][c], q = st2[nt][c];
+                a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+                q += __shfl_xor(q, 8); q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+                if (lane < 8) { sb[(w * 2 + 0) * 64 + 32 * nt + 4 * lane + c] = a; sb[(w * 2 + 1) * 64 + 32 * nt + 4 * lane + c] = q; }
+                st1[nt][c] = 0.f; st2[nt][c] = 0.f;
+            }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int k = threadIdx.x >> 6, c = threadIdx.x & 63;
+            const float t = sb[(0 * 2 + k) * 64 + c] + sb[(1 * 2 + k) * 64 + c] + sb[(2 * 2 + k) * 64 + c] + sb[(3 * 2 + k) * 64 + c];
+            if (!per_wg_rows) {
+                if (cur_tn * 64 + c < p.Np) p.stats[((size_t)cur_tm * 2 + k) * p.Np + cur_tn * 64 + c] = t;   // row = pixel tile
+            } else {
+                rslab = cur_tn; racc = t;
+                flush_row();
+            }
+        }
+        __syncthreads();                                                       // the block is free again
+        cur_tn = -1;
+    };
 
     for (int v = blockIdx.x; v < p.nblk; v += gridDim.x) {
         // re-derived per tile from an opaque copy of the thread id (see wino.hip: hoisted constants would spill)
@@ -93,6 +129,7 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
         const int x0 = (tm % tiles_x) * PW, y0 = ((tm / tiles_x) % tiles_y) * PH, b = tm / (tiles_x * tiles_y);
         const int n0 = tn * 64;
         const int nk = p.Kp >> 3;
+        if (cur_tn >= 0 && (tn != cur_tn || !per_wg_rows)) fold_stats();      // workgroup-uniform
 
         // ---- staging descriptors --------------------------------------------------------------------------------------
         const unsigned img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc * 4u;
@@ -233,9 +270,6 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
         const unsigned long long dt3 = W24_T(); (void)dt3;
         float* const ex = reinterpret_cast<float*>(smem);
         const int tl = tid >> 3, ng = tid & 7;                                // reader: tile, 4-channel group
-        float st1[2][4], st2[2][4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { st1[i >> 2][i & 3] = 0.f; st2[i >> 2][i & 3] = 0.f; }
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();
         // data-gradient launches have no bias, ReLU or statistics: 16 VALU per stored float4 less (the wave owns its SIMD, so
         // every VALU instruction of the epilogue is time the matrix pipe idles)
@@ -298,38 +332,14 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
             }
         }
         const unsigned long long dt5 = W24_T(); (void)dt5;
-        if (p.stats) {
-            // threads with equal (tid & 7) own the same channels: fold the 8 tiles of a wave (lane bits 3-5), then the 4 waves
-            __syncthreads();                                                   // every wave has read its exchange blocks
-            float* sb = ex;                                                    // [wave][2][64]
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float a = st1[nt][c], q = st2[nt][c];
-                    a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
-                    q += __shfl_xor(q, 8); q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-                    if (lane < 8) { sb[(w * 2 + 0) * 64 + 32 * nt + 4 * lane + c] = a; sb[(w * 2 + 1) * 64 + 32 * nt + 4 * lane + c] = q; }
-                }
-            __syncthreads();
-            if (tid < 128) {
-                const int k = tid >> 6, c = tid & 63;
-                const float t = sb[(0 * 2 + k) * 64 + c] + sb[(1 * 2 + k) * 64 + c] + sb[(2 * 2 + k) * 64 + c] + sb[(3 * 2 + k) * 64 + c];
-                if (!per_wg_rows) {
-                    if (n0 + c < p.Np) p.stats[((size_t)tm * 2 + k) * p.Np + n0 + c] = t;          // row = pixel tile
-                } else {
-                    if (tn != rslab) { flush_row(); rslab = tn; racc = 0.f; }                      // wave-uniform
-                    racc += t;
-                }
-            }
-        }
+        if (p.stats) { cur_tn = tn; cur_tm = tm; }
         __syncthreads();                                                   // exchange / statistics blocks are free again
         // [0] setup + first loads + first stores  [1] wait first stage + first fragments  [2] K loop  [3] exchange writes + barrier
         // [4] read-back, output transform, stores  [5] statistics  [6] tiles  [7] K chunks
         W24_ADD(0, dt1 - dt0); W24_ADD(1, dt2 - dt1); W24_ADD(2, dt3 - dt2); W24_ADD(3, dt4 - dt3); W24_ADD(4, dt5 - dt4);
         W24_ADD(5, W24_T() - dt5); W24_ADD(6, 1); W24_ADD(7, nk);
     }
-    if (per_wg_rows && threadIdx.x < 128) flush_row();
+    if (cur_tn >= 0) fold_stats();
 }
 
 // ---- filter transform: dst[(k/8)*24 + 6i + j][n][k%8] = (G4 g G6^T)[i][j], row 2 negated (jobs as in wino.hip) ---------
