@@ -113,6 +113,12 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
         cur_tn = -1;
     };
 
+    // Chunks 0 and 1 of the tile about to start.  The first tile of a workgroup loads them in its prologue; every later tile
+    // finds them in these registers: they are requested right behind the previous tile's K loop (the staging registers
+    // of the loop are dead there; the epilogue needs ~60 besides the accumulators), so the one exposed HBM latency per tile -- a
+    // third of the 13k-cycle prologue, tools/w24_diag.py -- is spent under the exchange, read-back, output transform and stores.  (Carrying three chunks across the WHOLE epilogue spilled: 180 registers beside the accumulators.)
+    uint4 pi0[NJI], pw0[NJW], pi1[NJI], pw1[NJW];
+    bool pre = false;
     for (int v = blockIdx.x; v < p.nblk; v += gridDim.x) {
         // re-derived per tile from an opaque copy of the thread id (see wino.hip: hoisted constants would spill)
         int tid = threadIdx.x;
@@ -234,14 +240,15 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
                 for (int nt = 0; nt < 2; ++nt) Bf[j][nt] = sm[wb + j * 2 * W24_WG + 32 * nt];
         };
 
-        {   // prologue: the first three chunks are requested back to back (one memory latency, not three)
-            uint4 ri0[NJI], rw0[NJW], ri1[NJI], rw1[NJW];
-            gload_to(0, true, ri0, rw0);
-            gload_to(1, 1 < nk, ri1, rw1);
-            gload(2, 2 < nk);
-            lds_store_from(0, ri0, rw0);
-            lds_store_from(1, ri1, rw1);
+        // prologue: the first three chunks are requested back to back (one memory latency, not three); chunks 0 and 1 are
+        // usually here already (see above)
+        if (!pre) {                                                           // workgroup-uniform
+            gload_to(0, true, pi0, pw0);
+            gload_to(1, 1 < nk, pi1, pw1);
         }
+        gload(2, 2 < nk);
+        lds_store_from(0, pi0, pw0);
+        lds_store_from(1, pi1, pw1);
         const unsigned long long dt1 = W24_T(); (void)dt1;
         __syncthreads();
         frags(0);
@@ -268,6 +275,46 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
         // ---- epilogue: Y = A4^T M A6, A6^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,0],[0,1,-1,8,-8,1]] in-lane (j -> q),
         // A4^T = [[1,1,1,0],[0,1,-1,-1]] across the four waves through LDS -------------------------------------------------
         const unsigned long long dt3 = W24_T(); (void)dt3;
+        {   // chunks 0 and 1 of this workgroup's next tile (descriptors as at the top of the loop)
+            // issued unconditionally -- behind the last tile with empty descriptors (zeros, no memory traffic) -- so that the
+            // registers are redefined on every path: a conditional prefetch would make their OLD contents live through the
+            // whole tile (the compiler cannot know that "no next tile" ends the loop) and spill
+            const int vn = v + (int)gridDim.x;
+            pre = vn < p.nblk;
+            {
+                const int bidn = xcd_remap(pre ? vn : v, p.nblk);
+                const int bndn = bidn / per_band, remn = bidn - bndn * per_band;
+                const int tnn = bndn * p.band + remn % p.band, tmn = remn / p.band;
+                const int x0n = (tmn % tiles_x) * PW, y0n = ((tmn / tiles_x) % tiles_y) * PH, bn = tmn / (tiles_x * tiles_y);
+#ifdef W24_ABLATE_SAMETILE
+                const __amdgpu_buffer_rsrc_t xrn = pre ? make_rsrc((const char*)p.x, img) : xrs_dead;
+#else
+                const __amdgpu_buffer_rsrc_t xrn = pre ? make_rsrc((const char*)p.x + (size_t)bn * img, img) : xrs_dead;
+#endif
+                const __amdgpu_buffer_rsrc_t wrn = pre ? wrs : wrs_dead;
+#pragma unroll
+                for (int j = 0; j < NJI; ++j) {
+                    int piece = tid + 256 * j;
+                    if (piece >= 2 * PIX) piece -= 2 * PIX;
+                    const int g = piece & 1, pix = piece >> 1;
+                    const int hy = pix / HW_, hx = pix - hy * HW_;
+#ifdef W24_ABLATE_SAMETILE
+                    const int yy = hy - 1, xx = hx - 1;
+#else
+                    const int yy = y0n + hy - 1, xx = x0n + hx - 1;
+#endif
+                    const unsigned vo = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? (unsigned)(((yy * p.W + xx) * p.x_ldc + 4 * g) * 4) : BUF_OOB;
+                    pi0[j] = buf_ld16(xrn, vo, 0u);
+                    pi1[j] = buf_ld16(xrn, vo, 32u);
+                }
+                const unsigned wvn = tnn * 64 + wn_ < p.Np ? (unsigned)(((wxi0 * p.Np + tnn * 64 + wn_) * 8 + 4 * wg_) * 4) : BUF_OOB;
+#pragma unroll
+                for (int j = 0; j < NJW; ++j) {
+                    pw0[j] = buf_ld16(wrn, wvn, j * w_vstep);
+                    pw1[j] = buf_ld16(wrn, wvn, w_chunk + j * w_vstep);
+                }
+            }
+        }
         float* const ex = reinterpret_cast<float*>(smem);
         const int tl = tid >> 3, ng = tid & 7;                                // reader: tile, 4-channel group
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();

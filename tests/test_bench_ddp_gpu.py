@@ -29,7 +29,7 @@ def test_bench_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'weak'
     assert d['config']['global_batch'] == 8 and d['config']['parallelism'] == 'dp2'
-    assert d['value'] == pytest.approx(8 * 3 / (d['ms_per_step'] * 3 / 1e3), rel=1e-3)      # all ranks' images / max-over-ranks time
+    assert d['value'] == pytest.approx(8 * 3 / (d['ms_per_step'] * 3 / 1e3), rel=1e-3, abs=0.006)   # all ranks' images / max-over-ranks time (value is printed with 2 decimals)
     assert 'cpu_baseline' not in d and 'also' not in d                                       # N > 1: headline only
     assert d['config']['final_loss'] == d['config']['final_loss']                            # finite
     c = d['comm']
