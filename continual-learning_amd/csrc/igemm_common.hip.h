@@ -30,9 +30,12 @@ struct IgemmParams {
     long long* pred;
 };
 
+#ifndef IGEMM_PW_NT
+#define IGEMM_PW_NT 2
+#endif
 template <int MODE, int TW> struct Geo {
     static constexpr int TH = 256 / TW;
-    static constexpr int NT = MODE == MODE_CONV3 ? 9 : 2;          // filter slabs per staged K-step
+    static constexpr int NT = MODE == MODE_CONV3 ? 9 : IGEMM_PW_NT; // filter slabs per staged K-step
     static constexpr int NIN = MODE == MODE_CONV3 ? 1 : NT;        // input slabs per staged K-step
     static constexpr int HW_ = MODE == MODE_CONV3 ? TW + 2 : TW;
     static constexpr int HH_ = MODE == MODE_CONV3 ? TH + 2 : TH;
