@@ -113,7 +113,8 @@ class WinoPackTable:
         cin_p = sum(s[1] for s in cin_segs)
         cout_p = cpad(cout)
         seg = (cin_segs[0][0], cin_segs[0][1]) if len(cin_segs) == 2 else (cin, cin_p)
-        self.jobs.append((w.data_ptr(), wf.data_ptr(), cout_p, cin_p, cout, cin, cout, cout_p, seg[0], seg[1], 0, 0))
+        if wf is not None:
+            self.jobs.append((w.data_ptr(), wf.data_ptr(), cout_p, cin_p, cout, cin, cout, cout_p, seg[0], seg[1], 0, 0))
         if wd is not None:
             self.jobs.append((w.data_ptr(), wd.data_ptr(), cin_p, cout_p, cin, cout, seg[0], seg[1], cout, cout_p, 1, 0))
 

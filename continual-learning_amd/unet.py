@@ -282,9 +282,15 @@ class _Engine:
             u.wino = self.wino and not u.im2col and (u.h | u.w_) % 2 == 0 and min(u.h, u.w_) >= 8
             u.w24 = u.wino and bool(WINOGRAD24) and u.w_ % 4 == 0          # forward / data gradient by F(2x4,3x3)
             u.w24g = u.w24 and (min(u.h, u.w_) >= 64 if WINOGRAD24_WGRAD == 'auto' else bool(WINOGRAD24_WGRAD))   # ... weight gradient
+            # ... data gradient: F(2x4) tiles are 256 pixels x 64 (input) channels; a launch with at most half a chip of them runs
+            # the F(2x2) kernel instead, whose 128-pixel tiles give twice the work items (1024 -> 512 @16x16, the data gradient of
+            # dec1.block.0: 128 items, 238 us against 160 us, tools/wino24_ab.py)
+            items24 = B * ((u.h + 7) // 8 * ((u.w_ + 31) // 32) if u.w_ >= 32 else (u.h + 15) // 16 * ((u.w_ + 15) // 16)) * (u.cin_p // 64)
+            u.w24d = u.w24 and not (2 * items24 <= (torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == 'cuda' else 256))
             ntap = 1 if u.im2col else ((24 if u.w24 else 16) if u.wino else 9)   # Winograd: [Cin_p/8][16|24][Cout_p][8] transformed filters
+            ntap_d = (24 if u.w24d else 16) if u.wino else ntap
             u.wf = torch.zeros(ntap * u.cout_p * u.cin_p, dtype=T, device=dev)
-            u.wd = None if first_of_net else torch.zeros(ntap * u.cin_p * u.cout_p, dtype=T, device=dev)
+            u.wd = None if first_of_net else torch.zeros(ntap_d * u.cin_p * u.cout_p, dtype=T, device=dev)
             u.bias_p = torch.zeros(u.cout_p, dtype=torch.float32, device=dev)
             u.vec = torch.zeros(7, u.cout_p, dtype=torch.float32, device=dev)   # scale, shift, mean, istd, k0, k1, k2
             u.m_fastest = 1 if 9 * u.cout_p > B * u.h * u.w_ else 0
@@ -434,7 +440,9 @@ class _Engine:
             if u.im2col:
                 tab.head(u.w, u.wf, None, 9 * u.cin, u.cout)     # [Cout][Cin*9] is already the (c*9 + tap) K order
             elif u.wino:
-                (wtab24 if u.w24 else wtab).conv3x3(u.w, u.wf, u.wd, u.cin_segs, u.cout)
+                (wtab24 if u.w24 else wtab).conv3x3(u.w, u.wf, None, u.cin_segs, u.cout)
+                if u.wd is not None:
+                    (wtab24 if u.w24d else wtab).conv3x3(u.w, None, u.wd, u.cin_segs, u.cout)
             else:
                 tab.conv3x3(u.w, u.wf, u.wd, u.cin_segs, u.cout)
             tab.vector(u.b, u.bias_p, u.cout)
@@ -523,7 +531,7 @@ class _Engine:
         """Multiply-adds the kernel executes per algorithmic (direct-convolution) multiply-add of unit u."""
         if not u.wino:
             return 1.0
-        return 24.0 / 72.0 if (u.w24g if direction == 'wgrad' else u.w24) else 16.0 / 36.0
+        return 24.0 / 72.0 if {'wgrad': u.w24g, 'dgrad': u.w24d}.get(direction, u.w24) else 16.0 / 36.0
 
     def executed_flop_deficit(self):
         """Algorithmic minus executed FLOPs of one train step (3x3 convolutions by Winograd), for bench.py."""
@@ -662,7 +670,7 @@ class _Engine:
             _TIMED_UNIT[:] = [u.name + ' dgrad', self.executed_fraction(u, 'dgrad')]
             if u.g_in is not None and u.wino:
                 _timed('igemm_conv3x3', flops, self._conv_bytes(u),
-                       'clamd_conv3x3_winograd24' if u.w24 else 'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
+                       'clamd_conv3x3_winograd24' if u.w24d else 'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
                        B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
             elif u.g_in is not None:
                 _timed('igemm_conv3x3', flops, self._conv_bytes(u),

@@ -11,7 +11,7 @@ lib, ptr = C._lib, C._lib.ptr
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B = 16
 SH = [(64, 64, 256), (64, 128, 128), (128, 128, 128), (128, 256, 64), (256, 256, 64), (256, 512, 32), (512, 512, 32), (512, 1024, 16),
-      (1024, 1024, 16), (1024, 512, 32), (512, 256, 64), (256, 128, 128), (128, 64, 256)]
+      (1024, 1024, 16), (1024, 512, 16), (1024, 512, 32), (512, 256, 64), (256, 128, 128), (128, 64, 256)]
 tot = {16: 0.0, 24: 0.0}
 print(f'{"layer":>18s} {"F2x2 us":>9s} {"TF/s":>7s} {"F2x4 us":>9s} {"TF/s":>7s} {"speedup":>8s}')
 for cin, cout, hw in SH:
