@@ -268,7 +268,20 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
                 for (int nt = 0; nt < 2; ++nt) mma16<float>(Ac[j], Bc[j][nt], acc[j][nt]);
             lds_store(k % NST);                                               // chunk k+2 over chunk k's stage
             gload(k + 3, k + 3 < nk);
+#ifndef W24_SCHED   // tools/w24_sched_ab.sh: F(2x4) over F(2x2) on the 14 layer shapes 1.158x (0), 1.115x (1), 1.099x (2), 1.030x (3), 1.058x (4)
+#define W24_SCHED 0
+#endif
+#if W24_SCHED == 0
             sched_mfma_slots<48, 24, 25, 25 + NJI + NJW, 30, 30 + NJI + NJW, 2>();
+#elif W24_SCHED == 1   // two reads per slot in the first 12, VALU from slot 4
+            sched_mfma_slots<48, 12, 25, 25 + NJI + NJW, 30, 30 + NJI + NJW, 2, 4, 2>();
+#elif W24_SCHED == 2   // two reads per slot, three VALU per slot from slot 8
+            sched_mfma_slots<48, 12, 25, 25 + NJI + NJW, 30, 30 + NJI + NJW, 3, 8, 2>();
+#elif W24_SCHED == 3   // one read per slot, VALU from slot 4
+            sched_mfma_slots<48, 24, 25, 25 + NJI + NJW, 30, 30 + NJI + NJW, 2, 4, 1>();
+#elif W24_SCHED == 4   // one read per slot, three VALU per slot from slot 12
+            sched_mfma_slots<48, 24, 28, 28 + NJI + NJW, 30, 30 + NJI + NJW, 3, 12, 1>();
+#endif
             __syncthreads();
         }
 
