@@ -220,3 +220,24 @@ def test_abi_rejects_bad_arguments_before_any_launch(C):
             call(name, *args)
         assert needle in str(e.value), (name, str(e.value))
         assert needle in lib.clamd_last_error().decode()
+
+
+def test_bf16x3_plane_layout_helpers_roundtrip():
+    """ops.split_encode / split_decode (host-side mirror of csrc/common.hip.h Vec8<split_t>): per 16-channel group 16 bf16 hi then 16
+    bf16 lo in the bytes of the fp32 tensor; hi = rne_bf16(x), hi + lo reproduces x to ~2^-17; encode(decode(e)) == e; a
+    16-channel-aligned slice decodes on its own."""
+    import torch
+    import continual_learning_amd as C
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 5, 48, generator=g) * 3.0
+    e = C.ops.split_encode(x)
+    assert e.shape == x.shape and e.dtype == torch.float32
+    raw = e.view(torch.int16).reshape(2, 3, 5, 3, 2, 16)
+    hi = (raw[..., 0, :].to(torch.int32) << 16).view(torch.float32).reshape(x.shape)
+    assert torch.equal(hi, x.to(torch.bfloat16).float())
+    d = C.ops.split_decode(e)
+    assert float((d - x).abs().max() / x.abs().max()) < 2.0 ** -16
+    assert torch.equal(C.ops.split_encode(d), e)
+    assert torch.equal(C.ops.split_decode(e[..., 16:32]), d[..., 16:32])
+    z = C.ops.split_encode(torch.zeros(1, 1, 1, 32))
+    assert int(z.view(torch.int32).abs().max()) == 0            # zero padding channels are all-zero bytes
