@@ -224,7 +224,7 @@ def test_abi_rejects_bad_arguments_before_any_launch(C):
 
 def test_bf16x3_plane_layout_helpers_roundtrip():
     """ops.split_encode / split_decode (host-side mirror of csrc/common.hip.h Vec8<split_t>): per 16-channel group 16 bf16 hi then 16
-    bf16 lo in the bytes of the fp32 tensor; hi = rne_bf16(x), hi + lo reproduces x to ~2^-17; encode(decode(e)) == e; a
+    bf16 lo in the bytes of the fp32 tensor; hi = rne_bf16(x), hi + lo reproduces x to ~2^-17 and is a fixed point of decode(encode(.)); a
     16-channel-aligned slice decodes on its own."""
     import torch
     import continual_learning_amd as C
@@ -237,7 +237,7 @@ def test_bf16x3_plane_layout_helpers_roundtrip():
     assert torch.equal(hi, x.to(torch.bfloat16).float())
     d = C.ops.split_decode(e)
     assert float((d - x).abs().max() / x.abs().max()) < 2.0 ** -16
-    assert torch.equal(C.ops.split_encode(d), e)
+    assert torch.equal(C.ops.split_decode(C.ops.split_encode(d)), d)      # hi + lo values are fixed points (the PAIR may differ at a rounding tie)
     assert torch.equal(C.ops.split_decode(e[..., 16:32]), d[..., 16:32])
     z = C.ops.split_encode(torch.zeros(1, 1, 1, 32))
     assert int(z.view(torch.int32).abs().max()) == 0            # zero padding channels are all-zero bytes
