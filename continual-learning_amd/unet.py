@@ -387,7 +387,7 @@ class _Engine:
         self.ws = torch.empty(ws // 4 + 16, dtype=torch.float32, device=dev)
         self.wg_stream = _second_stream(dev) if (WGRAD_STREAM and dev.type == 'cuda') else None
         self._wg_used = False
-        self._pack_pending = False
+        self._pack_pending = 0
         self.ws_bytes = ws
         self._build_pack_table()
         self._ptrs = None
@@ -435,14 +435,18 @@ class _Engine:
     # ------------------------------------------------------------------------------------------ pack table
     def _build_pack_table(self):
         tab = PackTable(self.dcode)
-        wtab, wtab24 = WinoPackTable(16), WinoPackTable(24)
-        for u in self.convs:
+        # Winograd filter transforms in two launches per form: "early" = the first three encoder stages (4 % of the parameters,
+        # needed 0.3 ms into the forward pass), "late" = everything else (first needed by enc4, 2 ms in): the forward pass waits for
+        # a few microseconds of packing instead of for all of it (see forward())
+        wtab = {(pl, late): WinoPackTable(pl) for pl in (16, 24) for late in (False, True)}
+        for i, u in enumerate(self.convs):
+            u.pack_late = i >= 6                                 # units 0-5 = enc1, enc2, enc3
             if u.im2col:
                 tab.head(u.w, u.wf, None, 9 * u.cin, u.cout)     # [Cout][Cin*9] is already the (c*9 + tap) K order
             elif u.wino:
-                (wtab24 if u.w24 else wtab).conv3x3(u.w, u.wf, None, u.cin_segs, u.cout)
+                wtab[(24 if u.w24 else 16, u.pack_late)].conv3x3(u.w, u.wf, None, u.cin_segs, u.cout)
                 if u.wd is not None:
-                    (wtab24 if u.w24d else wtab).conv3x3(u.w, None, u.wd, u.cin_segs, u.cout)
+                    wtab[(24 if u.w24d else 16, u.pack_late)].conv3x3(u.w, None, u.wd, u.cin_segs, u.cout)
             else:
                 tab.conv3x3(u.w, u.wf, u.wd, u.cin_segs, u.cout)
             tab.vector(u.b, u.bias_p, u.cout)
@@ -456,8 +460,9 @@ class _Engine:
                 tab.head(t.w, t.wf, t.wd, t.cin, t.cout)
             tab.vector(t.b, t.bias_p, t.cout)
         self.pack_table = tab.finalize(self.dev)
-        self.wino_table = wtab.finalize(self.dev) if wtab.jobs else None
-        self.wino24_table = wtab24.finalize(self.dev) if wtab24.jobs else None
+        self.wino_early = [t.finalize(self.dev) for (pl, late), t in wtab.items() if t.jobs and not late]
+        self.wino_late = [t.finalize(self.dev) for (pl, late), t in wtab.items() if t.jobs and late]
+        self._ev_early = torch.cuda.Event() if self.dev.type == 'cuda' else None
         self._param_ptrs = [p.data_ptr() for p in self.model.parameters()]
 
     def _check_ptrs(self, params):
@@ -486,15 +491,17 @@ class _Engine:
         self.pack_table.run(dc, s)
         # the Winograd filter transforms (454 MB of HBM traffic per step at config 2) are first needed by the SECOND convolution:
         # they run on the second stream under the first layer's im2col / pointwise conv / BatchNorm passes
-        self._pack_pending = False
+        self._pack_pending = 0               # 2: neither part waited for yet, 1: the early part has been waited for
         sp = s
-        if self.wg_stream is not None and KERNEL_TIMING is None and (self.wino_table is not None or self.wino24_table is not None):
+        if self.wg_stream is not None and KERNEL_TIMING is None and (self.wino_early or self.wino_late):
             self.wg_stream.wait_stream(torch.cuda.current_stream())
-            sp, self._pack_pending = self.wg_stream.cuda_stream, True
-        if self.wino_table is not None:
-            self.wino_table.run(sp)
-        if self.wino24_table is not None:
-            self.wino24_table.run(sp)
+            sp, self._pack_pending = self.wg_stream.cuda_stream, 2
+        for t in self.wino_early:
+            t.run(sp)
+        if self._pack_pending:
+            self._ev_early.record(self.wg_stream)
+        for t in self.wino_late:
+            t.run(sp)
         if self.convs[0].im2col:
             call('clamd_nchw_im2col3', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
                  self.x_in.shape[-1], dc, s)
@@ -519,9 +526,9 @@ class _Engine:
                 logits = torch.empty(B, self.K, H, W, dtype=torch.float32, device=self.dev)
                 call('clamd_conv1x1_logits', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(logits), B, h, w,
                      t.cin_p, t.cout_p, self.K, dc, s)
-        if self._pack_pending:          # no Winograd layer ran (cannot happen with the shapes that build the tables; stay safe)
+        if self._pack_pending:          # some part was never waited for (no late Winograd layer in this net): join before returning
             torch.cuda.current_stream().wait_stream(self.wg_stream)
-            self._pack_pending = False
+            self._pack_pending = 0
         if training:
             torch._foreach_add_(self.nbts, 1)
         return logits
@@ -555,9 +562,12 @@ class _Engine:
             call('clamd_conv1x1', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
                  ptr(u.stats) if training else None, None, None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
         elif u.wino:
-            if self._pack_pending:
+            if self._pack_pending == 2:
+                torch.cuda.current_stream().wait_event(self._ev_early)
+                self._pack_pending = 1
+            if self._pack_pending == 1 and u.pack_late:
                 torch.cuda.current_stream().wait_stream(self.wg_stream)
-                self._pack_pending = False
+                self._pack_pending = 0
             _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
                    'clamd_conv3x3_winograd24' if u.w24 else 'clamd_conv3x3_winograd', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
                    ptr(u.stats) if training else None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
@@ -584,7 +594,7 @@ class _Engine:
         m = self.model
         s = _lib.stream_ptr()
         self._wg_used = False
-        self._pack_pending = False
+        self._pack_pending = 0
         B, H, W, dc = self.B, self.H, self.W, self.dcode
         if not self.fwd_training:
             raise RuntimeError('UNet.backward after an eval-mode forward is not supported (BatchNorm backward uses batch statistics)')

@@ -156,7 +156,8 @@ def test_engine_geometry_and_pack_table(C):
     assert len(wino_units) == 15 and all(min(u.h, u.w_) >= 8 for u in wino_units)
     w24 = [u for u in wino_units if u.w24]
     assert len(w24) == 15                                   # every width here (64 ... 8) is a multiple of 4: F(2x4,3x3)
-    nw = len(e.wino24_table.jobs) + (len(e.wino_table.jobs) if e.wino_table is not None else 0)
+    nw = sum(len(t.jobs) for t in e.wino_early + e.wino_late)          # two launches per form: enc1-enc3 first, the rest behind
+    assert sum(len(t.jobs) for t in e.wino_early) == 2 * sum(1 for u in wino_units if not u.pack_late)
     assert nw == 2 * len(wino_units)
     assert len(jobs) + nw == 18 * 3 - 1 + 5 * 3
     assert e.pack_table.nblocks == sum(((j[3] + 31) // 32) * ((j[4] + 31) // 32) for j in jobs)
