@@ -57,6 +57,7 @@ if os.path.exists(f'{G}/{src}_prof_fp32_overlap/{src}_kernel_stats.csv'):
     L.append(f'| `{dst}_fp32_overlap_kernel_stats.csv`, `{dst}_bench_fp32_overlap_under_rocprof.json` | the fp32 trace again with the shipped two-stream overlap (weight gradients + filter pack on the second stream): begin-to-end times of kernels that share the chip are longer, the step is shorter |')
 L.append(f'| `{dst}_bench_<dtype>_under_rocprof.json` | the JSON line that same profiled command printed (clocks are lower under the profiler) |')
 L.append(f'| `{dst}_traffic_<dtype>.json` | per-kernel HBM bytes from two separate `--pmc` passes (FETCH_SIZE, WRITE_SIZE), `tools/pmc_summary.py`; FETCH_SIZE doubled per the gfx950 rule in MI355X_MICROARCH.md §HBM |\n')
+L.append(f'| `{dst}_trace_gaps_<dtype>.txt` | `tools/trace_gaps.py` on a two-stream `rocprofv3 --kernel-trace` of `bench.py --steps 4 --warmup 1 --dtype <dtype> --no-kernel-timing`: the intervals of one step in which no convolution / weight-gradient kernel is running, and what runs instead |\n')
 L.append('## Headline (un-profiled run)\n')
 L.append('| dtype | images/s | ms/step | step FLOP/s ÷ MFMA peak | conv3x3 fwd+dgrad kernels | conv3x3 wgrad (+reduce) |\n|---|---|---|---|---|---|')
 r, w = b['roofline'], b['roofline_wgrad']
