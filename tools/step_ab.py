@@ -39,4 +39,4 @@ for rd in range(5):
         for _ in range(10): loss = step()
         torch.cuda.synchronize()
         best[str(v)] = min(best[str(v)], (time.perf_counter() - t0) / 10)
-print(dtype, attr, '  '.join(f'{k}: {t * 1e3:.3f} ms/step ({16 / t:.1f} img/s)' for k, t in best.items()), f'loss {float(loss):.4f}')
+print(dtype, attr, '  '.join(f'{k}: {t * 1e3:.3f} ms/step ({16 / t:.1f} img/s)' for k, t in best.items()), f'loss {float(loss.detach()):.4f}')
