@@ -499,9 +499,10 @@ class _Engine:
         for t in self.wino_early:
             t.run(sp)
         if self._pack_pending:
-            self._ev_early.record(self.wg_stream)
-        for t in self.wino_late:
-            t.run(sp)
+            self._ev_early.record(self.wg_stream)        # the late part is enqueued in front of the first Winograd convolution
+        else:
+            for t in self.wino_late:
+                t.run(sp)
         if self.convs[0].im2col:
             call('clamd_nchw_im2col3', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
                  self.x_in.shape[-1], dc, s)
@@ -526,6 +527,9 @@ class _Engine:
                 logits = torch.empty(B, self.K, H, W, dtype=torch.float32, device=self.dev)
                 call('clamd_conv1x1_logits', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(logits), B, h, w,
                      t.cin_p, t.cout_p, self.K, dc, s)
+        if self._pack_pending == 2:     # no Winograd layer ran at all: the late part was never enqueued
+            for t in self.wino_late:
+                t.run(self.wg_stream.cuda_stream)
         if self._pack_pending:          # some part was never waited for (no late Winograd layer in this net): join before returning
             torch.cuda.current_stream().wait_stream(self.wg_stream)
             self._pack_pending = 0
@@ -563,7 +567,12 @@ class _Engine:
                  ptr(u.stats) if training else None, None, None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
         elif u.wino:
             if self._pack_pending == 2:
+                # the late transforms (HBM-bound, 0.15 ms) start here, under this MFMA-bound convolution, instead of beside the
+                # HBM-bound first-layer kernels
                 torch.cuda.current_stream().wait_event(self._ev_early)
+                self.wg_stream.wait_stream(torch.cuda.current_stream())
+                for t in self.wino_late:
+                    t.run(self.wg_stream.cuda_stream)
                 self._pack_pending = 1
             if self._pack_pending == 1 and u.pack_late:
                 torch.cuda.current_stream().wait_stream(self.wg_stream)
