@@ -1,0 +1,686 @@
+// Winograd F(2x4,3x3) with PRE-TRANSFORMED operands for the wide (>= 256-channel) 3x3 convolutions of the exact-fp32 path
+// (models/unet.py:28-33,50-55: enc3/enc4/dec1/dec2/dec3; loss.backward(), trainer.py:175).
+//
+// wino24.hip forms B^T d B inside the K loop of EVERY output-slab workgroup (8-16x per tile on the 512/1024-channel layers)
+// and wino24_wgrad.hip transforms both operands in its loop: 2-3.5 VALU and 0.5-2.3 LDS instructions per fp32 MFMA, each of
+// which costs matrix-pipe time on gfx950.  Here the transforms run ONCE per tensor in HBM-bound
+// kernels and the MFMA kernels read their operands from memory in fragment layout:
+//
+//   * wino24_xform_kernel: x [B,H,W,ldc] -> V [tile block][Kp/8][24 = 6i + j][2 = lane half][32 tiles][4 channels], the image
+//     wino24_kernel's in-lane transform produces (same formulas, same row-2 sign convention), so the filters of
+//     clamd_wino24_pack serve both kernels and the results are BIT-IDENTICAL to clamd_conv3x3_winograd24;
+//   * wino24g_kernel: wino24_kernel's tile / wave decomposition (wave w = Winograd row i, six j in-lane, 32 tiles x 64 output
+//     channels per workgroup, same epilogue, same statistics rows), but the K loop is 48 MFMAs + 18 buffer_load_dwordx4
+//     straight into the MFMA operand registers: no LDS, no barrier, no VALU.  Nothing is shared between the four waves of a
+//     workgroup inside the loop (each row i has its own slice of V and of the filters), so there is nothing to stage.  The
+//     load stream runs NSET chunks ahead and is continuous across the tiles of the persistent loop (the last chunks of a
+//     tile fetch the first chunks of the next one, whose latency then hides under the epilogue);
+//   * weight gradient: dU[p] = Yt[p]^T Vx[p] for the 24 planes as a batched GEMM with K = Winograd tiles.  Two transform
+//     kernels write Yt = A4 dY A6^T [24][Tp][Rp] and Vx = B4^T d B6 [24][Tp][Cp]; wino24g_wgrad_kernel gives every WAVE a
+//     128 x 128 block of one plane: a lane loads 16 bytes = 4 channels of one tile of each operand and issues the 4 x 4
+//     outer product as 16 MFMAs (k = 2 tiles), 256 accumulator registers, 2 loads per 16 MFMAs, no LDS, no barrier; the
+//     four waves of a workgroup take the 2 x 2 blocks of a 256 x 256 block so that operand panels are shared in L1.
+//     Split-K over tile ranges into fp32 slabs [split][24][Rp][Cp], fixed-order reduce with G4^T . G6 (deterministic).
+#include <string.h>
+#include <algorithm>
+#include "common.hip.h"
+#include "clamd_internal.h"
+#include "wino_common.hip.h"
+
+namespace clamd {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// input transform (forward / data gradient)
+// ---------------------------------------------------------------------------------------------------------------------
+struct W24XformParams {
+    const float* x; int x_ldc;
+    float* v;
+    int B, H, W, Kp;
+};
+
+// B6^T of one transformed row t[0..5] (float4 = 4 channels): the formulas of wino24_kernel's W24_COL, so that V is
+// bit-identical to the in-kernel transform
+#define W24G_COLS(t_, o_)                                                                                          \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                         \
+            const float t0_ = t_[0][e_], t1_ = t_[1][e_], t2_ = t_[2][e_], t3_ = t_[3][e_], t4_ = t_[4][e_], t5_ = t_[5][e_]; \
+            const float pq_ = fmaf(-4.f, t2_, t4_), qq_ = fmaf(-4.f, t1_, t3_);                                    \
+            const float rr_ = t4_ - t2_, ss_ = t3_ - t1_;                                                          \
+            o_[0][e_] = fmaf(4.f, t0_, fmaf(-5.f, t2_, t4_));                                                      \
+            o_[1][e_] = pq_ + qq_; o_[2][e_] = pq_ - qq_;                                                          \
+            o_[3][e_] = fmaf(2.f, ss_, rr_); o_[4][e_] = fmaf(-2.f, ss_, rr_);                                     \
+            o_[5][e_] = fmaf(4.f, t1_, fmaf(-5.f, t3_, t5_));                                                      \
+        }                                                                                                          \
+    } while (0)
+
+// One wave = one (tile block, 8-channel chunk): lane (h = lane >> 5, r = lane & 31) reads the 4 x 6 input patch of tile r,
+// channels 4h..4h+3 of the chunk, and writes its 16 bytes of each of the 24 planes: every store instruction of the wave is
+// one contiguous 1-KB unit [h][r][4] -- exactly what one buffer_load_dwordx4 of wino24g_kernel fetches.
+template <int TXN>
+__global__ void __launch_bounds__(256) wino24_xform_kernel(const W24XformParams p) {
+    constexpr int TYN = 32 / TXN, PW = 4 * TXN, PH = 2 * TYN;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nk = p.Kp >> 3, nkg = (nk + 3) >> 2;
+    const int tiles_x = (p.W + PW - 1) / PW, tiles_y = (p.H + PH - 1) / PH;
+    const int ntm = tiles_x * tiles_y * p.B;
+    // neighbouring tile blocks (shared halo rows / columns) get neighbouring ids inside one XCD's range
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int kg = bid / ntm, tm = bid - kg * ntm;
+    const int kc = kg * 4 + w;
+    if (kc >= nk) return;                                              // whole wave; the kernel has no barrier
+    (void)nkg;
+    const int x0 = (tm % tiles_x) * PW, y0 = ((tm / tiles_x) % tiles_y) * PH, b = tm / (tiles_x * tiles_y);
+    const int ty = r / TXN, tx = r % TXN;
+    const int py = y0 + 2 * ty - 1, px = x0 + 4 * tx - 1;
+    const unsigned img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc * 4u;
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x + (size_t)b * img, img);
+    float4 d[4][6];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int yy = py + a, xx = px + c;
+            const unsigned vo = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? (unsigned)(((yy * p.W + xx) * p.x_ldc + kc * 8 + 4 * h) * 4) : BUF_OOB;
+            const uint4 u = buf_ld16(xrs, vo, 0u);
+            d[a][c] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+        }
+    float* const dst = p.v + (((size_t)tm * nk + kc) * 24) * 256 + h * 128 + r * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // row i of the vertical F(2,3): t = d[a1] + s2 * d[a2] (row 2 carries the opposite sign; it is in the packed filters)
+        const int a1 = i == 0 ? 0 : 1, a2 = i == 3 ? 3 : 2;
+        const float s2 = i == 1 ? 1.f : -1.f;
+        float t[6][4], o[6][4];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            t[c][0] = fmaf(s2, d[a2][c].x, d[a1][c].x); t[c][1] = fmaf(s2, d[a2][c].y, d[a1][c].y);
+            t[c][2] = fmaf(s2, d[a2][c].z, d[a1][c].z); t[c][3] = fmaf(s2, d[a2][c].w, d[a1][c].w);
+        }
+        W24G_COLS(t, o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            *reinterpret_cast<float4*>(dst + (6 * i + j) * 256) = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward / data-gradient kernel on the transformed input
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int W24G_EXP = 36;                                  // row pitch (floats) of the epilogue exchange block
+
+template <int TXN, bool RAGGED, int NSET>
+__global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
+    constexpr int TYN = 32 / TXN;
+    constexpr int PW = 4 * TXN, PH = 2 * TYN;
+    constexpr int EXB = 4 * 4 * 32 * W24G_EXP;                            // floats of one nt exchange block [wave][q][tile][EXP]
+    constexpr int LDS = 2 * EXB * 4 / 16;
+    static_assert(LDS * 16 <= 160 * 1024, "LDS budget");
+    __shared__ uint4 smem[LDS];
+
+    // statistics rows: exactly wino24_kernel's scheme (per-workgroup rows on the persistent grid, registers across the tiles
+    // of one output slab, one fold per slab) -- the two kernels are interchangeable for bn_finalize
+    const bool per_wg_rows = p.stats != nullptr && gridDim.x < (unsigned)p.nblk;
+    if (per_wg_rows && threadIdx.x < 128)
+        for (int n = threadIdx.x & 63; n < p.Np; n += 64) p.stats[((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * p.Np + n] = 0.f;
+    float racc = 0.f;
+    int rslab = -1;
+    auto flush_row = [&]() {
+        if (rslab >= 0 && rslab * 64 + (int)(threadIdx.x & 63) < p.Np) {
+            float* dst = p.stats + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * p.Np + rslab * 64 + (threadIdx.x & 63);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst, old + racc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    float st1[2][4], st2[2][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { st1[i >> 2][i & 3] = 0.f; st2[i >> 2][i & 3] = 0.f; }
+    int cur_tn = -1, cur_tm = 0;
+    auto fold_stats = [&]() {
+        float* sb = reinterpret_cast<float*>(smem);                            // [wave][2][64]
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = st1[nt][c], q = st2[nt][c];
+                a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+                q += __shfl_xor(q, 8); q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+                if (lane < 8) { sb[(w * 2 + 0) * 64 + 32 * nt + 4 * lane + c] = a; sb[(w * 2 + 1) * 64 + 32 * nt + 4 * lane + c] = q; }
+                st1[nt][c] = 0.f; st2[nt][c] = 0.f;
+            }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int k = threadIdx.x >> 6, c = threadIdx.x & 63;
+            const float t = sb[(0 * 2 + k) * 64 + c] + sb[(1 * 2 + k) * 64 + c] + sb[(2 * 2 + k) * 64 + c] + sb[(3 * 2 + k) * 64 + c];
+            if (!per_wg_rows) {
+                if (cur_tn * 64 + c < p.Np) p.stats[((size_t)cur_tm * 2 + k) * p.Np + cur_tn * 64 + c] = t;
+            } else {
+                rslab = cur_tn; racc = t;
+                flush_row();
+            }
+        }
+        __syncthreads();
+        cur_tn = -1;
+    };
+
+    const int tiles_x = (p.W + PW - 1) / PW, tiles_y = (p.H + PH - 1) / PH;
+    const int ntn = p.Np >> 6;                                              // Np % 64 == 0 (checked on entry)
+    const int nk = p.Kp >> 3;                                               // nk % NSET == 0, nk >= 2 NSET (checked on entry)
+    const int per_band = (p.nblk / ntn) * p.band;
+    // one descriptor each for all of V and all of the filters: everything tile-dependent is a scalar offset
+    const __amdgpu_buffer_rsrc_t vrs = make_rsrc(p.x, (unsigned)((size_t)(p.nblk / ntn) * nk * 24 * 1024));
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.w, (unsigned)(24u * p.Np * p.Kp * 4u));
+    const __amdgpu_buffer_rsrc_t vrs_dead = make_rsrc(p.x, 0u), wrs_dead = make_rsrc(p.w, 0u);
+    const unsigned ustride = (unsigned)p.Np * 32u;                          // bytes of one (chunk, plane) of the filters
+    auto decode = [&](int v, int& tn, int& tm) {
+        const int bid = xcd_remap(v, p.nblk);
+        const int bnd = bid / per_band, rem = bid - bnd * per_band;
+        tn = bnd * p.band + rem % p.band; tm = rem / p.band;
+    };
+
+    uint4 A[NSET][6], Bq[NSET][6][2];
+    bool pre = false;
+    for (int v = blockIdx.x; v < p.nblk; v += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));                                        // per-tile re-derivation (see wino.hip: hoisted constants spill)
+        const int lane = tid & 63;
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int r = lane & 31, h = lane >> 5;
+        int tn, tm;
+        decode(v, tn, tm);
+        const int x0 = (tm % tiles_x) * PW, y0 = ((tm / tiles_x) % tiles_y) * PH, b = tm / (tiles_x * tiles_y);
+        const int n0 = tn * 64;
+        if (cur_tn >= 0 && (tn != cur_tn || !per_wg_rows)) fold_stats();      // workgroup-uniform
+
+        // the tile after this one (the load stream does not stop at a tile boundary)
+        const int vn = v + (int)gridDim.x;
+        const bool has_next = vn < p.nblk;
+        int tnn, tmn;
+        decode(has_next ? vn : v, tnn, tmn);
+
+        const unsigned a_vo = (unsigned)(h * 512 + r * 16);
+        const unsigned b_vo = (unsigned)((r * 8 + 4 * h) * 4);
+        const unsigned plane0 = (unsigned)(w * 6);
+        const unsigned vb_cur = (unsigned)tm * (unsigned)nk * 24u * 1024u, vb_nxt = (unsigned)tmn * (unsigned)nk * 24u * 1024u;
+        const unsigned ub_cur = (unsigned)n0 * 32u, ub_nxt = (unsigned)tnn * 64u * 32u;
+
+        // all of chunk k (of the tile whose bases are vb / ub) into register set s
+        auto load_j = [&](int s, int j, __amdgpu_buffer_rsrc_t vr, __amdgpu_buffer_rsrc_t ur, unsigned vb, unsigned ub, int k) {
+            const unsigned pl = (unsigned)k * 24u + plane0 + (unsigned)j;
+            A[s][j] = buf_ld16(vr, a_vo, vb + pl * 1024u);
+            Bq[s][j][0] = buf_ld16(ur, b_vo, ub + pl * ustride);
+            Bq[s][j][1] = buf_ld16(ur, b_vo, ub + pl * ustride + 1024u);
+        };
+
+        f32x16 acc[6][2];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+
+        if (!pre) {                                                           // first tile of this workgroup
+#pragma unroll
+            for (int s = 0; s < NSET; ++s)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    load_j(s, j, vrs, wrs, vb_cur, ub_cur, s);
+                    asm volatile("" ::: "memory");                             // ring order (see wino24g_wgrad_kernel)
+                }
+        }
+        // chunks [0, nk - NSET): every set is refilled from THIS tile
+        for (int k = 0; k < nk - NSET; k += NSET) {
+#pragma unroll
+            for (int s = 0; s < NSET; ++s)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    mma16<float>(A[s][j], Bq[s][j][0], acc[j][0]);
+                    mma16<float>(A[s][j], Bq[s][j][1], acc[j][1]);
+                    load_j(s, j, vrs, wrs, vb_cur, ub_cur, k + s + NSET);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+                }
+        }
+        // last NSET chunks: the sets are refilled with chunks 0..NSET-1 of the next tile (an empty descriptor behind the last
+        // tile: zeros, no traffic -- the registers are redefined on every path)
+        {
+            const __amdgpu_buffer_rsrc_t vr = has_next ? vrs : vrs_dead, ur = has_next ? wrs : wrs_dead;
+#pragma unroll
+            for (int s = 0; s < NSET; ++s)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    mma16<float>(A[s][j], Bq[s][j][0], acc[j][0]);
+                    mma16<float>(A[s][j], Bq[s][j][1], acc[j][1]);
+                    load_j(s, j, vr, ur, vb_nxt, ub_nxt, s);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+                }
+            pre = has_next;
+        }
+
+        // ---- epilogue: wino24_kernel's.  Y = A4^T M A6: A6^T in-lane (j -> q), A4^T across the four waves through LDS ----------
+        float* const ex = reinterpret_cast<float*>(smem);
+        const int tl = tid >> 3, ng = tid & 7;                                // reader: tile, 4-channel group
+        const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+        const bool plain = !p.relu && !p.bias && !p.stats;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float* const exb = ex + nt * EXB;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float m0 = acc[0][nt][e], m1 = acc[1][nt][e], m2 = acc[2][nt][e], m3 = acc[3][nt][e], m4 = acc[4][nt][e],
+                            m5 = acc[5][nt][e];
+                const float sa = m1 + m2, sb = m1 - m2, sc = m3 + m4, sd = m3 - m4;
+                const int row = acc_row(e, h);
+                exb[((w * 4 + 0) * 32 + row) * W24G_EXP + r] = m0 + sa + sc;
+                exb[((w * 4 + 1) * 32 + row) * W24G_EXP + r] = fmaf(2.f, sd, sb);
+                exb[((w * 4 + 2) * 32 + row) * W24G_EXP + r] = fmaf(4.f, sc, sa);
+                exb[((w * 4 + 3) * 32 + row) * W24G_EXP + r] = fmaf(8.f, sd, sb) + m5;
+            }
+        }
+        __syncthreads();
+        const int oty = tl / TXN, otx = tl % TXN;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float* const exb = ex + nt * EXB;
+            const int n = n0 + 32 * nt + 4 * ng;
+            float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias && n < p.Np) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 R[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) R[i] = *reinterpret_cast<const float4*>(exb + ((i * 4 + q) * 32 + tl) * W24G_EXP + 4 * ng);
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    float4 o;
+                    if (pp == 0) {
+                        o.x = R[0].x + R[1].x + R[2].x; o.y = R[0].y + R[1].y + R[2].y;
+                        o.z = R[0].z + R[1].z + R[2].z; o.w = R[0].w + R[1].w + R[2].w;
+                    } else {
+                        o.x = R[1].x - R[2].x - R[3].x; o.y = R[1].y - R[2].y - R[3].y;
+                        o.z = R[1].z - R[2].z - R[3].z; o.w = R[1].w - R[2].w - R[3].w;
+                    }
+                    if (!plain) {
+                        o.x = fmaxf(o.x + bias4.x, relu_lo); o.y = fmaxf(o.y + bias4.y, relu_lo);
+                        o.z = fmaxf(o.z + bias4.z, relu_lo); o.w = fmaxf(o.w + bias4.w, relu_lo);
+                    }
+                    const int yy = y0 + 2 * oty + pp, xx = x0 + 4 * otx + q;
+                    if (!RAGGED || (yy < p.H && xx < p.W)) {
+                        *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = o;
+                        if (!plain) {
+                            st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
+                            st2[nt][0] = fmaf(o.x, o.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, o.y, st2[nt][1]);
+                            st2[nt][2] = fmaf(o.z, o.z, st2[nt][2]); st2[nt][3] = fmaf(o.w, o.w, st2[nt][3]);
+                        }
+                    }
+                }
+            }
+        }
+        if (p.stats) { cur_tn = tn; cur_tm = tm; }
+        __syncthreads();                                                   // exchange / statistics blocks are free again
+    }
+    if (cur_tn >= 0) fold_stats();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradient: operand transforms
+// ---------------------------------------------------------------------------------------------------------------------
+struct W24WgXformParams {
+    const float* src; int ldc;
+    float* dst;                      // [24][Tp][Cp]
+    int B, H, W, Cp, T, Tp;
+};
+
+// thread = (tile, 4-channel group), channel groups fastest: reads and writes are both contiguous along the channels.
+// SIDE 0: Yt = A4 dY A6^T of the 2 x 4 gradient tile; SIDE 1: Vx = B4^T d B6 of the 4 x 6 input patch (zero padding).
+// Exact textbook matrices (no folded signs): the reduce applies plain G4^T . G6.
+template <int SIDE>
+__global__ void __launch_bounds__(256) wino24g_wgrad_xform_kernel(const W24WgXformParams p) {
+    const int ng = p.Cp >> 2;
+    const long long total = (long long)p.Tp * ng;
+    const int tw = p.W >> 2, th = p.H >> 1;
+    const unsigned img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.ldc * 4u;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int g = (int)(idx % ng);
+        const int t = (int)(idx / ng);
+        float* const dst = p.dst + (size_t)t * p.Cp + 4 * g;
+        const size_t ps = (size_t)p.Tp * p.Cp;
+        if (t >= p.T) {                                                    // padding tiles: zeros (they contribute nothing)
+#pragma unroll
+            for (int pl = 0; pl < 24; ++pl) *reinterpret_cast<float4*>(dst + pl * ps) = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        const int tx = t % tw, ty = (t / tw) % th, b = t / (tw * th);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc((const char*)p.src + (size_t)b * img, img);
+        if constexpr (SIDE == 0) {
+            float gq[2][4][4];                                             // [row][column][channel]
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint4 u = buf_ld16(rs, (unsigned)((((2 * ty + a) * p.W + 4 * tx + q) * p.ldc + 4 * g) * 4), 0u);
+                    gq[a][q][0] = __uint_as_float(u.x); gq[a][q][1] = __uint_as_float(u.y);
+                    gq[a][q][2] = __uint_as_float(u.z); gq[a][q][3] = __uint_as_float(u.w);
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // A4 = [[1,0],[1,1],[1,-1],[0,-1]]
+                float z[4][4], o[6][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        z[q][e] = i == 0 ? gq[0][q][e] : (i == 1 ? gq[0][q][e] + gq[1][q][e] : (i == 2 ? gq[0][q][e] - gq[1][q][e] : -gq[1][q][e]));
+                // A6 = [[1,0,0,0],[1,1,1,1],[1,-1,1,-1],[1,2,4,8],[1,-2,4,-8],[0,0,0,1]]
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sa = z[0][e] + z[2][e], sb = z[1][e] + z[3][e], sc = fmaf(4.f, z[2][e], z[0][e]), sd = fmaf(4.f, z[3][e], z[1][e]);
+                    o[0][e] = z[0][e]; o[1][e] = sa + sb; o[2][e] = sa - sb;
+                    o[3][e] = fmaf(2.f, sd, sc); o[4][e] = fmaf(-2.f, sd, sc); o[5][e] = z[3][e];
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(dst + (6 * i + j) * ps) = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
+            }
+        } else {
+            float4 d[4][6];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const int yy = 2 * ty - 1 + a, xx = 4 * tx - 1 + c;
+                    const unsigned vo = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? (unsigned)(((yy * p.W + xx) * p.ldc + 4 * g) * 4) : BUF_OOB;
+                    const uint4 u = buf_ld16(rs, vo, 0u);
+                    d[a][c] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // B4^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
+                const int a1 = i == 0 ? 0 : (i == 2 ? 2 : 1), a2 = i == 0 ? 2 : (i == 1 ? 2 : (i == 2 ? 1 : 3));
+                const float s2 = i == 1 ? 1.f : -1.f;
+                float t[6][4], o[6][4];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    t[c][0] = fmaf(s2, d[a2][c].x, d[a1][c].x); t[c][1] = fmaf(s2, d[a2][c].y, d[a1][c].y);
+                    t[c][2] = fmaf(s2, d[a2][c].z, d[a1][c].z); t[c][3] = fmaf(s2, d[a2][c].w, d[a1][c].w);
+                }
+                W24G_COLS(t, o);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(dst + (6 * i + j) * ps) = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradient: batched GEMM over the 24 planes, K = tiles
+// ---------------------------------------------------------------------------------------------------------------------
+struct W24WgGemmParams {
+    const float* yt; const float* vx;     // [24][Tp][Rp], [24][Tp][Cp]
+    float* partial;                       // [nsplit][24][Rp][Cp]
+    int Rp, Cp, Tp, nsplit, tiles_per_split;
+};
+
+constexpr int W24G_D = 8;                 // k-steps (of two tiles) the load stream runs ahead
+
+__global__ void __launch_bounds__(256, 1) wino24g_wgrad_kernel(const W24WgGemmParams p) {
+    int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i32 = lane & 31, h = lane >> 5;
+    const int rb_n = p.Rp >> 8, cb_n = p.Cp >> 8;
+    // (row block, column block) fastest: the workgroups of one XCD's id range share the operand panels of a (plane, split)
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int cb = bid % cb_n; bid /= cb_n;
+    const int rb = bid % rb_n; bid /= rb_n;
+    const int split = bid % p.nsplit;
+    const int pl = bid / p.nsplit;
+    const int r0 = rb * 256 + (w >> 1) * 128, c0 = cb * 256 + (w & 1) * 128;
+    const int t_begin = split * p.tiles_per_split;
+    const int t_end = min(p.Tp, t_begin + p.tiles_per_split);
+    const int nsteps = max(t_end - t_begin, 0) >> 1;                          // Tp and tiles_per_split are even
+
+    const unsigned a_bytes = (unsigned)p.Tp * (unsigned)p.Rp * 4u, b_bytes = (unsigned)p.Tp * (unsigned)p.Cp * 4u;
+    const __amdgpu_buffer_rsrc_t ars = make_rsrc((const char*)p.yt + (size_t)pl * a_bytes, a_bytes);
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc((const char*)p.vx + (size_t)pl * b_bytes, b_bytes);
+    const __amdgpu_buffer_rsrc_t ars_dead = make_rsrc(p.yt, 0u), brs_dead = make_rsrc(p.vx, 0u);
+    const unsigned a_vo = (unsigned)((h * p.Rp + r0 + 4 * i32) * 4), b_vo = (unsigned)((h * p.Cp + c0 + 4 * i32) * 4);
+    const unsigned a_step = (unsigned)p.Rp * 8u, b_step = (unsigned)p.Cp * 8u;   // two tiles
+    const unsigned a_so0 = (unsigned)t_begin * (unsigned)p.Rp * 4u, b_so0 = (unsigned)t_begin * (unsigned)p.Cp * 4u;
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+    uint4 a[W24G_D], b[W24G_D];
+    auto load = [&](int d, int s) {                 // step s (wave-uniform) into set d; past the end of the split: zeros, no traffic
+        const bool live = s < nsteps;
+        a[d] = buf_ld16(live ? ars : ars_dead, a_vo, a_so0 + (unsigned)s * a_step);
+        b[d] = buf_ld16(live ? brs : brs_dead, b_vo, b_so0 + (unsigned)s * b_step);
+    };
+#pragma unroll
+    for (int d = 0; d < W24G_D; ++d) {
+        load(d, d);
+        // keeps the prologue loads in ring order: hipcc otherwise reorders them, the loop header then has to wait for the
+        // YOUNGEST of them on the entry path, and the merged wait at the top of every iteration becomes vmcnt(0)
+        asm volatile("" ::: "memory");
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += W24G_D) {
+#pragma unroll
+        for (int d = 0; d < W24G_D; ++d) {
+            const float am[4] = {__uint_as_float(a[d].x), __uint_as_float(a[d].y), __uint_as_float(a[d].z), __uint_as_float(a[d].w)};
+            const float bn[4] = {__uint_as_float(b[d].x), __uint_as_float(b[d].y), __uint_as_float(b[d].z), __uint_as_float(b[d].w)};
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(am[m], bn[n], acc[m][n], 0, 0, 0);
+            load(d, s0 + d + W24G_D);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        }
+    }
+
+    // slab [split][plane][Rp][Cp]: MFMA (m, n) holds rows r0 + 4 i + m, columns c0 + 4 j + n; lane j stores its four n
+    float* const out = p.partial + (((size_t)split * 24 + pl) * p.Rp) * (size_t)p.Cp;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = r0 + 4 * acc_row(e, h) + m;
+            *reinterpret_cast<float4*>(out + (size_t)row * p.Cp + c0 + 4 * i32) = make_float4(acc[m][0][e], acc[m][1][e], acc[m][2][e], acc[m][3][e]);
+        }
+}
+
+// out[rl][cl][3][3] = G4^T (sum_s dU_s) G6.  256 threads = 64 (r, c) pairs x 4 split-phases (fixed order: deterministic).
+struct W24GReduceParams {
+    const float* partial; float* out;
+    int nsplit, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p;
+};
+
+__global__ void __launch_bounds__(256) wino24g_wgrad_reduce_kernel(const W24GReduceParams p) {
+    __shared__ float red[4][24][64];                                   // [phase][plane][pair]
+    const int pr = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const long long npair = (long long)p.Rp * p.Cp;
+    const size_t plane_sz = (size_t)npair, split_sz = plane_sz * 24;
+    for (long long base = (long long)blockIdx.x * 64; base < npair; base += (long long)gridDim.x * 64) {
+        const long long e = base + pr;
+        float s[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) s[i] = 0.f;
+        if (e < npair)
+            for (int k = ph; k < p.nsplit; k += 4) {
+                const float* q = p.partial + (size_t)k * split_sz + (size_t)e;
+#pragma unroll
+                for (int i = 0; i < 24; ++i) s[i] += q[(size_t)i * plane_sz];
+            }
+#pragma unroll
+        for (int i = 0; i < 24; ++i) red[ph][i][pr] = s[i];
+        __syncthreads();
+        if (threadIdx.x < 64 && e < npair) {
+            float U[4][6];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) U[i][j] = (red[0][6 * i + j][pr] + red[1][6 * i + j][pr]) + (red[2][6 * i + j][pr] + red[3][6 * i + j][pr]);
+            // rows: t = G4^T U, G4 = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+            float t[3][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                t[0][j] = U[0][j] + 0.5f * (U[1][j] + U[2][j]);
+                t[1][j] = 0.5f * (U[1][j] - U[2][j]);
+                t[2][j] = U[3][j] + 0.5f * (U[1][j] + U[2][j]);
+            }
+            const int cp = (int)(e % p.Cp), rp = (int)(e / p.Cp);
+            const int rl = wn_phys2log(rp, p.r_seg0, p.r_seg0p, p.R), cl = wn_phys2log(cp, p.c_seg0, p.c_seg0p, p.C);
+            if (rl >= 0 && cl >= 0) {
+                float* o = p.out + ((size_t)rl * p.C + cl) * 9;
+                // columns: dg = t G6, G6 = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float s12 = t[a][1] + t[a][2], d12 = t[a][2] - t[a][1], s34 = t[a][3] + t[a][4], d34 = t[a][3] - t[a][4];
+                    o[a * 3 + 0] = 0.25f * t[a][0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+                    o[a * 3 + 1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+                    o[a * 3 + 2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + t[a][5];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// workgroup tile of the forward kernels: 8 x 32 pixels, or 16 x 16 for images narrower than 32 (as wino24.hip)
+static inline void w24g_tile(int W, int& ph, int& pw) { if (W >= 32) { ph = 8; pw = 32; } else { ph = 16; pw = 16; } }
+static long long w24g_tiles(int B, int H, int W) {
+    int ph, pw;
+    w24g_tile(W, ph, pw);
+    return (long long)B * ((H + ph - 1) / ph) * ((W + pw - 1) / pw);
+}
+
+}  // namespace clamd
+
+using namespace clamd;
+
+// split-K plan of the weight-gradient GEMM: workgroups = 24 planes x (Rp/256) x (Cp/256) x nsplit, aimed at a whole number
+// of rounds of the chip; tiles per split a multiple of 2 * W24G_D (whole passes of the prefetch ring)
+static int w24g_wg_plan(long long T, int Rp, int Cp, const clamd_tuning& tn, int* tp_out, int* per_out) {
+    const int quant = 2 * W24G_D;
+    const long long Tp = (T + quant - 1) / quant * quant;
+    const int nb = 24 * (Rp / 256) * (Cp / 256);
+    const int cus = clamd_usable_cus(tn);
+    // target: three rounds of the chip (768 workgroups on 256 CUs), at least 4 passes of the ring per workgroup
+    long long nsplit = std::max<long long>(1, (3LL * cus) / nb);
+    nsplit = std::min<long long>(nsplit, std::max<long long>(1, Tp / (4 * quant)));
+    long long per = (Tp + nsplit - 1) / nsplit;
+    per = (per + quant - 1) / quant * quant;
+    nsplit = (Tp + per - 1) / per;
+    if (tp_out) *tp_out = (int)Tp;
+    if (per_out) *per_out = (int)per;
+    return (int)nsplit;
+}
+
+extern "C" {
+
+size_t clamd_winograd24_input_elems(int B, int H, int W, int Cp) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cp <= 0) return 0;
+    return (size_t)w24g_tiles(B, H, W) * (size_t)(Cp / 8) * 24 * 256;
+}
+
+int clamd_winograd24_transform_input(const float* x, int x_ldc, float* v, int B, int H, int W, int Cp, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("winograd24_transform_input: empty problem");
+    if ((H & 1) || (W & 3)) return clamd_fail("winograd24_transform_input: H must be even and W a multiple of 4 (2x4 output tiles)");
+    if (Cp % 8 || x_ldc % 4 || x_ldc < Cp) return clamd_fail("winograd24_transform_input: channel count / pitch must be padded");
+    if ((long long)H * W * x_ldc * 4 >= (1ll << 31)) return clamd_fail("winograd24_transform_input: image exceeds 2^31 bytes");
+    int ph, pw;
+    w24g_tile(W, ph, pw);
+    const long long ntm = w24g_tiles(B, H, W), nkg = (Cp / 8 + 3) / 4;
+    if (ntm * nkg > 0x7fffffff) return clamd_fail("winograd24_transform_input: grid out of range");
+    W24XformParams p{x, x_ldc, v, B, H, W, Cp};
+    if (pw == 32) hipLaunchKernelGGL(wino24_xform_kernel<8>, dim3((unsigned)(ntm * nkg)), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wino24_xform_kernel<4>, dim3((unsigned)(ntm * nkg)), dim3(256), 0, (hipStream_t)stream, p);
+    return clamd_check_launch("winograd24_transform_input");
+}
+
+int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const float* bias, float* y, int y_ldc,
+                                 float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
+                                 const clamd_tuning* tune, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("conv3x3_winograd24_pre: empty problem");
+    if ((H & 1) || (W & 3)) return clamd_fail("conv3x3_winograd24_pre: H must be even and W a multiple of 4 (2x4 output tiles)");
+    if (Cin_p % 32 || Cin_p < 64 || Cout_p % 64 || y_ldc % 8) return clamd_fail("conv3x3_winograd24_pre: needs Cin_p % 32 == 0, Cin_p >= 64, Cout_p % 64 == 0");
+    if (int e = clamd_check_tuning(tune)) return e;
+    const clamd_tuning& tn = clamd_tune(tune);
+    const long long tiles = w24g_tiles(B, H, W), ntn = Cout_p / 64;
+    if (tiles * ntn > 0x7fffffff) return clamd_fail("conv3x3_winograd24_pre: grid out of range");
+    if ((unsigned long long)tiles * (Cin_p / 8) * 24 * 1024 >= (1ull << 32) || (long long)24 * Cout_p * Cin_p * 4 >= (1ll << 31))
+        return clamd_fail("conv3x3_winograd24_pre: transformed input exceeds 2^32 bytes or filter 2^31 bytes");
+    if (stats && stat_rows != clamd_winograd24_stat_rows(B, H, W, Cout_p, tn))
+        return clamd_fail("conv3x3_winograd24_pre: stat_rows does not match clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD24, ...)");
+    WinoParams p{v, 0, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 1, 0};
+    p.band = wino_band(tiles, ntn, 3.0 * B * H * W * Cin_p, 24.0 * Cin_p * Cout_p, tn.wino_band);
+    p.nblk = (int)(tiles * ntn);
+    const unsigned grid = tn.wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_usable_cus(tn)) : (unsigned)p.nblk;
+    int ph, pw;
+    w24g_tile(W, ph, pw);
+    const bool ragged = (H % ph) != 0 || (W % pw) != 0;
+    hipStream_t s = (hipStream_t)stream;
+#define W24G_LAUNCH(TXN_, RG_) hipLaunchKernelGGL((wino24g_kernel<TXN_, RG_, 2>), dim3(grid), dim3(256), 0, s, p)
+    if (pw == 32) { if (ragged) W24G_LAUNCH(8, true); else W24G_LAUNCH(8, false); }
+    else { if (ragged) W24G_LAUNCH(4, true); else W24G_LAUNCH(4, false); }
+#undef W24G_LAUNCH
+    return clamd_check_launch("conv3x3_winograd24_pre");
+}
+
+size_t clamd_wgrad_winograd24_pre_operand_elems(int B, int H, int W, int Cp) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cp <= 0) return 0;
+    const long long T = (long long)B * (H / 2) * (W / 4), quant = 2 * W24G_D;
+    return (size_t)(24 * ((T + quant - 1) / quant * quant)) * (size_t)Cp;
+}
+
+size_t clamd_wgrad_winograd24_pre_workspace_bytes(int B, int H, int W, int Rp, int Cp) {
+    if (B <= 0 || H <= 0 || W <= 0 || Rp < 256 || Cp < 256) return 0;
+    // upper bound over cu_reserve: the plan with every CU
+    clamd_tuning tn = clamd_default_tuning();
+    tn.cu_reserve = 0;
+    const int nsplit = w24g_wg_plan((long long)B * (H / 2) * (W / 4), Rp, Cp, tn, nullptr, nullptr);
+    return (size_t)nsplit * 24 * Rp * Cp * sizeof(float);
+}
+
+int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* x, int x_ldc, float* yt, float* vx, float* workspace,
+                               size_t ws_bytes, float* out, int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0,
+                               int r_seg0p, int c_seg0, int c_seg0p, const clamd_tuning* tune, void* stream) {
+    if (int e = clamd_check_tuning(tune)) return e;
+    if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("wgrad_winograd24_pre: empty problem");
+    if ((H & 1) || (W & 3)) return clamd_fail("wgrad_winograd24_pre: H must be even and W a multiple of 4");
+    if (Rp % 256 || Cp % 256 || Rp <= 0 || Cp <= 0 || gz_ldc % 4 || x_ldc % 4) return clamd_fail("wgrad_winograd24_pre: needs Rp and Cp multiples of 256");
+    if ((long long)H * W * gz_ldc * 4 >= (1ll << 31) || (long long)H * W * x_ldc * 4 >= (1ll << 31)) return clamd_fail("wgrad_winograd24_pre: one image exceeds 2^31 bytes");
+    const clamd_tuning& tn = clamd_tune(tune);
+    const long long T = (long long)B * (H / 2) * (W / 4);
+    int Tp = 0, per = 0;
+    const int nsplit = w24g_wg_plan(T, Rp, Cp, tn, &Tp, &per);
+    if ((long long)Tp * std::max(Rp, Cp) * 4 >= (1ll << 32)) return clamd_fail("wgrad_winograd24_pre: one operand plane exceeds 2^32 bytes");
+    if ((size_t)nsplit * 24 * Rp * Cp * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd24_pre: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        W24WgXformParams pa{gz, gz_ldc, yt, B, H, W, Rp, (int)T, Tp}, pb{x, x_ldc, vx, B, H, W, Cp, (int)T, Tp};
+        const long long na = ((long long)Tp * (Rp / 4) + 255) / 256, nb = ((long long)Tp * (Cp / 4) + 255) / 256;
+        hipLaunchKernelGGL(wino24g_wgrad_xform_kernel<0>, dim3((unsigned)std::min<long long>(na, 1 << 20)), dim3(256), 0, s, pa);
+        hipLaunchKernelGGL(wino24g_wgrad_xform_kernel<1>, dim3((unsigned)std::min<long long>(nb, 1 << 20)), dim3(256), 0, s, pb);
+        if (int e = clamd_check_launch("wgrad_winograd24_pre transforms")) return e;
+    }
+    W24WgGemmParams p{yt, vx, workspace, Rp, Cp, Tp, nsplit, per};
+    hipLaunchKernelGGL(wino24g_wgrad_kernel, dim3((unsigned)(24 * nsplit * (Rp / 256) * (Cp / 256))), dim3(256), 0, s, p);
+    if (int e = clamd_check_launch("wgrad_winograd24_pre")) return e;
+    W24GReduceParams rp{workspace, out, nsplit, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p};
+    long long g = ((long long)Rp * Cp + 63) / 64;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(wino24g_wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, rp);
+    return clamd_check_launch("wgrad_winograd24_pre_reduce");
+}
+
+}  // extern "C"

@@ -117,6 +117,28 @@ size_t clamd_wgrad_winograd24_workspace_bytes(int Rp, int Cp);
 int clamd_wgrad_winograd24(const float* gz, int gz_ldc, const float* x, int x_ldc, float* workspace, size_t ws_bytes, float* out,
                            int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p,
                            const clamd_tuning* tune, void* stream);
+/* ---- F(2x4,3x3) with PRE-TRANSFORMED operands (wino24g.hip): the wide (>= 256-channel) 3x3 convolutions of
+ * models/unet.py:28-33,50-55 (enc3.4, enc4, dec1, dec2, dec3) and their gradients (trainer.py:175).
+ * clamd_conv3x3_winograd24 forms B^T d B inside the K loop of every output-slab workgroup; here it is formed ONCE per
+ * tensor (clamd_winograd24_transform_input: x [B,H,W,ldc] -> v, clamd_winograd24_input_elems() floats, 3x the
+ * activation) and clamd_conv3x3_winograd24_pre runs a transform-free K loop (48 MFMAs + 18 buffer loads straight into
+ * the operand registers, no LDS, no VALU) on the SAME packed filters, tile grid, epilogue and statistics rows:
+ * bit-identical to clamd_conv3x3_winograd24.  Needs Cin_p % 32 == 0, Cin_p >= 64, Cout_p % 64 == 0. */
+size_t clamd_winograd24_input_elems(int B, int H, int W, int Cp);
+int clamd_winograd24_transform_input(const float* x, int x_ldc, float* v, int B, int H, int W, int Cp, void* stream);
+int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const float* bias, float* y, int y_ldc,
+                                 float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
+                                 const clamd_tuning* tune, void* stream);
+/* Weight gradient of the same convolution as a batched GEMM over the 24 Winograd planes (K = tiles) on operands transformed
+ * once: yt / vx = caller-provided scratch of clamd_wgrad_winograd24_pre_operand_elems(B,H,W,Rp) / (..,Cp) floats
+ * (A4 dY A6^T and B4^T d B6, [24][tiles][channels]); every wave owns a 128 x 128 block of one plane (16 MFMAs per two
+ * 16-byte loads, no LDS); split-K slabs in `workspace` (>= clamd_wgrad_winograd24_pre_workspace_bytes), fixed-order reduce
+ * with G4^T . G6: deterministic.  Rp and Cp multiples of 256; other arguments as clamd_wgrad_winograd24. */
+size_t clamd_wgrad_winograd24_pre_operand_elems(int B, int H, int W, int Cp);
+size_t clamd_wgrad_winograd24_pre_workspace_bytes(int B, int H, int W, int Rp, int Cp);
+int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* x, int x_ldc, float* yt, float* vx, float* workspace,
+                               size_t ws_bytes, float* out, int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0,
+                               int r_seg0p, int c_seg0, int c_seg0p, const clamd_tuning* tune, void* stream);
 /* Weight gradient of the same convolution by Winograd (fp32, H and W even): out [R][C][3][3] = G^T (sum over tiles of
  * (A dY A^T) x (B^T d B)) G; arguments as clamd_wgrad(CLAMD_WGRAD_CONV3, ...) (gz = d loss / d conv output, x = conv input). */
 size_t clamd_wgrad_winograd_workspace_bytes(int Rp, int Cp);

@@ -538,6 +538,126 @@ def test_conv3x3_winograd24_fp32(C, shape):
             np.testing.assert_allclose(stats2.double().sum(0).cpu().numpy(), stats.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
 
 
+W24G_SHAPES = [  # B, Cin segs, Cout, H, W (Cin_p >= 64, Cout_p % 64 == 0)
+    (1, [(64, 64)], 64, 16, 16),                 # 16x16-pixel workgroup tile, 8 chunks
+    (2, [(128, 128)], 128, 8, 32),               # exactly one 8x32 tile per image, two output slabs
+    (2, [(40, 64), (50, 64)], 100, 24, 40),      # concat input, ragged rows and columns, padded output channels
+    (3, [(256, 256)], 256, 16, 16),              # 32 chunks, four slabs, persistent grid not reached
+    (1, [(96, 128)], 192, 34, 68),               # ragged in both directions with the wide tile, three slabs
+    (5, [(64, 64)], 640, 40, 64),                # 5*5*2 tiles x 10 slabs = 500 work items: the persistent loop and its
+    #                                              cross-tile load stream (next tile's chunks fetched by the last chunks)
+]
+
+
+@pytest.mark.parametrize('shape', W24G_SHAPES, ids=lambda sh: f'{sh[0]}x{"+".join(str(a) for a, _ in sh[1])}->{sh[2]}@{sh[3]}x{sh[4]}')
+def test_conv3x3_winograd24_pretransformed(C, shape):
+    """wino24g.hip: input transformed ONCE (clamd_winograd24_transform_input), transform-free K loop
+    (clamd_conv3x3_winograd24_pre).  Forward (+bias, ReLU, statistics rows) and data gradient against the oracle at the 2e-5
+    bound, and BIT-IDENTICAL to clamd_conv3x3_winograd24 (same filters, same MFMA chains, same epilogue, same rows)."""
+    B, segs, cout, H, W = shape
+    rng = np.random.default_rng(29)
+    cin = sum(s[0] for s in segs)
+    x = rnd(rng, B, cin, H, W)
+    w = rnd(rng, cout, cin, 3, 3) * (1.0 / np.sqrt(9 * cin))
+    b = rnd(rng, cout)
+    cin_p, cout_p = sum(s[1] for s in segs), C.ops.cpad(cout)
+    if cout_p % 64:
+        cout_p = 64
+    xt = nhwc_with_segs(C, x, segs, 0)
+    wt, bt = dev(w), dev(b)
+    wf = torch.zeros(24 * cout_p * cin_p, device='cuda')
+    wd = torch.zeros(24 * cin_p * cout_p, device='cuda')
+    bp = torch.zeros(cout_p, device='cuda')
+    tab = C.ops.WinoPackTable(24); tab.conv3x3(wt, wf, wd, segs, cout); tab.finalize('cuda').run()
+    pt = C.ops.PackTable(0); pt.vector(bt, bp, cout); pt.finalize('cuda').run(0)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    L = lib.load()
+    gz = rnd(rng, B, cout, H, W)
+    gzt = C.ops.to_nhwc(dev(gz), 0, cp=cout_p)
+    ref = O.relu_fwd(O.conv3x3_fwd(x, w, b))
+    rgx = O.conv3x3_bwd(x, w, gz)[0]
+    pm = phys_map(segs)
+    for tn in (None, lib.Tuning(wino_persist=0), lib.Tuning(cu_reserve=120), lib.Tuning(wino_band=1)):
+        tp = tn.ref() if tn else None
+        stats, rows = stat_buf(C, lib.OP_CONV3X3_WINOGRAD24, B, H, W, cin_p, cout_p, 0, tuning=tn)
+        stats_p = torch.full_like(stats, float('nan'))
+        y = torch.full((B, H, W, cout_p), 7.0, device='cuda')
+        y_p = torch.full((B, H, W, cout_p), 8.0, device='cuda')
+        lib.call('clamd_conv3x3_winograd24', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), rows, B, H, W, cin_p, cout_p, 1, tp, s)
+        v = torch.full((L.clamd_winograd24_input_elems(B, H, W, cin_p),), float('nan'), device='cuda')
+        lib.call('clamd_winograd24_transform_input', ptr(xt), cin_p, ptr(v), B, H, W, cin_p, s)
+        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), cout_p, ptr(stats_p), rows, B, H, W, cin_p, cout_p, 1, tp, s)
+        sync()
+        assert not bool(torch.isnan(v).any()), 'the transform must write every element of V'
+        assert torch.equal(y, y_p)
+        # rows: per tile, or per workgroup of the persistent grid.  The block order (band of output slabs) follows each kernel's own
+        # traffic model, so per-workgroup rows partition the tiles differently unless the band is forced: same totals always,
+        # identical rows under a forced band and on the one-workgroup-per-tile grid
+        np.testing.assert_allclose(stats_p.double().sum(0).cpu().numpy(), stats.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+        if tn is not None and (tn.wino_band == 1 or tn.wino_persist == 0):
+            assert torch.equal(stats, stats_p)
+        stats_q = torch.full_like(stats, float('nan'))
+        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), cout_p, ptr(stats_q), rows, B, H, W, cin_p, cout_p, 1, tp, s)
+        sync()
+        assert torch.equal(stats_p, stats_q), 'statistics rows differ between two identical launches'
+        assert rel_l2(C.ops.from_nhwc(y_p, cout, 0).cpu().numpy(), ref) < TOL[0]
+        # data gradient: the same two calls on the gradient tensor and the tap-flipped filters
+        gx = torch.full((B, H, W, cin_p), 3.0, device='cuda')
+        gx_p = torch.full((B, H, W, cin_p), 4.0, device='cuda')
+        lib.call('clamd_conv3x3_winograd24', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, 0, B, H, W, cout_p, cin_p, 0, tp, s)
+        vg = torch.empty(L.clamd_winograd24_input_elems(B, H, W, cout_p), device='cuda')
+        lib.call('clamd_winograd24_transform_input', ptr(gzt), cout_p, ptr(vg), B, H, W, cout_p, s)
+        lib.call('clamd_conv3x3_winograd24_pre', ptr(vg), ptr(wd), None, ptr(gx_p), cin_p, None, 0, B, H, W, cout_p, cin_p, 0, tp, s)
+        sync()
+        assert torch.equal(gx, gx_p)
+        got_gx = gx_p.cpu().numpy().transpose(0, 3, 1, 2)
+        assert rel_l2(got_gx[:, [p_ for p_, l in enumerate(pm) if l >= 0]], rgx) < TOL[0]
+    # refused shapes
+    with pytest.raises(RuntimeError, match='Cout_p % 64'):
+        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), 32, None, 0, B, H, W, cin_p, 32, 1, None, s)
+
+
+W24G_WGRAD_SHAPES = [  # B, Cin segs, Cout, H, W (Cin_p, Cout_p multiples of 256)
+    (2, [(256, 256)], 256, 16, 16),
+    (1, [(100, 256), (130, 256)], 200, 12, 20),      # concat input with padding, padded output channels, odd tile count (15)
+    (3, [(256, 256)], 512, 32, 32),                  # several splits
+]
+
+
+@pytest.mark.parametrize('shape', W24G_WGRAD_SHAPES, ids=lambda sh: f'{sh[0]}x{"+".join(str(a) for a, _ in sh[1])}->{sh[2]}@{sh[3]}x{sh[4]}')
+def test_wgrad_winograd24_pretransformed(C, shape):
+    """Weight gradient as a batched GEMM over the 24 Winograd planes on operands transformed once (wino24g.hip): against
+    the oracle at the 2e-5 bound of the other weight-gradient kernels, bit-reproducible, same result under another split."""
+    B, segs, cout, H, W = shape
+    rng = np.random.default_rng(31)
+    cin = sum(s[0] for s in segs)
+    x = rnd(rng, B, cin, H, W)
+    w = rnd(rng, cout, cin, 3, 3) * (1.0 / np.sqrt(9 * cin))
+    gz = rnd(rng, B, cout, H, W)
+    cin_p, cout_p = sum(s[1] for s in segs), (cout + 255) // 256 * 256
+    xt = nhwc_with_segs(C, x, segs, 0)
+    gzt = C.ops.to_nhwc(dev(gz), 0, cp=cout_p)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    L = lib.load()
+    yt = torch.full((L.clamd_wgrad_winograd24_pre_operand_elems(B, H, W, cout_p),), float('nan'), device='cuda')
+    vx = torch.full((L.clamd_wgrad_winograd24_pre_operand_elems(B, H, W, cin_p),), float('nan'), device='cuda')
+    wsb = L.clamd_wgrad_winograd24_pre_workspace_bytes(B, H, W, cout_p, cin_p)
+    ws = torch.empty(wsb // 4 + 4, device='cuda')
+    c_seg0, c_seg0p = (segs[0][0], segs[0][1]) if len(segs) == 2 else (cin, cin_p)
+    rgw = O.conv3x3_bwd(x, w, gz)[1]
+    outs = []
+    for tn in (None, None, lib.Tuning(cu_reserve=100)):
+        gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
+        lib.call('clamd_wgrad_winograd24_pre', ptr(gzt), cout_p, ptr(xt), cin_p, ptr(yt), ptr(vx), ptr(ws), wsb, ptr(gw), B, H, W,
+                 cout_p, cin_p, cout, cin, cout, cout_p, c_seg0, c_seg0p, tn.ref() if tn else None, s)
+        sync()
+        outs.append(gw)
+        assert rel_l2(gw.cpu().numpy(), rgw) < 2e-5
+    assert not bool(torch.isnan(yt).any()) and not bool(torch.isnan(vx).any())
+    assert torch.equal(outs[0], outs[1]), 'two identical launches must be bit-identical'
+    np.testing.assert_allclose(outs[2].cpu().numpy(), outs[0].cpu().numpy(), rtol=0, atol=2e-5 * float(np.abs(rgw).max()) * 50)
+
+
 def _random_conv_shapes(n, seed):
     """Seeded random problem sizes that hit ragged tiles, several channel slabs, K-step pairs / fours / odd counts and
     the split-K tail of every 3x3 kernel."""
