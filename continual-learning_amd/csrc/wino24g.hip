@@ -15,12 +15,13 @@
 //     workgroup inside the loop (each row i has its own slice of V and of the filters), so there is nothing to stage.  The
 //     load stream runs NSET chunks ahead and is continuous across the tiles of the persistent loop (the last chunks of a
 //     tile fetch the first chunks of the next one, whose latency then hides under the epilogue);
-//   * weight gradient: dU[p] = Yt[p]^T Vx[p] for the 24 planes as a batched GEMM with K = Winograd tiles.  Two transform
-//     kernels write Yt = A4 dY A6^T [24][Tp][Rp] and Vx = B4^T d B6 [24][Tp][Cp]; wino24g_wgrad_kernel gives every WAVE a
-//     128 x 128 block of one plane: a lane loads 16 bytes = 4 channels of one tile of each operand and issues the 4 x 4
-//     outer product as 16 MFMAs (k = 2 tiles), 256 accumulator registers, 2 loads per 16 MFMAs, no LDS, no barrier; the
-//     four waves of a workgroup take the 2 x 2 blocks of a 256 x 256 block so that operand panels are shared in L1.
-//     Split-K over tile ranges into fp32 slabs [split][24][Rp][Cp], fixed-order reduce with G4^T . G6 (deterministic).
+//   * weight gradient: dU[p] = Yt[p]^T V[p] for the 24 planes as a batched GEMM with K = Winograd tiles.  One transform
+//     kernel writes Yt = A4 dY A6^T [24][tiles][Rp] (tiles in V's order); the x side is the forward image V itself, read in
+//     place.  wino24g_wgrad_kernel gives every WAVE a 128 x 128 block of one plane: a lane loads 16 bytes = 4 channels of
+//     one tile of each operand and issues the 4 x 4 outer product as 16 MFMAs (k = 2 tiles), 256 accumulator registers,
+//     2 loads per 16 MFMAs, no LDS, no barrier; the four waves of a workgroup take the 2 x 2 blocks of a 256 x 256 block so
+//     that operand panels are shared in L1.  Split-K over tile ranges into fp32 slabs [split][24][Rp][Cp], fixed-order
+//     reduce with G4^T . G6 (deterministic).
 #include <string.h>
 #include <algorithm>
 #include "common.hip.h"
@@ -327,90 +328,60 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// weight gradient: operand transforms
+// weight gradient: gradient-side operand transform
 // ---------------------------------------------------------------------------------------------------------------------
 struct W24WgXformParams {
-    const float* src; int ldc;
-    float* dst;                      // [24][Tp][Cp]
-    int B, H, W, Cp, T, Tp;
+    const float* src; int ldc;       // gz [B,H,W,ldc]
+    float* dst;                      // Yt [24][Tp][Rp]
+    int B, H, W, Rp, Tp;
 };
 
-// thread = (tile, 4-channel group), channel groups fastest: reads and writes are both contiguous along the channels.
-// SIDE 0: Yt = A4 dY A6^T of the 2 x 4 gradient tile; SIDE 1: Vx = B4^T d B6 of the 4 x 6 input patch (zero padding).
-// Exact textbook matrices (no folded signs): the reduce applies plain G4^T . G6.
-template <int SIDE>
+// Yt = A4 dY A6^T of every 2 x 4 gradient tile, tiles in the order of the forward image V (t = 32 * tile block + tile in block),
+// so that V itself is the other operand of the weight-gradient GEMM.  thread = (tile, 4-channel group), channel groups fastest:
+// reads and writes are contiguous along the channels.  Tiles of a ragged block that lie outside the image read zeros.
+template <int TXN>
 __global__ void __launch_bounds__(256) wino24g_wgrad_xform_kernel(const W24WgXformParams p) {
-    const int ng = p.Cp >> 2;
+    constexpr int TYN = 32 / TXN, PW = 4 * TXN, PH = 2 * TYN;
+    const int ng = p.Rp >> 2;
     const long long total = (long long)p.Tp * ng;
-    const int tw = p.W >> 2, th = p.H >> 1;
+    const int tiles_x = (p.W + PW - 1) / PW, tiles_y = (p.H + PH - 1) / PH;
     const unsigned img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.ldc * 4u;
+    const size_t ps = (size_t)p.Tp * p.Rp;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int g = (int)(idx % ng);
         const int t = (int)(idx / ng);
-        float* const dst = p.dst + (size_t)t * p.Cp + 4 * g;
-        const size_t ps = (size_t)p.Tp * p.Cp;
-        if (t >= p.T) {                                                    // padding tiles: zeros (they contribute nothing)
-#pragma unroll
-            for (int pl = 0; pl < 24; ++pl) *reinterpret_cast<float4*>(dst + pl * ps) = make_float4(0.f, 0.f, 0.f, 0.f);
-            continue;
-        }
-        const int tx = t % tw, ty = (t / tw) % th, b = t / (tw * th);
+        const int tm = t >> 5, r = t & 31;
+        const int x0 = (tm % tiles_x) * PW + 4 * (r % TXN), y0 = ((tm / tiles_x) % tiles_y) * PH + 2 * (r / TXN), b = tm / (tiles_x * tiles_y);
+        float* const dst = p.dst + (size_t)t * p.Rp + 4 * g;
         const __amdgpu_buffer_rsrc_t rs = make_rsrc((const char*)p.src + (size_t)b * img, img);
-        if constexpr (SIDE == 0) {
-            float gq[2][4][4];                                             // [row][column][channel]
+        float gq[2][4][4];                                             // [row][column][channel]
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint4 u = buf_ld16(rs, (unsigned)((((2 * ty + a) * p.W + 4 * tx + q) * p.ldc + 4 * g) * 4), 0u);
-                    gq[a][q][0] = __uint_as_float(u.x); gq[a][q][1] = __uint_as_float(u.y);
-                    gq[a][q][2] = __uint_as_float(u.z); gq[a][q][3] = __uint_as_float(u.w);
-                }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // A4 = [[1,0],[1,1],[1,-1],[0,-1]]
-                float z[4][4], o[6][4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        z[q][e] = i == 0 ? gq[0][q][e] : (i == 1 ? gq[0][q][e] + gq[1][q][e] : (i == 2 ? gq[0][q][e] - gq[1][q][e] : -gq[1][q][e]));
-                // A6 = [[1,0,0,0],[1,1,1,1],[1,-1,1,-1],[1,2,4,8],[1,-2,4,-8],[0,0,0,1]]
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float sa = z[0][e] + z[2][e], sb = z[1][e] + z[3][e], sc = fmaf(4.f, z[2][e], z[0][e]), sd = fmaf(4.f, z[3][e], z[1][e]);
-                    o[0][e] = z[0][e]; o[1][e] = sa + sb; o[2][e] = sa - sb;
-                    o[3][e] = fmaf(2.f, sd, sc); o[4][e] = fmaf(-2.f, sd, sc); o[5][e] = z[3][e];
-                }
-#pragma unroll
-                for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(dst + (6 * i + j) * ps) = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
+            for (int q = 0; q < 4; ++q) {
+                const int yy = y0 + a, xx = x0 + q;
+                const uint4 u = buf_ld16(rs, (yy < p.H && xx < p.W) ? (unsigned)(((yy * p.W + xx) * p.ldc + 4 * g) * 4) : BUF_OOB, 0u);
+                gq[a][q][0] = __uint_as_float(u.x); gq[a][q][1] = __uint_as_float(u.y);
+                gq[a][q][2] = __uint_as_float(u.z); gq[a][q][3] = __uint_as_float(u.w);
             }
-        } else {
-            float4 d[4][6];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+        for (int i = 0; i < 4; ++i) {
+            // A4 = [[1,0],[1,1],[1,-1],[0,-1]]
+            float z[4][4], o[6][4];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    const int yy = 2 * ty - 1 + a, xx = 4 * tx - 1 + c;
-                    const unsigned vo = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? (unsigned)(((yy * p.W + xx) * p.ldc + 4 * g) * 4) : BUF_OOB;
-                    const uint4 u = buf_ld16(rs, vo, 0u);
-                    d[a][c] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-                }
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // B4^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
-                const int a1 = i == 0 ? 0 : (i == 2 ? 2 : 1), a2 = i == 0 ? 2 : (i == 1 ? 2 : (i == 2 ? 1 : 3));
-                const float s2 = i == 1 ? 1.f : -1.f;
-                float t[6][4], o[6][4];
+                for (int e = 0; e < 4; ++e)
+                    z[q][e] = i == 0 ? gq[0][q][e] : (i == 1 ? gq[0][q][e] + gq[1][q][e] : (i == 2 ? gq[0][q][e] - gq[1][q][e] : -gq[1][q][e]));
+            // A6 = [[1,0,0,0],[1,1,1,1],[1,-1,1,-1],[1,2,4,8],[1,-2,4,-8],[0,0,0,1]]
 #pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    t[c][0] = fmaf(s2, d[a2][c].x, d[a1][c].x); t[c][1] = fmaf(s2, d[a2][c].y, d[a1][c].y);
-                    t[c][2] = fmaf(s2, d[a2][c].z, d[a1][c].z); t[c][3] = fmaf(s2, d[a2][c].w, d[a1][c].w);
-                }
-                W24G_COLS(t, o);
-#pragma unroll
-                for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(dst + (6 * i + j) * ps) = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
+            for (int e = 0; e < 4; ++e) {
+                const float sa = z[0][e] + z[2][e], sb = z[1][e] + z[3][e], sc = fmaf(4.f, z[2][e], z[0][e]), sd = fmaf(4.f, z[3][e], z[1][e]);
+                o[0][e] = z[0][e]; o[1][e] = sa + sb; o[2][e] = sa - sb;
+                o[3][e] = fmaf(2.f, sd, sc); o[4][e] = fmaf(-2.f, sd, sc); o[5][e] = z[3][e];
             }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(dst + (6 * i + j) * ps) = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
         }
     }
 }
@@ -419,13 +390,19 @@ __global__ void __launch_bounds__(256) wino24g_wgrad_xform_kernel(const W24WgXfo
 // weight gradient: batched GEMM over the 24 planes, K = tiles
 // ---------------------------------------------------------------------------------------------------------------------
 struct W24WgGemmParams {
-    const float* yt; const float* vx;     // [24][Tp][Rp], [24][Tp][Cp]
+    const float* yt;                      // [24][Tp][Rp]
+    const float* v;                       // forward image of the convolution input: [Tp/32][Cp/8][24][2][32][4]
     float* partial;                       // [nsplit][24][Rp][Cp]
     int Rp, Cp, Tp, nsplit, tiles_per_split;
 };
 
 constexpr int W24G_D = 8;                 // k-steps (of two tiles) the load stream runs ahead
 
+// Every WAVE owns a 128 x 128 block of one plane: lane (i = lane & 31, h = lane >> 5) loads 16 bytes = 4 channels of tile
+// t + h of each operand and the wave issues the 4 x 4 outer product as 16 MFMAs (k = the two tiles): MFMA (m, n) accumulates rows
+// r0 + 4i + m, columns c0 + 4j + n.  The x side comes straight from the forward image V: the 4 channels c0 + 4i.. of tile t are
+// the 16 bytes at [t >> 5][(c0 + 4i) / 8][plane][i & 1][t & 31] -- one 128-byte line per lane pair, whose other seven tiles are
+// the next three k-steps' (L1).  Two loads per 16 MFMAs, running W24G_D steps ahead; no LDS, no barrier, no VALU in the loop.
 __global__ void __launch_bounds__(256, 1) wino24g_wgrad_kernel(const W24WgGemmParams p) {
     int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -443,13 +420,16 @@ __global__ void __launch_bounds__(256, 1) wino24g_wgrad_kernel(const W24WgGemmPa
     const int t_end = min(p.Tp, t_begin + p.tiles_per_split);
     const int nsteps = max(t_end - t_begin, 0) >> 1;                          // Tp and tiles_per_split are even
 
-    const unsigned a_bytes = (unsigned)p.Tp * (unsigned)p.Rp * 4u, b_bytes = (unsigned)p.Tp * (unsigned)p.Cp * 4u;
+    const int nk = p.Cp >> 3;
+    const unsigned a_bytes = (unsigned)p.Tp * (unsigned)p.Rp * 4u;
     const __amdgpu_buffer_rsrc_t ars = make_rsrc((const char*)p.yt + (size_t)pl * a_bytes, a_bytes);
-    const __amdgpu_buffer_rsrc_t brs = make_rsrc((const char*)p.vx + (size_t)pl * b_bytes, b_bytes);
-    const __amdgpu_buffer_rsrc_t ars_dead = make_rsrc(p.yt, 0u), brs_dead = make_rsrc(p.vx, 0u);
-    const unsigned a_vo = (unsigned)((h * p.Rp + r0 + 4 * i32) * 4), b_vo = (unsigned)((h * p.Cp + c0 + 4 * i32) * 4);
-    const unsigned a_step = (unsigned)p.Rp * 8u, b_step = (unsigned)p.Cp * 8u;   // two tiles
-    const unsigned a_so0 = (unsigned)t_begin * (unsigned)p.Rp * 4u, b_so0 = (unsigned)t_begin * (unsigned)p.Cp * 4u;
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc(p.v, (unsigned)((size_t)(p.Tp >> 5) * nk * 24 * 1024));
+    const __amdgpu_buffer_rsrc_t ars_dead = make_rsrc(p.yt, 0u), brs_dead = make_rsrc(p.v, 0u);
+    const unsigned a_vo = (unsigned)((h * p.Rp + r0 + 4 * i32) * 4);
+    const unsigned b_vo = (unsigned)(((c0 >> 3) + (i32 >> 1)) * 24 * 1024 + (i32 & 1) * 512 + h * 16);
+    const unsigned a_step = (unsigned)p.Rp * 8u;                              // two tiles
+    const unsigned a_so0 = (unsigned)t_begin * (unsigned)p.Rp * 4u;
+    const unsigned b_blk = (unsigned)nk * 24u * 1024u, b_pl = (unsigned)pl * 1024u;
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -462,8 +442,9 @@ __global__ void __launch_bounds__(256, 1) wino24g_wgrad_kernel(const W24WgGemmPa
     uint4 a[W24G_D], b[W24G_D];
     auto load = [&](int d, int s) {                 // step s (wave-uniform) into set d; past the end of the split: zeros, no traffic
         const bool live = s < nsteps;
+        const unsigned t = (unsigned)(t_begin + 2 * s);
         a[d] = buf_ld16(live ? ars : ars_dead, a_vo, a_so0 + (unsigned)s * a_step);
-        b[d] = buf_ld16(live ? brs : brs_dead, b_vo, b_so0 + (unsigned)s * b_step);
+        b[d] = buf_ld16(live ? brs : brs_dead, b_vo, (t >> 5) * b_blk + b_pl + (t & 31u) * 16u);
     };
 #pragma unroll
     for (int d = 0; d < W24G_D; ++d) {
@@ -498,48 +479,70 @@ __global__ void __launch_bounds__(256, 1) wino24g_wgrad_kernel(const W24WgGemmPa
         }
 }
 
-// out[rl][cl][3][3] = G4^T (sum_s dU_s) G6.  256 threads = 64 (r, c) pairs x 4 split-phases (fixed order: deterministic).
+// out[rl][cl][3][3] = G4^T (sum_s dU_s) G6.  A thread owns four consecutive (r, c) pairs (16-byte loads of all 24 planes); the
+// splits are dealt to PHS lane groups of a wave and combined with two fixed shuffle steps: the summation order is fixed
+// (deterministic).  Plane row i = 2 carries the forward image's sign convention (row 2 of B4^T negated) and is flipped here.
 struct W24GReduceParams {
     const float* partial; float* out;
     int nsplit, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p;
 };
 
+template <int PHS>
 __global__ void __launch_bounds__(256) wino24g_wgrad_reduce_kernel(const W24GReduceParams p) {
-    __shared__ float red[4][24][64];                                   // [phase][plane][pair]
-    const int pr = threadIdx.x & 63, ph = threadIdx.x >> 6;
-    const long long npair = (long long)p.Rp * p.Cp;
-    const size_t plane_sz = (size_t)npair, split_sz = plane_sz * 24;
-    for (long long base = (long long)blockIdx.x * 64; base < npair; base += (long long)gridDim.x * 64) {
-        const long long e = base + pr;
-        float s[24];
+    constexpr int QW = 64 / PHS;                                       // quads per wave
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = lane % QW, ph = lane / QW;
+    const long long nquad = (long long)p.Rp * p.Cp / 4;
+    const size_t plane_sz = (size_t)p.Rp * p.Cp, split_sz = plane_sz * 24;
+    for (long long base = ((long long)blockIdx.x * 4 + wv) * QW; base < nquad; base += (long long)gridDim.x * 4 * QW) {
+        const long long quad = base + q;
+        const bool ok = quad < nquad;
+        float4 s[24];
 #pragma unroll
-        for (int i = 0; i < 24; ++i) s[i] = 0.f;
-        if (e < npair)
-            for (int k = ph; k < p.nsplit; k += 4) {
-                const float* q = p.partial + (size_t)k * split_sz + (size_t)e;
+        for (int i = 0; i < 24; ++i) s[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok)
+            for (int k = ph; k < p.nsplit; k += PHS) {
+                const float* src = p.partial + (size_t)k * split_sz + (size_t)quad * 4;
 #pragma unroll
-                for (int i = 0; i < 24; ++i) s[i] += q[(size_t)i * plane_sz];
+                for (int i = 0; i < 24; ++i) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)i * plane_sz);
+                    s[i].x += v.x; s[i].y += v.y; s[i].z += v.z; s[i].w += v.w;
+                }
             }
+        if constexpr (PHS > 1) {
 #pragma unroll
-        for (int i = 0; i < 24; ++i) red[ph][i][pr] = s[i];
-        __syncthreads();
-        if (threadIdx.x < 64 && e < npair) {
-            float U[4][6];
+            for (int i = 0; i < 24; ++i) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) U[i][j] = (red[0][6 * i + j][pr] + red[1][6 * i + j][pr]) + (red[2][6 * i + j][pr] + red[3][6 * i + j][pr]);
-            // rows: t = G4^T U, G4 = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
-            float t[3][6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                t[0][j] = U[0][j] + 0.5f * (U[1][j] + U[2][j]);
-                t[1][j] = 0.5f * (U[1][j] - U[2][j]);
-                t[2][j] = U[3][j] + 0.5f * (U[1][j] + U[2][j]);
+                for (int o = QW; o < 64; o *= 2) {
+                    s[i].x += __shfl_xor(s[i].x, o); s[i].y += __shfl_xor(s[i].y, o);
+                    s[i].z += __shfl_xor(s[i].z, o); s[i].w += __shfl_xor(s[i].w, o);
+                }
             }
-            const int cp = (int)(e % p.Cp), rp = (int)(e / p.Cp);
-            const int rl = wn_phys2log(rp, p.r_seg0, p.r_seg0p, p.R), cl = wn_phys2log(cp, p.c_seg0, p.c_seg0p, p.C);
-            if (rl >= 0 && cl >= 0) {
+        }
+        if (ph == 0 && ok) {
+            const int rp = (int)((quad * 4) / p.Cp), cp0 = (int)((quad * 4) % p.Cp);
+            const int rl = wn_phys2log(rp, p.r_seg0, p.r_seg0p, p.R);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int cl = wn_phys2log(cp0 + e, p.c_seg0, p.c_seg0p, p.C);
+                if (rl < 0 || cl < 0) continue;
+                float U[4][6];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const float4 v = s[6 * i + j];
+                        const float x = e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w));
+                        U[i][j] = i == 2 ? -x : x;
+                    }
+                // rows: t = G4^T U, G4 = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+                float t[3][6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    t[0][j] = U[0][j] + 0.5f * (U[1][j] + U[2][j]);
+                    t[1][j] = 0.5f * (U[1][j] - U[2][j]);
+                    t[2][j] = U[3][j] + 0.5f * (U[1][j] + U[2][j]);
+                }
                 float* o = p.out + ((size_t)rl * p.C + cl) * 9;
                 // columns: dg = t G6, G6 = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]]
 #pragma unroll
@@ -551,7 +554,6 @@ __global__ void __launch_bounds__(256) wino24g_wgrad_reduce_kernel(const W24GRed
                 }
             }
         }
-        __syncthreads();
     }
 }
 
@@ -567,22 +569,30 @@ static long long w24g_tiles(int B, int H, int W) {
 
 using namespace clamd;
 
-// split-K plan of the weight-gradient GEMM: workgroups = 24 planes x (Rp/256) x (Cp/256) x nsplit, aimed at a whole number
-// of rounds of the chip; tiles per split a multiple of 2 * W24G_D (whole passes of the prefetch ring)
-static int w24g_wg_plan(long long T, int Rp, int Cp, const clamd_tuning& tn, int* tp_out, int* per_out) {
+// Split-K plan of the weight-gradient GEMM: workgroups = 24 planes x (Rp/256) x (Cp/256) x nsplit.  A workgroup costs
+// (tiles / 2) k-steps of 16 fp32 MFMAs (1024 cycles) plus ~28k cycles of prologue latency and slab stores (256 KB per
+// workgroup; measured, tools/wino24g_ab.py), the chip runs ceil(workgroups / CUs) rounds of them, and the reduce pass reads
+// every slab once: pick the split count with the smallest modelled time.  Tiles per split: a multiple of 2 W24G_D (whole
+// passes of the prefetch ring).
+static int w24g_wg_plan(long long Tp, int Rp, int Cp, const clamd_tuning& tn, int* per_out) {
     const int quant = 2 * W24G_D;
-    const long long Tp = (T + quant - 1) / quant * quant;
     const int nb = 24 * (Rp / 256) * (Cp / 256);
     const int cus = clamd_usable_cus(tn);
-    // target: three rounds of the chip (768 workgroups on 256 CUs), at least 4 passes of the ring per workgroup
-    long long nsplit = std::max<long long>(1, (3LL * cus) / nb);
-    nsplit = std::min<long long>(nsplit, std::max<long long>(1, Tp / (4 * quant)));
-    long long per = (Tp + nsplit - 1) / nsplit;
-    per = (per + quant - 1) / quant * quant;
-    nsplit = (Tp + per - 1) / per;
-    if (tp_out) *tp_out = (int)Tp;
-    if (per_out) *per_out = (int)per;
-    return (int)nsplit;
+    const long long max_split = std::max<long long>(1, std::min<long long>((3LL * clamd_num_cus()) / nb, Tp / quant));
+    double best = 0;
+    long long best_ns = 1, best_per = Tp;
+    for (long long ns = 1; ns <= max_split; ++ns) {
+        long long per = (Tp + ns - 1) / ns;
+        per = (per + quant - 1) / quant * quant;
+        const long long n = (Tp + per - 1) / per;                           // splits that are not empty
+        if (n != ns) continue;
+        const double rounds = (double)((nb * n + cus - 1) / cus);
+        const double cycles = rounds * (per / 2 * 1024.0 + 28000.0);
+        const double t = cycles / 2.3e9 + (double)nb * n * 262144.0 / 4.5e12;
+        if (best == 0 || t < best) { best = t; best_ns = n; best_per = per; }
+    }
+    if (per_out) *per_out = (int)best_per;
+    return (int)best_ns;
 }
 
 extern "C" {
@@ -636,50 +646,58 @@ int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const floa
     return clamd_check_launch("conv3x3_winograd24_pre");
 }
 
-size_t clamd_wgrad_winograd24_pre_operand_elems(int B, int H, int W, int Cp) {
-    if (B <= 0 || H <= 0 || W <= 0 || Cp <= 0) return 0;
-    const long long T = (long long)B * (H / 2) * (W / 4), quant = 2 * W24G_D;
-    return (size_t)(24 * ((T + quant - 1) / quant * quant)) * (size_t)Cp;
+size_t clamd_wgrad_winograd24_pre_operand_elems(int B, int H, int W, int Rp) {
+    if (B <= 0 || H <= 0 || W <= 0 || Rp <= 0) return 0;
+    return (size_t)(24 * w24g_tiles(B, H, W) * 32) * (size_t)Rp;
 }
 
 size_t clamd_wgrad_winograd24_pre_workspace_bytes(int B, int H, int W, int Rp, int Cp) {
     if (B <= 0 || H <= 0 || W <= 0 || Rp < 256 || Cp < 256) return 0;
-    // upper bound over cu_reserve: the plan with every CU
-    clamd_tuning tn = clamd_default_tuning();
-    tn.cu_reserve = 0;
-    const int nsplit = w24g_wg_plan((long long)B * (H / 2) * (W / 4), Rp, Cp, tn, nullptr, nullptr);
-    return (size_t)nsplit * 24 * Rp * Cp * sizeof(float);
+    const long long Tp = w24g_tiles(B, H, W) * 32;
+    const long long nb = 24LL * (Rp / 256) * (Cp / 256);
+    const long long max_split = std::max<long long>(1, std::min<long long>((3LL * clamd_num_cus()) / nb, Tp / (2 * W24G_D)));
+    return (size_t)max_split * 24 * Rp * Cp * sizeof(float);
 }
 
-int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* x, int x_ldc, float* yt, float* vx, float* workspace,
-                               size_t ws_bytes, float* out, int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0,
-                               int r_seg0p, int c_seg0, int c_seg0p, const clamd_tuning* tune, void* stream) {
+int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, float* yt, float* workspace, size_t ws_bytes, float* out,
+                               int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p,
+                               const clamd_tuning* tune, void* stream) {
     if (int e = clamd_check_tuning(tune)) return e;
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("wgrad_winograd24_pre: empty problem");
     if ((H & 1) || (W & 3)) return clamd_fail("wgrad_winograd24_pre: H must be even and W a multiple of 4");
-    if (Rp % 256 || Cp % 256 || Rp <= 0 || Cp <= 0 || gz_ldc % 4 || x_ldc % 4) return clamd_fail("wgrad_winograd24_pre: needs Rp and Cp multiples of 256");
-    if ((long long)H * W * gz_ldc * 4 >= (1ll << 31) || (long long)H * W * x_ldc * 4 >= (1ll << 31)) return clamd_fail("wgrad_winograd24_pre: one image exceeds 2^31 bytes");
+    if (Rp % 256 || Cp % 256 || Rp <= 0 || Cp <= 0 || gz_ldc % 4) return clamd_fail("wgrad_winograd24_pre: needs Rp and Cp multiples of 256");
+    if ((long long)H * W * gz_ldc * 4 >= (1ll << 31)) return clamd_fail("wgrad_winograd24_pre: one image exceeds 2^31 bytes");
     const clamd_tuning& tn = clamd_tune(tune);
-    const long long T = (long long)B * (H / 2) * (W / 4);
-    int Tp = 0, per = 0;
-    const int nsplit = w24g_wg_plan(T, Rp, Cp, tn, &Tp, &per);
-    if ((long long)Tp * std::max(Rp, Cp) * 4 >= (1ll << 32)) return clamd_fail("wgrad_winograd24_pre: one operand plane exceeds 2^32 bytes");
+    const long long ntm = w24g_tiles(B, H, W), Tp = ntm * 32;
+    if (Tp * Rp * 4 >= (1ll << 32) || (unsigned long long)ntm * (Cp / 8) * 24 * 1024 >= (1ull << 32))
+        return clamd_fail("wgrad_winograd24_pre: an operand exceeds 2^32 bytes");
+    int per = 0;
+    const int nsplit = w24g_wg_plan(Tp, Rp, Cp, tn, &per);
     if ((size_t)nsplit * 24 * Rp * Cp * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd24_pre: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     {
-        W24WgXformParams pa{gz, gz_ldc, yt, B, H, W, Rp, (int)T, Tp}, pb{x, x_ldc, vx, B, H, W, Cp, (int)T, Tp};
-        const long long na = ((long long)Tp * (Rp / 4) + 255) / 256, nb = ((long long)Tp * (Cp / 4) + 255) / 256;
-        hipLaunchKernelGGL(wino24g_wgrad_xform_kernel<0>, dim3((unsigned)std::min<long long>(na, 1 << 20)), dim3(256), 0, s, pa);
-        hipLaunchKernelGGL(wino24g_wgrad_xform_kernel<1>, dim3((unsigned)std::min<long long>(nb, 1 << 20)), dim3(256), 0, s, pb);
-        if (int e = clamd_check_launch("wgrad_winograd24_pre transforms")) return e;
+        W24WgXformParams pa{gz, gz_ldc, yt, B, H, W, Rp, (int)Tp};
+        const long long na = (Tp * (Rp / 4) + 255) / 256;
+        const unsigned g = (unsigned)std::min<long long>(na, 1 << 20);
+        if (W >= 32) hipLaunchKernelGGL(wino24g_wgrad_xform_kernel<8>, dim3(g), dim3(256), 0, s, pa);
+        else hipLaunchKernelGGL(wino24g_wgrad_xform_kernel<4>, dim3(g), dim3(256), 0, s, pa);
+        if (int e = clamd_check_launch("wgrad_winograd24_pre transform")) return e;
     }
-    W24WgGemmParams p{yt, vx, workspace, Rp, Cp, Tp, nsplit, per};
+    W24WgGemmParams p{yt, v, workspace, Rp, Cp, (int)Tp, nsplit, per};
     hipLaunchKernelGGL(wino24g_wgrad_kernel, dim3((unsigned)(24 * nsplit * (Rp / 256) * (Cp / 256))), dim3(256), 0, s, p);
     if (int e = clamd_check_launch("wgrad_winograd24_pre")) return e;
     W24GReduceParams rp{workspace, out, nsplit, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p};
-    long long g = ((long long)Rp * Cp + 63) / 64;
-    if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(wino24g_wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, rp);
+    const long long nquad = (long long)Rp * Cp / 4;
+#define W24G_REDUCE(PHS_)                                                                                              \
+    do {                                                                                                               \
+        long long g = (nquad + 4 * (64 / PHS_) - 1) / (4 * (64 / PHS_));                                               \
+        if (g > 8192) g = 8192;                                                                                        \
+        hipLaunchKernelGGL(wino24g_wgrad_reduce_kernel<PHS_>, dim3((unsigned)g), dim3(256), 0, s, rp);                 \
+    } while (0)
+    if (nsplit >= 4 && nquad <= 65536) W24G_REDUCE(4);
+    else if (nsplit >= 2 && nquad <= 131072) W24G_REDUCE(2);
+    else W24G_REDUCE(1);
+#undef W24G_REDUCE
     return clamd_check_launch("wgrad_winograd24_pre_reduce");
 }
 

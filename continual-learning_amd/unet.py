@@ -36,6 +36,13 @@ WINOGRAD24 = True
 # (tools/wino24_wgrad_ab.py: 1.02-1.04x there, 0.88-1.00x on the deep layers -- both operands are transformed in the loop,
 # 3.5 transform VALU per MFMA, so the 25 % fewer MFMAs buy little); True = everywhere it applies; False = F(2x2,3x3).
 WINOGRAD24_WGRAD = 'auto'
+# ... and, for the wide layers, with the operands transformed ONCE per tensor (csrc/wino24g.hip): the in-kernel transform is
+# redone by every output-slab workgroup (8-16x per tile at 512/1024 channels) and costs 2-3.5 VALU per fp32 MFMA; the
+# transform-free K loop runs at 0.77-0.90 of the MFMA pipe instead of 0.57-0.66 (tools/wino24g_ab.py).  The transformed
+# input (3x the activation) is kept from the forward pass and is also the x-side operand of the weight-gradient GEMM.
+# 'auto' = where the transform pass pays for itself (see _Engine.unit); False = never.
+PRETRANSFORM = os.environ.get('CLAMD_PRETRANSFORM', 'auto')
+PRETRANSFORM = {'0': False, 'false': False, '1': True, 'true': True}.get(str(PRETRANSFORM).lower(), 'auto')
 # Weight-gradient kernels (and the bias-gradient channel sums of the ConvTranspose / head layers) go to a second HIP stream:
 # they are off the critical chain of the backward pass (dgrad -> BatchNorm-backward reduce / finalize / apply -> dgrad ...),
 # and the HBM-bound BatchNorm passes of the NEXT unit fit beside a weight-gradient workgroup on the same CU (one wave per
@@ -285,8 +292,21 @@ class _Engine:
             # ... data gradient: F(2x4) tiles are 256 pixels x 64 (input) channels; a launch with at most half a chip of them runs
             # the F(2x2) kernel instead, whose 128-pixel tiles give twice the work items (1024 -> 512 @16x16, the data gradient of
             # dec1.block.0: 128 items, 238 us against 160 us, tools/wino24_ab.py)
-            items24 = B * ((u.h + 7) // 8 * ((u.w_ + 31) // 32) if u.w_ >= 32 else (u.h + 15) // 16 * ((u.w_ + 15) // 16)) * (u.cin_p // 64)
+            items24 = B * ((u.h + 7) // 8 * ((u.w_ + 31) // 32) if u.w_ >= 32 else (u.h + 15) // 16 * ((u.w_ + 15) // 16)) * ((u.cin_p + 63) // 64)
             u.w24d = u.w24 and not (2 * items24 <= (torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == 'cuda' else 256))
+            # pre-transformed operands (wino24g.hip).  Weight gradient: both channel counts multiples of 256 (a wave owns a 128 x 128
+            # block, a workgroup 256 x 256).  Forward: >= 256 input channels, and either the image is needed by the weight gradient
+            # anyway or there are enough output channels to amortise the transform pass (its cost grows with Cin, the kernel's gain
+            # with Cin x Cout: 512 -> 256 @64x64 loses 6 %, 256 -> 128 @128x128 26 %, tools/wino24g_ab.py).  Data gradient: the
+            # same with the roles of the channel counts exchanged; the transformed gradient is used once and not kept.
+            pt = PRETRANSFORM
+            u.pre_w = bool(pt) and u.w24 and u.cin_p % 256 == 0 and u.cout_p % 256 == 0
+            u.pre_f = bool(pt) and u.w24 and u.cin_p >= 64 and u.cout_p % 64 == 0 and (
+                pt is True or (u.cin_p >= 256 and (u.pre_w or 2 * u.cout_p > u.cin_p)))
+            u.pre_w = u.pre_w and u.pre_f
+            u.pre_d = bool(pt) and u.w24d and not first_of_net and u.cout_p >= 64 and u.cin_p % 64 == 0 and (
+                pt is True or (u.cout_p >= 256 and 2 * u.cin_p > u.cout_p))
+            u.vx = torch.empty(lib.clamd_winograd24_input_elems(B, u.h, u.w_, u.cin_p), dtype=torch.float32, device=dev) if u.pre_f else None
             ntap = 1 if u.im2col else ((24 if u.w24 else 16) if u.wino else 9)   # Winograd: [Cin_p/8][16|24][Cout_p][8] transformed filters
             ntap_d = (24 if u.w24d else 16) if u.wino else ntap
             u.wf = torch.zeros(ntap * u.cout_p * u.cin_p, dtype=T, device=dev)
@@ -378,6 +398,8 @@ class _Engine:
                 ws = max(ws, lib.clamd_wgrad_winograd_workspace_bytes(u.cout_p, u.cin_p))
             if u.w24g:
                 ws = max(ws, lib.clamd_wgrad_winograd24_workspace_bytes(u.cout_p, u.cin_p))
+            if u.pre_w:
+                ws = max(ws, lib.clamd_wgrad_winograd24_pre_workspace_bytes(B, u.h, u.w_, u.cout_p, u.cin_p))
         for s in self.stages:
             t = s.get('tail')
             if t is not None:
@@ -385,6 +407,12 @@ class _Engine:
                 rp, cp_ = (t.cin_p, t.cout_p) if t.kind == 'convT' else (t.cout_p, t.cin_p)
                 ws = max(ws, lib.clamd_wgrad_workspace_bytes(mode, B, H >> t.level, W >> t.level, rp, cp_, self.dcode))
         self.ws = torch.empty(ws // 4 + 16, dtype=torch.float32, device=dev)
+        # scratch of the pre-transformed kernels: the transformed gradient of the data-gradient launch (main stream) and the
+        # gradient-side operand of the weight-gradient GEMM (second stream); launches on one stream are serialised, so one each
+        nvg = max([lib.clamd_winograd24_input_elems(B, u.h, u.w_, u.cout_p) for u in convs if u.pre_d] + [0])
+        nyt = max([lib.clamd_wgrad_winograd24_pre_operand_elems(B, u.h, u.w_, u.cout_p) for u in convs if u.pre_w] + [0])
+        self.vg = torch.empty(nvg, dtype=torch.float32, device=dev) if nvg else None
+        self.yt = torch.empty(nyt, dtype=torch.float32, device=dev) if nyt else None
         self.wg_stream = _second_stream(dev) if (WGRAD_STREAM and dev.type == 'cuda') else None
         self._wg_used = False
         self._pack_pending = 0
@@ -542,7 +570,7 @@ class _Engine:
         """Multiply-adds the kernel executes per algorithmic (direct-convolution) multiply-add of unit u."""
         if not u.wino:
             return 1.0
-        return 24.0 / 72.0 if {'wgrad': u.w24g, 'dgrad': u.w24d}.get(direction, u.w24) else 16.0 / 36.0
+        return 24.0 / 72.0 if {'wgrad': u.w24g or u.pre_w, 'dgrad': u.w24d}.get(direction, u.w24) else 16.0 / 36.0
 
     def executed_flop_deficit(self):
         """Algorithmic minus executed FLOPs of one train step (3x3 convolutions by Winograd), for bench.py."""
@@ -577,9 +605,16 @@ class _Engine:
             if self._pack_pending == 1 and u.pack_late:
                 torch.cuda.current_stream().wait_stream(self.wg_stream)
                 self._pack_pending = 0
-            _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
-                   'clamd_conv3x3_winograd24' if u.w24 else 'clamd_conv3x3_winograd', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
-                   ptr(u.stats) if training else None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
+            if u.pre_f:
+                _timed('wino_transform', 0.0, 16 * B * u.h * u.w_ * u.cin_p,        # reads the activation once, writes 3x its size
+                       'clamd_winograd24_transform_input', ptr(u.xin), u.xin_ldc, ptr(u.vx), B, u.h, u.w_, u.cin_p, s)
+                _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
+                       'clamd_conv3x3_winograd24_pre', ptr(u.vx), ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
+                       ptr(u.stats) if training else None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
+            else:
+                _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
+                       'clamd_conv3x3_winograd24' if u.w24 else 'clamd_conv3x3_winograd', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
+                       ptr(u.stats) if training else None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
         else:
             _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
                    'clamd_conv3x3', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
@@ -687,7 +722,13 @@ class _Engine:
         flops = 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout
         def dgrad():
             _TIMED_UNIT[:] = [u.name + ' dgrad', self.executed_fraction(u, 'dgrad')]
-            if u.g_in is not None and u.wino:
+            if u.g_in is not None and u.pre_d:
+                _timed('wino_transform', 0.0, 16 * B * u.h * u.w_ * u.cout_p,      # reads the gradient once, writes 3x its size
+                       'clamd_winograd24_transform_input', ptr(u.gz), u.cout_p, ptr(self.vg), B, u.h, u.w_, u.cout_p, s)
+                _timed('igemm_conv3x3', flops, self._conv_bytes(u),
+                       'clamd_conv3x3_winograd24_pre', ptr(self.vg), ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
+                       B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
+            elif u.g_in is not None and u.wino:
                 _timed('igemm_conv3x3', flops, self._conv_bytes(u),
                        'clamd_conv3x3_winograd24' if u.w24d else 'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
                        B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
@@ -712,7 +753,11 @@ class _Engine:
                  g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, 9 * u.cin, u.cout, u.cout_p, 9 * u.cin, u.cin_p, dc, tp, sw)
             return
         _TIMED_UNIT[:] = [u.name + ' wgrad', self.executed_fraction(u, 'wgrad')]
-        if u.wino:
+        if u.pre_w:
+            _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
+                   'clamd_wgrad_winograd24_pre', ptr(u.gz), u.cout_p, ptr(u.vx), ptr(self.yt), ptr(self.ws), self.ws_bytes,
+                   g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, tp, sw)
+        elif u.wino:
             _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
                    'clamd_wgrad_winograd24' if u.w24g else 'clamd_wgrad_winograd', ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
                    g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, tp, sw)

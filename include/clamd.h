@@ -130,15 +130,16 @@ int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const floa
                                  float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
                                  const clamd_tuning* tune, void* stream);
 /* Weight gradient of the same convolution as a batched GEMM over the 24 Winograd planes (K = tiles) on operands transformed
- * once: yt / vx = caller-provided scratch of clamd_wgrad_winograd24_pre_operand_elems(B,H,W,Rp) / (..,Cp) floats
- * (A4 dY A6^T and B4^T d B6, [24][tiles][channels]); every wave owns a 128 x 128 block of one plane (16 MFMAs per two
- * 16-byte loads, no LDS); split-K slabs in `workspace` (>= clamd_wgrad_winograd24_pre_workspace_bytes), fixed-order reduce
- * with G4^T . G6: deterministic.  Rp and Cp multiples of 256; other arguments as clamd_wgrad_winograd24. */
-size_t clamd_wgrad_winograd24_pre_operand_elems(int B, int H, int W, int Cp);
+ * once: v = the forward image of the convolution INPUT (clamd_winograd24_transform_input, kept from the forward pass: it is
+ * read in place as the x-side operand), yt = caller-provided scratch of clamd_wgrad_winograd24_pre_operand_elems(B,H,W,Rp)
+ * floats for A4 dY A6^T of gz ([24][tiles][Rp], written here).  Every wave owns a 128 x 128 block of one plane (16 MFMAs per
+ * two 16-byte loads, no LDS); split-K slabs in `workspace` (>= clamd_wgrad_winograd24_pre_workspace_bytes), fixed-order
+ * reduce with G4^T . G6: deterministic.  Rp and Cp multiples of 256; other arguments as clamd_wgrad_winograd24. */
+size_t clamd_wgrad_winograd24_pre_operand_elems(int B, int H, int W, int Rp);
 size_t clamd_wgrad_winograd24_pre_workspace_bytes(int B, int H, int W, int Rp, int Cp);
-int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* x, int x_ldc, float* yt, float* vx, float* workspace,
-                               size_t ws_bytes, float* out, int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0,
-                               int r_seg0p, int c_seg0, int c_seg0p, const clamd_tuning* tune, void* stream);
+int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, float* yt, float* workspace, size_t ws_bytes, float* out,
+                               int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p,
+                               const clamd_tuning* tune, void* stream);
 /* Weight gradient of the same convolution by Winograd (fp32, H and W even): out [R][C][3][3] = G^T (sum over tiles of
  * (A dY A^T) x (B^T d B)) G; arguments as clamd_wgrad(CLAMD_WGRAD_CONV3, ...) (gz = d loss / d conv output, x = conv input). */
 size_t clamd_wgrad_winograd_workspace_bytes(int Rp, int Cp);

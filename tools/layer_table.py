@@ -43,7 +43,8 @@ for _ in range(3):
     torch.cuda.synchronize()
     U.KERNEL_TIMING = None
     for tag, flops, e0, e1, nbytes, unit, frac in ev:
-        a = acc.setdefault(unit, [0.0, flops, 0, frac])
+        xf = tag == 'wino_transform'            # the input transform of a pre-transformed launch: its own (HBM-bound) row
+        a = acc.setdefault(unit + (' xform' if xf else ''), [0.0, nbytes if xf else flops, 0, frac])
         a[0] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
 eng = next(iter(m._engines.values()))
@@ -52,10 +53,16 @@ print(f'{"unit":22s} {"us":>8s} {"alg TF/s":>9s} {"of peak":>8s}')
 for unit, (sec, flops, n, ex) in acc.items():
     t = sec / n
     u = [c for c in eng.convs if unit.startswith(c.name + ' ')][0]
+    if unit.endswith(' xform'):
+        print(f'{unit:22s} {t * 1e6:8.1f} {flops / t / 1e12:6.2f} TB/s          transform of the launch below')
+        tt = tot.setdefault('xform', [0.0, 0.0])
+        tt[0] += t
+        continue
     tf = flops / t / 1e12
-    print(f'{unit:22s} {t * 1e6:8.1f} {tf:9.1f} {tf * ex / PEAK:8.3f}   {u.cin}->{u.cout} @{u.h}x{u.w_}')
+    pre = {'fwd': u.pre_f, 'dgrad': u.pre_d, 'wgrad': u.pre_w}.get(unit.split()[-1], False)
+    print(f'{unit:22s} {t * 1e6:8.1f} {tf:9.1f} {tf * ex / PEAK:8.3f}   {u.cin}->{u.cout} @{u.h}x{u.w_}{"  pre-transformed" if pre else ""}')
     d = unit.split()[-1]
     tt = tot.setdefault(d, [0.0, 0.0])
     tt[0] += t; tt[1] += flops
 for d, (t, f) in tot.items():
-    print(f'total {d:6s} {t * 1e3:7.3f} ms  {f / t / 1e12:7.1f} alg TF/s')
+    print(f'total {d:6s} {t * 1e3:7.3f} ms' + (f'  {f / t / 1e12:7.1f} alg TF/s' if f else ''))
