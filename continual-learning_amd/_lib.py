@@ -98,9 +98,13 @@ SIGNATURES = {
     'clamd_voc_prepare': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_label_to_rgb': (_I, [_P, _P, _LL, _LL, _P]),
     'clamd_fill_f32': (_I, [_P, _LL, _D, _P]),
-    'clamd_debug_hold_cus': (_I, [_I, _I, _P]),
+    'clamd_f32_to_bf16': (_I, [_P, _P, _LL, _P]),
+    'clamd_bf16_to_f32': (_I, [_P, _P, _LL, _P]),
     'clamd_scale_by_device_scalar': (_I, [_P, _LL, _P, _P]),
 }
+
+# include/clamd_debug.h: measurement scaffolding (tools/cu_steal.py), bound when present, never part of the product header
+DEBUG_SIGNATURES = {'clamd_debug_hold_cus': (_I, [_I, _I, _P])}
 
 _lib = None
 
@@ -118,6 +122,11 @@ def load():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in DEBUG_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 

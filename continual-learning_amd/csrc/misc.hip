@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include "common.hip.h"
 #include "clamd_internal.h"
+#include "../../include/clamd_debug.h"
 
 static thread_local char g_err[512] = "";
 
@@ -292,9 +293,29 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamTensor* __restrict_
         }
     }
     if (l2_accum) {
+        // no float atomics: one partial per workgroup (shuffle tree, then the four waves in a fixed order); adam_l2_final_kernel
+        // adds the partials in a fixed order, so the reported penalty is bit-reproducible
+        __shared__ float wsum[4];
         l2sum = wave_sum(l2sum);
-        if ((threadIdx.x & 63) == 0 && l2sum != 0.f) atomicAdd(l2_accum, l2sum);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = l2sum;
+        __syncthreads();
+        if (threadIdx.x == 0) l2_accum[1 + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
     }
+}
+
+// l2[0] = sum of the per-workgroup partials l2[1 .. n] in a fixed order (fp64): thread t adds partials t, t + 256, ...; then a
+// fixed tree over the 256 threads
+__global__ void __launch_bounds__(256) adam_l2_final_kernel(float* l2, int n) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)l2[1 + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) l2[0] = (float)red[0];
 }
 
 // ------------------------------------------------------------------------------------------------ metrics
@@ -403,6 +424,40 @@ __global__ void __launch_bounds__(256) hold_cus_kernel(unsigned long long ticks,
     if (ticks == ~0ull && sink) sink[0] = pad[threadIdx.x];       // never true: keeps the LDS allocation alive
 }
 
+// gradient exchange in bf16 (ddp.GradSync(grad_dtype='bf16'), BASELINE.json configs[2]/[4] "bf16 DDP"): a bucket of the flat
+// fp32 gradient buffer is rounded to bf16 (rne) for the all-reduce and widened back afterwards.  A bucket starts at an
+// arbitrary element of the flat buffer: `head` leading elements are converted one by one, the aligned body 8 per thread and
+// pass (the bf16 buffer is placed at the same element phase, checked on entry), then the tail.
+__global__ void __launch_bounds__(256) f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long long n, int head) {
+    const long long nb = n - head, nv = nb >> 3;
+    const float* sb = src + head;
+    uint16_t* db = dst + head;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(sb)[2 * i], b = reinterpret_cast<const float4*>(sb)[2 * i + 1];
+        reinterpret_cast<uint4*>(db)[i] = make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
+    }
+    if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < head) dst[threadIdx.x] = f2bf(src[threadIdx.x]);
+        if ((long long)threadIdx.x < (nb & 7)) db[(nv << 3) + threadIdx.x] = f2bf(sb[(nv << 3) + threadIdx.x]);
+    }
+}
+__global__ void __launch_bounds__(256) bf16_to_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, long long n, int head) {
+    const long long nb = n - head, nv = nb >> 3;
+    const uint16_t* sb = src + head;
+    float* db = dst + head;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+        const uint4 u = reinterpret_cast<const uint4*>(sb)[i];
+        reinterpret_cast<float4*>(db)[2 * i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+        reinterpret_cast<float4*>(db)[2 * i + 1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                                                               __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+    }
+    if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < head) dst[threadIdx.x] = bf2f(src[threadIdx.x]);
+        if ((long long)threadIdx.x < (nb & 7)) db[(nv << 3) + threadIdx.x] = bf2f(sb[(nv << 3) + threadIdx.x]);
+    }
+}
+
 __global__ void fill_kernel(float* p, long long n, float v) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -465,6 +520,7 @@ int clamd_adam_step(const void* tensors_dev, const void* chunks_dev, int nchunks
     hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, s, hyper_dev, step_dev, derived_dev);
     hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, s, (const AdamTensor*)tensors_dev,
                        (const AdamChunk*)chunks_dev, hyper_dev, derived_dev, l2_accum_dev);
+    if (l2_accum_dev) hipLaunchKernelGGL(adam_l2_final_kernel, dim3(1), dim3(256), 0, s, l2_accum_dev, nchunks);
     return clamd_check_launch("adam_step");
 }
 
@@ -519,6 +575,38 @@ int clamd_fill_f32(float* p, long long n, double v, void* stream) {
     if (g < 1) g = 1;
     hipLaunchKernelGGL(fill_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, p, n, (float)v);
     return clamd_check_launch("fill");
+}
+
+// leading elements up to the first 32-byte boundary of the fp32 side; the bf16 side must sit at the same element phase
+static int bf16_head(const void* f32, const void* bf16, long long n, int* head) {
+    const unsigned long long a = (unsigned long long)f32, b = (unsigned long long)bf16;
+    if ((a & 3ull) || (b & 1ull)) return -1;
+    if (((a >> 2) & 7ull) != ((b >> 1) & 7ull)) return -1;
+    const int h = (int)((8 - ((a >> 2) & 7ull)) & 7ull);
+    *head = (long long)h < n ? h : (int)n;
+    return 0;
+}
+
+int clamd_f32_to_bf16(const float* src, void* dst, long long n, void* stream) {
+    if (n <= 0 || !src || !dst) return clamd_fail("f32_to_bf16: bad arguments");
+    int head = 0;
+    if (bf16_head(src, dst, n, &head)) return clamd_fail("f32_to_bf16: the bf16 buffer must sit at the fp32 buffer's element phase ((addr / elem size) % 8)");
+    long long g = (((n - head) >> 3) + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, n, head);
+    return clamd_check_launch("f32_to_bf16");
+}
+
+int clamd_bf16_to_f32(const void* src, float* dst, long long n, void* stream) {
+    if (n <= 0 || !src || !dst) return clamd_fail("bf16_to_f32: bad arguments");
+    int head = 0;
+    if (bf16_head(dst, src, n, &head)) return clamd_fail("bf16_to_f32: the bf16 buffer must sit at the fp32 buffer's element phase ((addr / elem size) % 8)");
+    long long g = (((n - head) >> 3) + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, dst, n, head);
+    return clamd_check_launch("bf16_to_f32");
 }
 
 }  // extern "C"

@@ -29,21 +29,44 @@ def init_rccl(device, max_channels=RCCL_MAX_CHANNELS, **kw):
     """``init_process_group('nccl')`` (= RCCL on ROCm) with the channel cap in place.  NCCL_MAX_NCHANNELS /
     NCCL_MIN_NCHANNELS already present in the environment win.  Returns the settings (bench.py records them)."""
     os.environ.setdefault('NCCL_MAX_NCHANNELS', str(max_channels))
-    os.environ.setdefault('NCCL_MIN_NCHANNELS', str(min(4, max_channels)))
+    # MIN follows the EFFECTIVE maximum (a pre-set NCCL_MAX_NCHANNELS of 1-3 must not end up below the minimum)
+    eff_max = int(os.environ['NCCL_MAX_NCHANNELS'])
+    os.environ.setdefault('NCCL_MIN_NCHANNELS', str(max(1, min(4, eff_max))))
+    if int(os.environ['NCCL_MIN_NCHANNELS']) > eff_max:
+        os.environ['NCCL_MIN_NCHANNELS'] = str(eff_max)
+    # Streams are multiplexed onto GPU_MAX_HW_QUEUES hardware queues in creation order and a kernel waits behind whatever
+    # shares its queue; a rank has the default stream, the engine's second stream, GradSync's stream and RCCL's.  The runtime
+    # reads the variable when it starts: set it here only if HIP has not been initialised yet (bench.py sets it at import time).
+    if not torch.cuda.is_initialized():
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     dist.init_process_group('nccl', device_id=device, **kw)
     return rccl_settings()
 
 
 def rccl_settings():
     return {'backend': dist.get_backend() if dist.is_initialized() else None,
-            'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS'), 'NCCL_MIN_NCHANNELS': os.environ.get('NCCL_MIN_NCHANNELS')}
+            'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS'), 'NCCL_MIN_NCHANNELS': os.environ.get('NCCL_MIN_NCHANNELS'),
+            'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES')}
 
 
 class GradSync:
+    """``grad_dtype``: 'fp32' exchanges the flat fp32 gradient buffer as it is (124 MB per step for UNet(21,3,64));
+    'bf16' rounds every bucket to bf16 on the side stream, all-reduces 62 MB and widens the sums back (BASELINE.json
+    configs[2]/[4] "bf16 DDP": the bf16 backward pass is ~4 ms, so the exchange it has to hide is halved); None = 'bf16' for a
+    ``compute_dtype='bf16'`` model, 'fp32' otherwise (fp32 and bf16x3 keep bit-level equality with the one-rank step)."""
+
     def __init__(self, model, optimizer=None, process_group=None, min_bucket_bytes=4 << 20, cu_reserve=None, timing=False,
-                 wino_per_tile=None):
+                 wino_per_tile=None, grad_dtype=None):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
+        if grad_dtype is None:
+            grad_dtype = os.environ.get('CLAMD_GRAD_DTYPE') or ('bf16' if getattr(model, 'compute_dtype', 'fp32') == 'bf16' else 'fp32')
+        if grad_dtype not in ('fp32', 'bf16'):
+            raise ValueError("grad_dtype must be 'fp32' or 'bf16'")
+        self.grad_dtype = grad_dtype
+        self._bf16 = {}                   # (offset, numel) -> staging buffer of a bucket
+        self.buckets = []                 # last step: dicts(bytes=, launch event) in launch order
+        self._begin_ev = None
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.min_bucket = min_bucket_bytes
@@ -66,13 +89,21 @@ class GradSync:
         if wino_per_tile and self.world > 1:
             model.tuning.wino_persist = 0
         # optional: grids sized to the chip leave CUs free for the RCCL channels (see the break-even above)
-        if cu_reserve is None:
-            cu_reserve = int(os.environ.get('CLAMD_CU_RESERVE', '0') or 0)
-        model.tuning.cu_reserve = max(0, min(128, int(cu_reserve)))
+        if cu_reserve is None and os.environ.get('CLAMD_CU_RESERVE'):
+            cu_reserve = int(os.environ['CLAMD_CU_RESERVE'])
+        if cu_reserve is not None:          # otherwise whatever the user set on model.tuning stays
+            model.tuning.cu_reserve = max(0, min(128, int(cu_reserve)))
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
             optimizer.pre_step_hooks.append(self.wait)
             optimizer._hyper_host = None
+
+    def begin(self):
+        """Called by the UNet backward before its first launch (timing only: launch offsets of the buckets)."""
+        self.buckets = []
+        if self.timing and torch.cuda.is_available():
+            self._begin_ev = torch.cuda.Event(enable_timing=True)
+            self._begin_ev.record()
 
     def stage_done(self, eng, st):
         """Called by the UNet backward after the gradients of one stage have been enqueued."""
@@ -97,17 +128,55 @@ class GradSync:
 
     def _launch(self, flat):
         self.launches += 1
+        half = self.grad_dtype == 'bf16'
+        rec = {'bytes': flat.numel() * (2 if half else 4)}
         if flat.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream()
+            if self.timing and self._begin_ev is not None:
+                rec['ev'] = torch.cuda.Event(enable_timing=True)
+                rec['ev'].record()                                   # on the compute stream: when the bucket became ready
             self._stream.wait_stream(torch.cuda.current_stream())
             if getattr(self, '_wg_stream', None) is not None:
                 self._stream.wait_stream(self._wg_stream)
             with torch.cuda.stream(self._stream):
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                if half:
+                    from ._lib import call, ptr
+                    key = (flat.data_ptr(), flat.numel())
+                    buf = self._bf16.get(key)
+                    if buf is None:
+                        # staging buffer at the bucket's element phase (a bucket starts anywhere in the flat buffer; the
+                        # conversion kernels move 8 elements per 16-byte access from the first 32-byte boundary on)
+                        phase = (flat.data_ptr() // 4) % 8
+                        buf = self._bf16[key] = torch.empty(flat.numel() + 8, dtype=torch.bfloat16, device=flat.device)[phase:phase + flat.numel()]
+                    sp = self._stream.cuda_stream
+                    call('clamd_f32_to_bf16', ptr(flat), ptr(buf), flat.numel(), sp)
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                    call('clamd_bf16_to_f32', ptr(buf), ptr(flat), flat.numel(), sp)
+                else:
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             self._pending.append(None)
-        else:   # CPU tensors (gloo) in tests
+        elif half:   # CPU tensors (gloo) in tests: the same rounding with torch's converters, synchronously
+            buf = flat.to(torch.bfloat16)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            flat.copy_(buf.float())
+            self._pending.append(None)
+        else:        # CPU tensors (gloo) in tests
             self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.buckets.append(rec)
+
+    def bucket_report(self):
+        """Buckets of the LAST backward pass in launch order: bytes on the wire per rank and (with timing=True) the offset of
+        the launch from the start of the backward pass in ms.  Synchronises."""
+        out = []
+        if any('ev' in b for b in self.buckets):
+            torch.cuda.synchronize()
+        for b in self.buckets:
+            r = {'bytes': b['bytes']}
+            if 'ev' in b and self._begin_ev is not None:
+                r['launch_offset_ms'] = round(self._begin_ev.elapsed_time(b['ev']), 3)
+            out.append(r)
+        return out
 
     def wait(self):
         for h in self._pending:

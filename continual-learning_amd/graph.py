@@ -39,6 +39,7 @@ class GraphedStep:
         with torch.cuda.graph(self.graph):
             self.loss = self._step().detach()
         self.optim.note_replayed_step(-1)            # the capture ran step() on the host without executing the kernel
+        self._tuning_key = tuple(model.tuning.as_dict().values())     # the captured launches carry this kernel structure
 
     def _step(self):
         out = self.model(self.inputs)
@@ -53,6 +54,9 @@ class GraphedStep:
             self.inputs.copy_(inputs, non_blocking=True)
         if labels is not None:
             self.labels.copy_(labels, non_blocking=True)
+        if tuple(self.model.tuning.as_dict().values()) != self._tuning_key:
+            raise RuntimeError('model.tuning changed after the step was captured: the graph still holds the old kernel structure; '
+                               'build a new GraphedStep')
         self.optim.sync_hyper()                      # lr schedule: the captured Adam kernel reads lr from device memory
         self.graph.replay()
         self.optim.note_replayed_step()

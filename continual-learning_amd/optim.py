@@ -45,7 +45,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self._derived = torch.zeros(2, dtype=torch.float32, device=dev)
         self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)
-        self._l2acc = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._l2acc = None            # [0] = sum ||theta - theta_old||^2 of the last step, [1..] = per-workgroup partials
         off, steps0 = 0, set()
         self._step_host = torch.tensor(0.0)          # ONE host-side step counter shared by every parameter's state
         for p, st in zip(params, prev):
@@ -77,6 +77,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._tensors_dev = torch.from_numpy(t.view(np.uint8).copy()).to(dev)
         self._chunks_dev = torch.tensor(chunks, dtype=torch.int32, device=dev)
         self._nchunks = len(chunks)
+        self._l2acc = torch.zeros(1 + self._nchunks, dtype=torch.float32, device=dev)
         self._table = [(p.data_ptr(), p.grad.data_ptr()) for p in params]
 
     def load_state_dict(self, state_dict):
@@ -94,7 +95,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def l2_penalty(self):
         """lam * sum ||theta - theta_old||^2 as accumulated by the LAST step (device scalar)."""
-        return self._l2acc * self._l2_lambda
+        return self._l2acc[:1] * self._l2_lambda
 
     def sync_hyper(self):
         """Upload lr / betas / eps / gradient scale / L2 weight to device memory if they changed on the host (LambdaLR
@@ -133,8 +134,6 @@ class FusedAdam(torch.optim.Optimizer):
                 self._init_state(params)
             self._build_table(params)
         self.sync_hyper()
-        if self._anchor is not None:
-            self._l2acc.zero_()
         call('clamd_adam_step', ptr(self._tensors_dev), ptr(self._chunks_dev), self._nchunks, ptr(self._hyper),
              ptr(self._step_dev), ptr(self._derived), ptr(self._l2acc) if self._anchor is not None else None,
              _lib.stream_ptr())

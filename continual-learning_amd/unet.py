@@ -104,21 +104,55 @@ def stage_table(num_classes, in_dim=3, conv_dim=64):
     return t
 
 
-class _Stage(nn.Module):
+class _NoForward:
+    """The children of UNet are PARAMETER CONTAINERS (torch's default init, the reference's state_dict names).  Their own
+    ``forward`` would run stock torch operators (MIOpen) -- a silent fallback this package does not have: it raises."""
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError(f'{type(self).__name__}.forward: the children of continual-learning_amd.UNet only hold parameters; '
+                           'run UNet.forward / UNet.predict (one autograd Function over libclamd kernels) -- there is no '
+                           'stock-torch path for a single block')
+
+
+class _Seq(_NoForward, nn.Sequential):
+    pass
+
+
+class _Conv2d(_NoForward, nn.Conv2d):
+    pass
+
+
+class _ConvTranspose2d(_NoForward, nn.ConvTranspose2d):
+    pass
+
+
+class _BatchNorm2d(_NoForward, nn.BatchNorm2d):
+    pass
+
+
+class _ReLU(_NoForward, nn.ReLU):
+    pass
+
+
+class _MaxPool2d(_NoForward, nn.MaxPool2d):
+    pass
+
+
+class _Stage(_NoForward, nn.Module):
     """Gives the 'encN.block.K' / 'decN.block.K' key names of models/unet.py:8-38."""
 
     def __init__(self, layers):
         super().__init__()
-        self.block = nn.Sequential(*layers)
+        self.block = _Seq(*layers)
 
 
 def _stage_modules(st):
-    layers = [nn.MaxPool2d(2, 2)] if st['pool'] else []
+    layers = [_MaxPool2d(2, 2)] if st['pool'] else []
     for _, _, cin, cout in st['convs']:
-        layers += [nn.Conv2d(cin, cout, 3, 1, 1), nn.ReLU(), nn.BatchNorm2d(cout)]
+        layers += [_Conv2d(cin, cout, 3, 1, 1), _ReLU(), _BatchNorm2d(cout)]
     if st['tail'] is not None:
         kind, _, cin, cout = st['tail']
-        layers.append(nn.ConvTranspose2d(cin, cout, 2, 2) if kind == 'convT' else nn.Conv2d(cin, cout, 1, 1))
+        layers.append(_ConvTranspose2d(cin, cout, 2, 2) if kind == 'convT' else _Conv2d(cin, cout, 1, 1))
     return layers
 
 
@@ -141,7 +175,7 @@ class UNet(nn.Module):
         self._table = stage_table(num_classes, in_dim, conv_dim)
         for st in self._table:
             layers = _stage_modules(st)
-            self.add_module(st['name'], _Stage(layers) if st['wrapped'] else nn.Sequential(*layers))
+            self.add_module(st['name'], _Stage(layers) if st['wrapped'] else _Seq(*layers))
         self._engines = {}
         self.grad_sync = None          # set by ddp.GradSync to overlap RCCL all-reduce with backward
         self._tuning = None
@@ -157,6 +191,14 @@ class UNet(nn.Module):
     def _seq(self, st):
         m = getattr(self, st['name'])
         return m.block if st['wrapped'] else m
+
+    def _replicate_for_data_parallel(self):
+        """``nn.DataParallel(model)`` (trainer.py:120-122) on ONE device calls the module directly and works as is.  On several
+        devices it would replicate this module into threads of one process every forward; the engine (activation buffers,
+        streams, flat gradient buffer) belongs to one device, and the reference's scheme is what ddp.GradSync replaces:
+        one process per GPU, RCCL all-reduce overlapped with backward."""
+        raise RuntimeError('continual-learning_amd.UNet cannot be replicated by nn.DataParallel across devices: run one process per '
+                           'GPU (torch.distributed.run) with continual-learning_amd.ddp.init_rccl + ddp.GradSync(model, optimizer)')
 
     def forward(self, x):
         if not x.is_cuda:
@@ -547,10 +589,16 @@ class _Engine:
             if t.kind == 'convT':
                 call('clamd_convT2x2_fwd', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(t.y_slice), t.y_ldc,
                      B, h, w, t.cin_p, t.cout_p, dc, s)
-            elif predict:      # arg-max fused into the head's epilogue: the logits never reach HBM
+            elif predict and t.cout_p <= 64:      # arg-max fused into the head's epilogue: the logits never reach HBM
                 logits = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
                 call('clamd_conv1x1_argmax', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(logits), None, B, h, w,
                      t.cin_p, t.cout_p, self.K, dc, s)
+            elif predict:      # more than 64 (padded) classes: the fused epilogue holds one 64-class slab; logits, then arg-max
+                lg = torch.empty(B, self.K, H, W, dtype=torch.float32, device=self.dev)
+                call('clamd_conv1x1_logits', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(lg), B, h, w,
+                     t.cin_p, t.cout_p, self.K, dc, s)
+                logits = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
+                call('clamd_argmax_confusion', ptr(lg), None, ptr(logits), None, B, self.K, 1, H, W, s)
             else:
                 logits = torch.empty(B, self.K, H, W, dtype=torch.float32, device=self.dev)
                 call('clamd_conv1x1_logits', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(logits), B, h, w,
@@ -642,6 +690,9 @@ class _Engine:
         B, H, W, dc = self.B, self.H, self.W, self.dcode
         if not self.fwd_training:
             raise RuntimeError('UNet.backward after an eval-mode forward is not supported (BatchNorm backward uses batch statistics)')
+        if tuple(self.tuning.as_dict().values()) != self._tune_key:
+            # the partial-row buffers were planned for the forward's kernel structure
+            raise RuntimeError('model.tuning changed between forward and backward: change it between steps (before the forward)')
         p0 = next(iter(m.parameters()))
         if p0.grad is not None:
             lo = self.gflat.data_ptr()
@@ -657,6 +708,8 @@ class _Engine:
         base = self.gflat.data_ptr()
         g = {n: base + 4 * o for n, (o, _) in self.goffset.items()}      # raw device pointers into the flat buffer
         sync = m.grad_sync
+        if sync is not None:
+            sync.begin()
         self._gp = g
         tp = tune_ptr(self.tuning)
         for st in reversed(self.stages):

@@ -230,7 +230,9 @@ int clamd_ce_fwd_bwd(const float* logits, const long long* labels, const float* 
                      double temperature, double lam, float* dlogits, float* loss3, void* workspace, size_t ws_bytes,
                      int B, int K, int H, int W, long long ignore_index, double grad_scale, void* stream);
 /* torch.optim.Adam.step over all parameters in one launch (trainer.py:108-110,176); hyper/step/derived live on the
- * device so a captured graph can be replayed with a new learning rate. */
+ * device so a captured graph can be replayed with a new learning rate.  l2_accum_dev (optional, with the L2-to-old-weights
+ * term): 1 + nchunks floats, [0] = sum ||theta - theta_old||^2 of this step, [1..] = per-workgroup partials added in a fixed
+ * order (no float atomics: the value is bit-reproducible). */
 int clamd_adam_step(const void* tensors_dev, const void* chunks_dev, int nchunks, const float* hyper_dev, int* step_dev,
                     float* derived_dev, float* l2_accum_dev, void* stream);
 /* argmax over classes + confusion matrix (trainer.py:183-188, metrics.py:32-38). */
@@ -245,10 +247,11 @@ int clamd_voc_prepare(const unsigned char* img_rgb, const unsigned char* mask_rg
 /* voc.to_rgb (datasets/voc.py:74-89): labels int64 [N,H,W] -> palette colours [N,3,H,W] (0..255 as float). */
 int clamd_label_to_rgb(const long long* labels, float* rgb, long long n_img, long long hw, void* stream);
 int clamd_fill_f32(float* p, long long n, double v, void* stream);
-/* Rehearsal aid for data parallelism on a one-GPU box: `ncus` workgroups that each hold a whole CU for `usec` microseconds
- * and do nothing else -- what an RCCL channel workgroup does to the one-workgroup-per-CU MFMA kernels during a collective
- * (tools/cu_steal.py measures the step with and without clamd_tuning::cu_reserve).  Not used by the product path. */
-int clamd_debug_hold_cus(int ncus, int usec, void* stream);
+/* Gradient exchange in bf16 (replaces the reduce of nn.DataParallel, trainer.py:120-122, for BASELINE.json configs[2]/[4]
+ * "bf16 DDP"): a bucket of the flat fp32 gradient buffer rounded to bf16 (rne) for the RCCL all-reduce and widened back.
+ * A bucket may start at any element: the bf16 buffer must sit at the same element phase, (address / element size) % 8. */
+int clamd_f32_to_bf16(const float* src, void* dst_bf16, long long n, void* stream);
+int clamd_bf16_to_f32(const void* src_bf16, float* dst, long long n, void* stream);
 /* p[i] *= *scale_dev for a DEVICE scalar, nothing at all when it is exactly 1 (the upstream gradient loss.backward()
  * hands to the loss function, trainer.py:175): no host sync, no pass over d logits in the common case. */
 int clamd_scale_by_device_scalar(float* p, long long n, const float* scale_dev, void* stream);

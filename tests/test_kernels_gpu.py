@@ -1049,6 +1049,17 @@ def test_fused_adam_golden_and_l2(C, golden):
     ref, _, _ = O.adam_step(p0, gr + 2 * 0.3 * (p0 - old), np.zeros_like(p0), np.zeros_like(p0), 1, 1e-2)
     assert rel_l2(q.detach().cpu().numpy(), ref) < 1e-6
     assert abs(float(o2.l2_penalty()) - 0.3 * float(((p0 - old).astype(np.float64) ** 2).sum())) < 1e-2
+    # the penalty is a fixed-order sum of per-workgroup partials (no float atomics): bit-identical run after run, also over
+    # many workgroups (3M elements = hundreds of chunks)
+    big_p, big_old, big_g = rnd(rng, 3_000_017), rnd(rng, 3_000_017), rnd(rng, 3_000_017)
+    pens = []
+    for _ in range(5):
+        q = torch.nn.Parameter(dev(big_p)); o3 = C.FusedAdam([q], lr=1e-2, betas=[0.5, 0.99]); o3.set_l2_anchor([dev(big_old)], 0.3)
+        q.grad = dev(big_g); o3.step(); sync()
+        pens.append(o3.l2_penalty().clone())
+    assert all(torch.equal(pens[0], t) for t in pens[1:]), [float(t) for t in pens]
+    want = 0.3 * float(((big_p - big_old).astype(np.float64) ** 2).sum())
+    assert float(pens[0]) == pytest.approx(want, rel=2e-6)
 
 
 def test_metrics_golden(C, golden):

@@ -167,9 +167,11 @@ def test_full_size_config2_vs_reference_golden(C, golden, dtype):
         loss.backward()
         if s == 0:
             sub = out.detach().reshape(-1)[::int(g['logits_flat_stride'])].cpu().numpy()
-            tol = 1e-3 if fp32 else 6e-2
-            assert rel_l2(sub, g['logits']) < tol, rel_l2(sub, g['logits'])
-            assert maxrel(sub, g['logits']) < tol * (1 if fp32 else 2)
+            # bf16: storage rounding of 23 stacked convolutions; measured 1.5e-2 (the reference itself with bf16-rounded operands
+            # gives the same) -- bound at < 2x the measurement so that a regression shows
+            tol = 1e-3 if fp32 else 2.5e-2
+            assert rel_l2(sub, g['logits']) < tol, f'logits rel L2 {rel_l2(sub, g["logits"]):.3e} (bound {tol})'
+            assert maxrel(sub, g['logits']) < tol * (1 if fp32 else 2.5), f'logits max-abs ratio {maxrel(sub, g["logits"]):.3e}'
             gn = np.array([float(p.grad.double().norm()) for p in model.parameters()])
             big = g['grad_norms'] > 1e-4 * g['grad_norms'].max()
             np.testing.assert_allclose(gn[big], g['grad_norms'][big], rtol={'fp32': 5e-3, 'bf16x3': 2e-2, 'bf16': 0.3}[dtype])
@@ -208,9 +210,11 @@ def test_full_size_config5_vs_reference_golden(C, golden, dtype):
         loss.backward()
         if s == 0:
             sub = out.detach().reshape(-1)[::int(g['logits_flat_stride'])].cpu().numpy()
-            tol = 1e-3 if fp32 else 6e-2
-            assert rel_l2(sub, g['logits']) < tol, rel_l2(sub, g['logits'])
-            assert maxrel(sub, g['logits']) < tol * (1 if fp32 else 2)
+            # bf16: storage rounding of 23 stacked convolutions; measured 1.5e-2 (the reference itself with bf16-rounded operands
+            # gives the same) -- bound at < 2x the measurement so that a regression shows
+            tol = 1e-3 if fp32 else 2.5e-2
+            assert rel_l2(sub, g['logits']) < tol, f'logits rel L2 {rel_l2(sub, g["logits"]):.3e} (bound {tol})'
+            assert maxrel(sub, g['logits']) < tol * (1 if fp32 else 2.5), f'logits max-abs ratio {maxrel(sub, g["logits"]):.3e}'
             gn = np.array([float(p.grad.double().norm()) for p in model.parameters()])
             big = g['grad_norms'] > 1e-4 * g['grad_norms'].max()
             np.testing.assert_allclose(gn[big], g['grad_norms'][big], rtol={'fp32': 5e-3, 'bf16x3': 2e-2, 'bf16': 0.3}[dtype])
@@ -235,8 +239,8 @@ def test_full_size_config5_vs_reference_golden(C, golden, dtype):
         out = model(x)
         loss = crit(out, y)
     sub = out.reshape(-1)[::int(f['logits_flat_stride'])].cpu().numpy()
-    tol = 1e-3 if fp32 else 6e-2
-    assert rel_l2(sub, f['logits']) < tol, rel_l2(sub, f['logits'])
+    tol = 1e-3 if fp32 else 2.5e-2
+    assert rel_l2(sub, f['logits']) < tol, f'logits rel L2 {rel_l2(sub, f["logits"]):.3e} (bound {tol})'
     assert float(loss) == pytest.approx(float(f['loss']), rel=2e-4 if fp32 else 3e-2)
     m = C.eval_metrics(y, out, 21)
     assert abs(float(m[2]) - float(f['metrics'][2])) < (1e-5 if fp32 else 0.1)
@@ -244,6 +248,46 @@ def test_full_size_config5_vs_reference_golden(C, golden, dtype):
     assert np.abs(hist - f['pred_hist']).sum() <= (2e-4 if fp32 else 0.1) * hist.sum()
     stats = np.concatenate([v.cpu().numpy().reshape(-1) for k, v in model.state_dict().items() if k.endswith(('running_mean', 'running_var'))])
     assert rel_l2(stats, f['stats1']) < (1e-4 if dtype == 'fp32' else 1e-3 if fp32 else 2e-2)
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'bf16x3'])
+def test_full_size_config5_bs32_full_train_step(C, golden, dtype):
+    """BASELINE.json configs[4] at its REAL size -- 512x512, bs32 per GPU -- the whole train step (forward, CE, backward,
+    Adam), not only the forward: the step-0 loss equals the reference's capture (the reference's own bs32 backward needs more
+    host memory than the build container has, so loss + logits pin the forward and the properties below pin the rest), two
+    runs of two steps are bit-identical (every reduction at this size is a fixed-order sum), every parameter tensor moved,
+    and the second loss is lower than the first."""
+    f = golden('unet_cd64_c21_512_b32_fwd.npz')
+    x = torch.from_numpy(C.synth.images(1234, 32, 3, 512, 512)).cuda()
+    y = torch.from_numpy(C.synth.labels(1234, 32, 512, 512, 21)).cuda()
+    crit = C.CrossEntropyLoss()
+
+    def two_steps():
+        model = C.UNet(21, 3, 64, compute_dtype=dtype)
+        load_closed_form(C, model)
+        model = model.cuda().train()
+        w0 = [p.detach().clone() for p in model.parameters()]
+        opt = C.FusedAdam(model.parameters(), lr=1e-4, betas=[0.5, 0.99])
+        losses = []
+        for _ in range(2):
+            out = model(x); opt.zero_grad(); loss = crit(out, y); loss.backward(); opt.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+        moved = [bool((p.detach() != w).any()) for p, w in zip(model.parameters(), w0)]
+        gn = float(torch.cat([p.grad.reshape(-1) for p in model.parameters()]).double().norm())
+        del model, opt, out, loss
+        torch.cuda.empty_cache()
+        return losses, flat, moved, gn
+
+    l1, f1, moved, gn = two_steps()
+    tol = 3e-2 if dtype == 'bf16' else 2e-4
+    assert float(l1[0]) == pytest.approx(float(f['loss']), rel=tol), f'step-0 loss {float(l1[0]):.6f} vs reference {float(f["loss"]):.6f}'
+    assert all(moved), 'Adam must move every parameter tensor'
+    assert float(l1[1]) < float(l1[0]) and gn == gn and gn > 0
+    l2, f2, _, _ = two_steps()
+    assert torch.equal(l1[0], l2[0]) and torch.equal(l1[1], l2[1]), 'losses of two identical runs differ'
+    assert torch.equal(f1, f2), f'{int((f1 != f2).sum())} weights differ between two identical runs'
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'bf16x3'])
@@ -527,7 +571,7 @@ def test_train_step_is_bit_reproducible(C, dtype, nc, cd, B, size, runs):
         assert torch.equal(got[2], ref[2]), f'run {r}: weights differ'
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'bf16x3'])
 def test_scheduling_knobs_do_not_change_results(C, dtype):
     """Scheduling choices -- one workgroup per tile instead of the persistent Winograd grid, CUs left free for RCCL
     (cu_reserve) -- only change how the statistics are split into partial rows: the same sums up to fp32 rounding of the
@@ -540,7 +584,7 @@ def test_scheduling_knobs_do_not_change_results(C, dtype):
         # the statistics agree to 1e-8 between the grids (tools/w24_stats_check.py); a ReLU / max-pool tie that falls the other
         # way moves individual gradient elements, as between any two fp32 implementations: loss tight, gradient loose
         assert abs(float(a[0]) - float(ref[0])) < 1e-5 * abs(float(ref[0])), knob
-        assert float((a[1] - ref[1]).norm() / ref[1].norm()) < (5e-3 if dtype == 'fp32' else 2e-2), knob
+        assert float((a[1] - ref[1]).norm() / ref[1].norm()) < (2e-2 if dtype == 'bf16' else 5e-3), knob
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16x3', 'bf16'])
@@ -560,6 +604,62 @@ def test_fused_bn_backward_sums_match_the_separate_reduction(C, dtype, monkeypat
     assert torch.equal(a[1], a2[1]) and torch.equal(a[2], a2[2])
     assert float((a[1] - ref[1]).norm() / ref[1].norm()) < (1e-4 if dtype != 'bf16' else 2e-2)
     assert abs(float(a[0]) - float(ref[0])) < 1e-5 * abs(float(ref[0]))      # the forward pass is the same launches
+
+
+def test_misuse_errors(C):
+    """There is no silent stock-torch path: (1) a child module called on its own raises (the children only hold parameters);
+    (2) nn.DataParallel (trainer.py:120-122) on ONE device calls the module itself and works, across devices the replication is
+    refused with a pointer to ddp.GradSync; (3) torch's DistributedDataParallel wrapper works (world 1: bit-identical to the
+    plain step) -- its reducer hooks see the gradients this path's autograd Function returns."""
+    import torch.nn as nn
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(5)
+    m = C.UNet(5, 3, 8).to(dev).train()
+    x = torch.from_numpy(C.synth.images(3, 2, 3, 32, 32)).to(dev)
+    y = torch.from_numpy(C.synth.labels(3, 2, 32, 32, 5)).to(dev)
+    for child, arg in ((m.enc1, x), (m.enc2, torch.zeros(2, 8, 32, 32, device=dev)), (m.enc2.block, torch.zeros(2, 8, 32, 32, device=dev)),
+                       (m.enc1[0], x), (m.enc1[2], torch.zeros(2, 8, 32, 32, device=dev)), (m.dec1.block[6], torch.zeros(2, 128, 2, 2, device=dev)),
+                       (m.last[6], torch.zeros(2, 8, 32, 32, device=dev))):
+        with pytest.raises(RuntimeError, match='no stock-torch path'):
+            child(arg)
+    assert isinstance(m.enc1[0], nn.Conv2d) and isinstance(m.enc1[2], nn.BatchNorm2d) and isinstance(m.dec1.block[6], nn.ConvTranspose2d)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(x.cpu())
+    # (2) DataParallel
+    out_plain = m(x).detach().clone()
+    dp = nn.DataParallel(m, device_ids=[0])
+    assert torch.equal(dp(x).detach(), out_plain)
+    with pytest.raises(RuntimeError, match='GradSync'):
+        m._replicate_for_data_parallel()
+    # (3) DistributedDataParallel, world 1
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29541')
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', rank=0, world_size=1)
+        created = True
+    try:
+        def run(wrap):
+            torch.manual_seed(5)
+            mm = C.UNet(5, 3, 8).to(dev).train()
+            net = nn.parallel.DistributedDataParallel(mm, device_ids=[0]) if wrap else mm
+            opt = C.FusedAdam(mm.parameters(), lr=1e-3, betas=[0.5, 0.99])
+            crit = C.CrossEntropyLoss()
+            for _ in range(2):
+                out = net(x); opt.zero_grad(); loss = crit(out, y); loss.backward(); opt.step()
+            torch.cuda.synchronize()
+            return loss.detach().clone(), torch.cat([p.detach().reshape(-1) for p in mm.parameters()]).clone()
+        (l0, w0), (l1, w1) = run(False), run(True)
+        assert torch.equal(l0, l1) and torch.equal(w0, w1), float((w0 - w1).abs().max())
+    finally:
+        if created:
+            dist.destroy_process_group()
+    # eval path with more classes than the fused arg-max epilogue holds (64): logits head + arg-max kernel, same answer
+    big = C.UNet(70, 3, 4).to(dev).eval()
+    xb = torch.from_numpy(C.synth.images(4, 1, 3, 32, 32)).to(dev)
+    with torch.no_grad():
+        assert torch.equal(big.predict(xb), torch.max(big(xb), 1)[1])
 
 
 def test_engine_buffers_are_released_with_the_model(C):
@@ -595,9 +695,9 @@ def test_gradsync_rccl_world1_on_gpu(C):
     try:
         def ddp_hook(m, opt):
             C.ddp.broadcast_parameters(m)
-            C.ddp.GradSync(m, opt, min_bucket_bytes=16 << 10)
+            C.ddp.GradSync(m, opt, min_bucket_bytes=16 << 10, grad_dtype='fp32')      # bit-level identity needs the fp32 exchange
             assert opt.grad_scale == 1.0 and m.tuning.cu_reserve == 0        # one rank: no channels to make room for
-        for dtype in ('fp32', 'bf16'):
+        for dtype in ('fp32', 'bf16', 'bf16x3'):
             plain = _one_step(C, dtype, 6, 8, 2, 64, steps=2)
             synced = _one_step(C, dtype, 6, 8, 2, 64, steps=2, hook=ddp_hook)
             assert torch.equal(plain[0], synced[0]), (dtype, float(plain[0]), float(synced[0]))
@@ -633,7 +733,8 @@ def test_checkpoint_roundtrip_and_resume(C, tmp_path):
 
 
 @pytest.mark.gpu
-def test_graphed_step_matches_eager(C):
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16x3'])
+def test_graphed_step_matches_eager(C, dtype):
     """The whole train step captured in ONE HIP graph (graph.GraphedStep) replays the same kernels as the eager loop:
     the SAME loss sequence, bit for bit (every reduction is a fixed-order sum); the LambdaLR schedule still reaches the
     captured Adam kernel (lr is read from device memory), and the host-side step counter follows the replays."""
@@ -643,7 +744,7 @@ def test_graphed_step_matches_eager(C):
 
     def make():
         torch.manual_seed(3)
-        m = C.UNet(5, 3, 8).to(dev).train()
+        m = C.UNet(5, 3, 8, compute_dtype=dtype).to(dev).train()
         o = C.FusedAdam(m.parameters(), lr=1e-3, betas=[0.5, 0.99])
         sch = torch.optim.lr_scheduler.LambdaLR(o, lambda n: 0.5 ** n)
         return m, o, sch, C.CrossEntropyLoss()
@@ -733,16 +834,41 @@ def test_random_model_configs_vs_stock_torch(C, cfg, dtype):
     tol = 2e-4 if dtype == 'fp32' else 1e-3
     assert rel_l2(out_o.detach().cpu().numpy(), out_r.detach().cpu().numpy()) < tol
     assert float(l_o.detach()) == pytest.approx(float(l_r.detach()), rel=tol)
-    gr = dict(ref.named_parameters())
-    # per tensor for the weights; the conv / convT biases in front of a BatchNorm have gradients that cancel to (almost)
-    # zero, so their relative error is meaningless -- they are covered by the norm over all gradients together
-    worst = max((rel_l2(p.grad.cpu().numpy(), gr[n].grad.cpu().numpy()), n) for n, p in ours.named_parameters() if p.dim() > 1)
-    # Gradients of small random nets are decided by ReLU / max-pool ties: against an fp64 run, stock torch fp32 (CPU and
-    # GPU) is itself 5e-3 .. 8e-3 off in the gradient norm on these configurations while its logits agree to 1e-6
-    # (probe: ours-direct 2e-6 .. 3e-3, ours-Winograd 2e-3 .. 8e-3, ours-bf16x3 1.2e-2 .. 2.2e-2).  The bounds admit such
-    # flips; logits and loss above are held tight.
-    gtol_t, gtol_all = (0.15, 3e-2) if dtype == 'fp32' else (0.2, 6e-2)
-    assert worst[0] < gtol_t, worst
-    ga = torch.cat([p.grad.reshape(-1) for _, p in ours.named_parameters()]).cpu().numpy()
-    gb = torch.cat([gr[n].grad.reshape(-1) for n, _ in ours.named_parameters()]).cpu().numpy()
-    assert rel_l2(ga, gb) < gtol_all
+    # Gradients of small random nets are decided by ReLU / max-pool TIES: a pre-activation within rounding distance of zero, or two
+    # nearly equal values in a pooling window, falls the other way, the gradient takes another route, and at the deep levels
+    # (tens of samples per channel here) one such flip moves a whole tensor's gradient by ~1/samples.  This is a property of
+    # the network, not of an implementation, and the test DEMONSTRATES it on the reference arithmetic itself: the stock
+    # counterpart in float64 (CPU), re-run with every conv weight perturbed by a relative 1e-6 (the size of fp32 Winograd
+    # rounding; 1e-5 for bf16x3's split products), moves its own gradients by `floor` -- orders of magnitude more than the
+    # perturbation wherever a tie flips.  This path may deviate from the unperturbed fp64 gradients by at most 2x the largest
+    # floor seen over 8 perturbation seeds (whole gradient) / 3x (per weight tensor, where single flips are luckier).
+    def fp64_grads(delta=0.0, seed=0):
+        m64 = TC.build_unet(nc, 3, cd).double()
+        sd64 = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in ref.state_dict().items()}
+        if delta:
+            gen = torch.Generator().manual_seed(1000 + seed)
+            for k in sd64:
+                if k.endswith('.weight') and sd64[k].dim() == 4:
+                    sd64[k] = sd64[k] * (1.0 + delta * torch.randn(sd64[k].shape, generator=gen, dtype=torch.float64))
+        m64.load_state_dict(sd64)
+        m64.train()
+        l64 = torch.nn.CrossEntropyLoss()(m64(x.cpu().double()), y.cpu()); l64.backward()
+        return {n: p.grad.numpy() for n, p in m64.named_parameters()}
+    g64 = fp64_grads()
+    delta = 1e-6 if dtype == 'fp32' else 1e-5
+    names = [n for n, p in ours.named_parameters() if p.dim() > 1]       # biases in front of a BatchNorm cancel to ~0: covered by the total
+    cat = lambda g: np.concatenate([np.asarray(g[n], np.float64).reshape(-1) for n, _ in ours.named_parameters()])
+    floor_t = {n: 0.0 for n in names}
+    floor_all = 0.0
+    for seed in range(8):
+        gp = fp64_grads(delta, seed)
+        floor_all = max(floor_all, rel_l2(cat(gp), cat(g64)))
+        for n in names:
+            floor_t[n] = max(floor_t[n], rel_l2(gp[n], g64[n]))
+    go = {n: p.grad.cpu().numpy() for n, p in ours.named_parameters()}
+    e_all = rel_l2(cat(go), cat(g64))
+    worst = max((rel_l2(go[n].astype(np.float64), g64[n]) / max(floor_t[n], 20 * delta), n) for n in names)
+    print(f'gradient vs fp64: whole {e_all:.2e} (fp64 under a {delta:g} weight perturbation: {floor_all:.2e}); '
+          f'worst tensor {worst[1]} at {worst[0]:.2f}x its perturbation floor {floor_t[worst[1]]:.2e}')
+    assert e_all < 2.0 * max(floor_all, 20 * delta), (e_all, floor_all)
+    assert worst[0] < 3.0, worst
