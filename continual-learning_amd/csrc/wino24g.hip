@@ -328,6 +328,303 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// hybrid kernel for the narrow layers (64 / 128 channels, levels 0-1): the input transform stays in the kernel (3x the
+// activation bytes through HBM would make these layers HBM-bound), but the FILTERS -- 48 of the 59 KB a workgroup moves per
+// chunk in wino24_kernel: global -> registers -> LDS (12 ds_write_b128 per thread) -> fragments (12 ds_read_b128 per wave) --
+// go straight into the MFMA operand registers as in wino24g_kernel: each wave needs only the slice of its own row i, nothing
+// is shared.  Per chunk and wave: 48 MFMAs, 72 transform VALU, 12 LDS reads + 3 LDS writes + 15 buffer loads (wino24_kernel:
+// 103 VALU incl. 25 register copies, 24 LDS reads, 15 LDS writes, 15 loads).  The chunk loop is unrolled by two: the transformed
+// input alternates between two register sets (no copies), the filter sets are refilled two chunks ahead behind their MFMAs and the
+// stream runs on into the next tile.  Same V formulas, same MFMA chains, same epilogue: bit-identical to wino24_kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TXN, bool RAGGED>
+__global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
+    constexpr int TYN = 32 / TXN;
+    constexpr int PW = 4 * TXN, PH = 2 * TYN;
+    constexpr int HW_ = PW + 2, HH_ = PH + 2, PIX = HW_ * HH_;            // input halo
+    constexpr int PIXMAX = (HH_ - 1) * HW_ + (HW_ - 1) + ((HH_ - 1) >> 1) + 1;   // slots incl. the row skew (see wino24.hip)
+    constexpr int PIXP = PIXMAX + ((10 - PIXMAX % 8) % 8);                // == 2 (mod 8): conflict-free staging stores
+    constexpr int IN_SLOTS = 2 * PIXP;
+    constexpr int NJI = (2 * PIX + 255) / 256;                            // input staging loads per thread
+    constexpr int EXB = 4 * 4 * 32 * W24G_EXP;
+    constexpr int LDS = 2 * EXB * 4 / 16;                                 // the exchange blocks alias the two input stages
+    static_assert(2 * IN_SLOTS <= LDS && LDS * 16 <= 160 * 1024, "LDS budget");
+    __shared__ uint4 smem[LDS];
+
+    const bool per_wg_rows = p.stats != nullptr && gridDim.x < (unsigned)p.nblk;
+    if (per_wg_rows && threadIdx.x < 128)
+        for (int n = threadIdx.x & 63; n < p.Np; n += 64) p.stats[((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * p.Np + n] = 0.f;
+    float racc = 0.f;
+    int rslab = -1;
+    auto flush_row = [&]() {
+        if (rslab >= 0 && rslab * 64 + (int)(threadIdx.x & 63) < p.Np) {
+            float* dst = p.stats + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * p.Np + rslab * 64 + (threadIdx.x & 63);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst, old + racc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    float st1[2][4], st2[2][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { st1[i >> 2][i & 3] = 0.f; st2[i >> 2][i & 3] = 0.f; }
+    int cur_tn = -1, cur_tm = 0;
+    auto fold_stats = [&]() {
+        float* sb = reinterpret_cast<float*>(smem);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a = st1[nt][c], q = st2[nt][c];
+                a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+                q += __shfl_xor(q, 8); q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+                if (lane < 8) { sb[(w * 2 + 0) * 64 + 32 * nt + 4 * lane + c] = a; sb[(w * 2 + 1) * 64 + 32 * nt + 4 * lane + c] = q; }
+                st1[nt][c] = 0.f; st2[nt][c] = 0.f;
+            }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int k = threadIdx.x >> 6, c = threadIdx.x & 63;
+            const float t = sb[(0 * 2 + k) * 64 + c] + sb[(1 * 2 + k) * 64 + c] + sb[(2 * 2 + k) * 64 + c] + sb[(3 * 2 + k) * 64 + c];
+            if (!per_wg_rows) {
+                if (cur_tn * 64 + c < p.Np) p.stats[((size_t)cur_tm * 2 + k) * p.Np + cur_tn * 64 + c] = t;
+            } else {
+                rslab = cur_tn; racc = t;
+                flush_row();
+            }
+        }
+        __syncthreads();
+        cur_tn = -1;
+    };
+
+    const int tiles_x = (p.W + PW - 1) / PW, tiles_y = (p.H + PH - 1) / PH;
+    const int ntn = p.Np >> 6;                                              // Np % 64 == 0 (checked on entry)
+    const int nk = p.Kp >> 3;                                               // even, >= 4 (checked on entry)
+    const int per_band = (p.nblk / ntn) * p.band;
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.w, (unsigned)(24u * p.Np * p.Kp * 4u));
+    const __amdgpu_buffer_rsrc_t wrs_dead = make_rsrc(p.w, 0u);
+    const unsigned img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc * 4u;
+    const __amdgpu_buffer_rsrc_t xrs_dead = make_rsrc(p.x, 0u);
+    const unsigned ustride = (unsigned)p.Np * 32u;
+    auto decode = [&](int v, int& tn, int& tm) {
+        const int bid = xcd_remap(v, p.nblk);
+        const int bnd = bid / per_band, rem = bid - bnd * per_band;
+        tn = bnd * p.band + rem % p.band; tm = rem / p.band;
+    };
+
+    uint4 Bq[6][2];                            // filter fragments of ONE chunk, refilled with the next chunk's behind their MFMAs (the
+    //                                            filters of these narrow layers are <= 3 MB: L2 hits, one chunk = 3k cycles ahead is plenty)
+    uint4 pi0[NJI], pi1[NJI];                  // input chunks 0 and 1 of the tile about to start (requested under the epilogue)
+    bool pre = false;
+    for (int v = blockIdx.x; v < p.nblk; v += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int r = lane & 31, h = lane >> 5;
+        int tn, tm;
+        decode(v, tn, tm);
+        const int x0 = (tm % tiles_x) * PW, y0 = ((tm / tiles_x) % tiles_y) * PH, b = tm / (tiles_x * tiles_y);
+        const int n0 = tn * 64;
+        if (cur_tn >= 0 && (tn != cur_tn || !per_wg_rows)) fold_stats();
+
+        const int vn = v + (int)gridDim.x;
+        const bool has_next = vn < p.nblk;
+        int tnn, tmn;
+        decode(has_next ? vn : v, tnn, tmn);
+
+        // ---- input staging (wino24_kernel's halo image) -------------------------------------------------------------------
+        const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x + (size_t)b * img, img);
+        unsigned in_vo[NJI];
+        int in_slot[NJI];
+#pragma unroll
+        for (int j = 0; j < NJI; ++j) {
+            int piece = tid + 256 * j;                           // (pixel, 16-byte group); the last pass wraps
+            if (piece >= 2 * PIX) piece -= 2 * PIX;
+            const int g = piece & 1, pix = piece >> 1;
+            const int hy = pix / HW_, hx = pix - hy * HW_;
+            const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+            in_vo[j] = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? (unsigned)(((yy * p.W + xx) * p.x_ldc + 4 * g) * 4) : BUF_OOB;
+            in_slot[j] = g * PIXP + hy * HW_ + hx + (hy >> 1);
+        }
+        uint4 rin[NJI];
+        auto gload_in = [&](int k, bool live, uint4 (&ri)[NJI]) {
+            const __amdgpu_buffer_rsrc_t xr = live ? xrs : xrs_dead;
+#pragma unroll
+            for (int j = 0; j < NJI; ++j) ri[j] = buf_ld16(xr, in_vo[j], (unsigned)(k * 32));
+        };
+        auto lds_store_in = [&](int st, const uint4 (&ri)[NJI]) {
+            uint4* sm = smem + st * IN_SLOTS;
+#pragma unroll
+            for (int j = 0; j < NJI; ++j) sm[in_slot[j]] = ri[j];
+        };
+
+        // ---- filters: straight into the fragment registers ------------------------------------------------------------------
+        const unsigned b_vo = (unsigned)((r * 8 + 4 * h) * 4);
+        const unsigned plane0 = (unsigned)(w * 6);
+        const unsigned ub_cur = (unsigned)n0 * 32u, ub_nxt = (unsigned)tnn * 64u * 32u;
+        auto load_b = [&](int j, __amdgpu_buffer_rsrc_t ur, unsigned ub, int k) {
+            const unsigned pl = (unsigned)k * 24u + plane0 + (unsigned)j;
+            Bq[j][0] = buf_ld16(ur, b_vo, ub + pl * ustride);
+            Bq[j][1] = buf_ld16(ur, b_vo, ub + pl * ustride + 1024u);
+        };
+
+        // ---- fragments of the input: wave w = vertical Winograd row i (wino24_kernel) ----------------------------------------
+        const int a1 = w == 0 ? 0 : 1, a2 = w == 3 ? 3 : 2;
+        const float s2 = w == 1 ? 1.f : -1.f;
+        const int ty = r / TXN, tx = r % TXN;
+        const int pb = h * PIXP + (2 * ty) * HW_ + 4 * tx + ty;
+        const int p1 = pb + a1 * HW_ + (a1 >> 1), p2 = pb + a2 * HW_ + (a2 >> 1);
+        auto frags = [&](int st, uint4 (&A)[6]) {
+            const uint4* sm = smem + st * IN_SLOTS;
+            float t[6][4], o[6][4];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const uint4 u1 = sm[p1 + c], u2 = sm[p2 + c];
+                t[c][0] = fmaf(s2, __uint_as_float(u2.x), __uint_as_float(u1.x));
+                t[c][1] = fmaf(s2, __uint_as_float(u2.y), __uint_as_float(u1.y));
+                t[c][2] = fmaf(s2, __uint_as_float(u2.z), __uint_as_float(u1.z));
+                t[c][3] = fmaf(s2, __uint_as_float(u2.w), __uint_as_float(u1.w));
+            }
+            W24G_COLS(t, o);
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                A[j] = make_uint4(__float_as_uint(o[j][0]), __float_as_uint(o[j][1]), __float_as_uint(o[j][2]), __float_as_uint(o[j][3]));
+        };
+
+        f32x16 acc[6][2];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+
+        if (!pre) {                                                           // first tile of this workgroup
+            gload_in(0, true, pi0);
+            gload_in(1, true, pi1);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                load_b(j, wrs, ub_cur, 0);
+                asm volatile("" ::: "memory");                                 // ring order (see wino24g_wgrad_kernel)
+            }
+        }
+        gload_in(2, 2 < nk, rin);
+        lds_store_in(0, pi0);
+        lds_store_in(1, pi1);
+        __syncthreads();
+        uint4 A0[6], A1[6];
+        frags(0, A0);
+        __syncthreads();                                                      // stage 0 is free again
+
+        // one chunk: 48 MFMAs on (Acur, Bq); the transformed input of chunk k+1 goes to Anext; chunk k+2 of the input is stored
+        // over chunk k's stage, chunk k+3 requested; Bq[j] is refilled with chunk k+1 (or the next tile's chunk 0) behind its MFMAs
+#define W24H_CHUNK(k_, Acur_, Anext_, ur_, ub_, kb_)                                                                   \
+    do {                                                                                                               \
+        frags(((k_) + 1) & 1, Anext_);                                        /* visible since the last barrier */      \
+        _Pragma("unroll") for (int j_ = 0; j_ < 6; ++j_) {                                                             \
+            mma16<float>(Acur_[j_], Bq[j_][0], acc[j_][0]);                                                            \
+            mma16<float>(Acur_[j_], Bq[j_][1], acc[j_][1]);                                                            \
+            load_b(j_, ur_, ub_, kb_);                                                                                 \
+        }                                                                                                              \
+        lds_store_in((k_) & 1, rin);                                          /* chunk k+2 over chunk k's stage */       \
+        gload_in((k_) + 3, (k_) + 3 < nk, rin);                                                                        \
+        sched_mfma_slots<48, 12, 20, 20 + NJI, 24, 24 + NJI, 2, 4, 1>();                                               \
+        __syncthreads();                                                                                               \
+    } while (0)
+        for (int k = 0; k < nk - 2; k += 2) {
+            W24H_CHUNK(k, A0, A1, wrs, ub_cur, k + 1);
+            W24H_CHUNK(k + 1, A1, A0, wrs, ub_cur, k + 2);
+        }
+        {
+            W24H_CHUNK(nk - 2, A0, A1, wrs, ub_cur, nk - 1);
+            const __amdgpu_buffer_rsrc_t ur = has_next ? wrs : wrs_dead;
+            W24H_CHUNK(nk - 1, A1, A0, ur, ub_nxt, 0);
+            pre = has_next;
+        }
+#undef W24H_CHUNK
+        {   // input chunks 0 and 1 of the next tile: requested here, they land under the epilogue (empty descriptor behind the
+            // last tile: the registers are redefined on every path)
+            const int x0n = (tmn % tiles_x) * PW, y0n = ((tmn / tiles_x) % tiles_y) * PH, bn = tmn / (tiles_x * tiles_y);
+            const __amdgpu_buffer_rsrc_t xrn = has_next ? make_rsrc((const char*)p.x + (size_t)bn * img, img) : xrs_dead;
+#pragma unroll
+            for (int j = 0; j < NJI; ++j) {
+                int piece = tid + 256 * j;
+                if (piece >= 2 * PIX) piece -= 2 * PIX;
+                const int g = piece & 1, pix = piece >> 1;
+                const int hy = pix / HW_, hx = pix - hy * HW_;
+                const int yy = y0n + hy - 1, xx = x0n + hx - 1;
+                const unsigned vo = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? (unsigned)(((yy * p.W + xx) * p.x_ldc + 4 * g) * 4) : BUF_OOB;
+                pi0[j] = buf_ld16(xrn, vo, 0u);
+                pi1[j] = buf_ld16(xrn, vo, 32u);
+            }
+        }
+
+        // ---- epilogue: wino24_kernel's -----------------------------------------------------------------------------------------
+        float* const ex = reinterpret_cast<float*>(smem);
+        const int tl = tid >> 3, ng = tid & 7;
+        const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+        const bool plain = !p.relu && !p.bias && !p.stats;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float* const exb = ex + nt * EXB;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float m0 = acc[0][nt][e], m1 = acc[1][nt][e], m2 = acc[2][nt][e], m3 = acc[3][nt][e], m4 = acc[4][nt][e],
+                            m5 = acc[5][nt][e];
+                const float sa = m1 + m2, sb = m1 - m2, sc = m3 + m4, sd = m3 - m4;
+                const int row = acc_row(e, h);
+                exb[((w * 4 + 0) * 32 + row) * W24G_EXP + r] = m0 + sa + sc;
+                exb[((w * 4 + 1) * 32 + row) * W24G_EXP + r] = fmaf(2.f, sd, sb);
+                exb[((w * 4 + 2) * 32 + row) * W24G_EXP + r] = fmaf(4.f, sc, sa);
+                exb[((w * 4 + 3) * 32 + row) * W24G_EXP + r] = fmaf(8.f, sd, sb) + m5;
+            }
+        }
+        __syncthreads();
+        const int oty = tl / TXN, otx = tl % TXN;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float* const exb = ex + nt * EXB;
+            const int n = n0 + 32 * nt + 4 * ng;
+            float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias && n < p.Np) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 R[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) R[i] = *reinterpret_cast<const float4*>(exb + ((i * 4 + q) * 32 + tl) * W24G_EXP + 4 * ng);
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    float4 o;
+                    if (pp == 0) {
+                        o.x = R[0].x + R[1].x + R[2].x; o.y = R[0].y + R[1].y + R[2].y;
+                        o.z = R[0].z + R[1].z + R[2].z; o.w = R[0].w + R[1].w + R[2].w;
+                    } else {
+                        o.x = R[1].x - R[2].x - R[3].x; o.y = R[1].y - R[2].y - R[3].y;
+                        o.z = R[1].z - R[2].z - R[3].z; o.w = R[1].w - R[2].w - R[3].w;
+                    }
+                    if (!plain) {
+                        o.x = fmaxf(o.x + bias4.x, relu_lo); o.y = fmaxf(o.y + bias4.y, relu_lo);
+                        o.z = fmaxf(o.z + bias4.z, relu_lo); o.w = fmaxf(o.w + bias4.w, relu_lo);
+                    }
+                    const int yy = y0 + 2 * oty + pp, xx = x0 + 4 * otx + q;
+                    if (!RAGGED || (yy < p.H && xx < p.W)) {
+                        *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = o;
+                        if (!plain) {
+                            st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
+                            st2[nt][0] = fmaf(o.x, o.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, o.y, st2[nt][1]);
+                            st2[nt][2] = fmaf(o.z, o.z, st2[nt][2]); st2[nt][3] = fmaf(o.w, o.w, st2[nt][3]);
+                        }
+                    }
+                }
+            }
+        }
+        if (p.stats) { cur_tn = tn; cur_tm = tm; }
+        __syncthreads();                                                   // exchange / statistics blocks are free again
+    }
+    if (cur_tn >= 0) fold_stats();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // weight gradient: gradient-side operand transform
 // ---------------------------------------------------------------------------------------------------------------------
 struct W24WgXformParams {
@@ -644,6 +941,35 @@ int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const floa
     else { if (ragged) W24G_LAUNCH(4, true); else W24G_LAUNCH(4, false); }
 #undef W24G_LAUNCH
     return clamd_check_launch("conv3x3_winograd24_pre");
+}
+
+int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
+                                            float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
+                                            const clamd_tuning* tune, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("conv3x3_winograd24_direct_filters: empty problem");
+    if ((H & 1) || (W & 3)) return clamd_fail("conv3x3_winograd24_direct_filters: H must be even and W a multiple of 4 (2x4 output tiles)");
+    if (Cin_p % 32 || Cout_p % 64 || x_ldc % 8 || y_ldc % 8) return clamd_fail("conv3x3_winograd24_direct_filters: needs Cin_p % 32 == 0, Cout_p % 64 == 0");
+    if ((long long)H * W * x_ldc * 4 >= (1ll << 31) || (long long)24 * Cout_p * Cin_p * 4 >= (1ll << 31))
+        return clamd_fail("conv3x3_winograd24_direct_filters: image or filter exceeds 2^31 bytes");
+    if (int e = clamd_check_tuning(tune)) return e;
+    const clamd_tuning& tn = clamd_tune(tune);
+    const long long tiles = w24g_tiles(B, H, W), ntn = Cout_p / 64;
+    if (tiles * ntn > 0x7fffffff) return clamd_fail("conv3x3_winograd24_direct_filters: grid out of range");
+    if (stats && stat_rows != clamd_winograd24_stat_rows(B, H, W, Cout_p, tn))
+        return clamd_fail("conv3x3_winograd24_direct_filters: stat_rows does not match clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD24, ...)");
+    WinoParams p{x, x_ldc, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 1, 0};
+    p.band = wino_band(tiles, ntn, (double)B * H * W * Cin_p, 24.0 * Cin_p * Cout_p, tn.wino_band);
+    p.nblk = (int)(tiles * ntn);
+    const unsigned grid = tn.wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_usable_cus(tn)) : (unsigned)p.nblk;
+    int ph, pw;
+    w24g_tile(W, ph, pw);
+    const bool ragged = (H % ph) != 0 || (W % pw) != 0;
+    hipStream_t s = (hipStream_t)stream;
+#define W24H_LAUNCH(TXN_, RG_) hipLaunchKernelGGL((wino24h_kernel<TXN_, RG_>), dim3(grid), dim3(256), 0, s, p)
+    if (pw == 32) { if (ragged) W24H_LAUNCH(8, true); else W24H_LAUNCH(8, false); }
+    else { if (ragged) W24H_LAUNCH(4, true); else W24H_LAUNCH(4, false); }
+#undef W24H_LAUNCH
+    return clamd_check_launch("conv3x3_winograd24_direct_filters");
 }
 
 size_t clamd_wgrad_winograd24_pre_operand_elems(int B, int H, int W, int Rp) {

@@ -129,6 +129,13 @@ int clamd_winograd24_transform_input(const float* x, int x_ldc, float* v, int B,
 int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const float* bias, float* y, int y_ldc,
                                  float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
                                  const clamd_tuning* tune, void* stream);
+/* The narrow layers (64 / 128 channels, levels 0-1 of models/unet.py:49-72, where 3x the activation bytes through HBM would
+ * cost more than the in-kernel transform): clamd_conv3x3_winograd24 with the FILTER fragments loaded straight into the MFMA
+ * operand registers instead of being staged through LDS (wino24h_kernel, wino24g.hip).  Same arguments, same packed filters,
+ * bit-identical results and statistics rows; needs Cout_p % 64 == 0 and Cin_p % 32 == 0. */
+int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
+                                            float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
+                                            const clamd_tuning* tune, void* stream);
 /* Weight gradient of the same convolution as a batched GEMM over the 24 Winograd planes (K = tiles) on operands transformed
  * once: v = the forward image of the convolution INPUT (clamd_winograd24_transform_input, kept from the forward pass: it is
  * read in place as the x-side operand), yt = caller-provided scratch of clamd_wgrad_winograd24_pre_operand_elems(B,H,W,Rp)

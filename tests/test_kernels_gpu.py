@@ -612,6 +612,17 @@ def test_conv3x3_winograd24_pretransformed(C, shape):
         assert torch.equal(gx, gx_p)
         got_gx = gx_p.cpu().numpy().transpose(0, 3, 1, 2)
         assert rel_l2(got_gx[:, [p_ for p_, l in enumerate(pm) if l >= 0]], rgx) < TOL[0]
+        # the narrow-layer variant: in-kernel transform, filters straight into the operand registers -- bit-identical as well
+        y_h = torch.full((B, H, W, cout_p), 9.0, device='cuda')
+        stats_h = torch.full_like(stats, float('nan'))
+        lib.call('clamd_conv3x3_winograd24_direct_filters', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y_h), cout_p, ptr(stats_h), rows, B, H, W,
+                 cin_p, cout_p, 1, tp, s)
+        gx_h = torch.full((B, H, W, cin_p), 5.0, device='cuda')
+        lib.call('clamd_conv3x3_winograd24_direct_filters', ptr(gzt), cout_p, ptr(wd), None, ptr(gx_h), cin_p, None, 0, B, H, W, cout_p, cin_p,
+                 0, tp, s)
+        sync()
+        assert torch.equal(y, y_h) and torch.equal(gx, gx_h)
+        assert torch.equal(stats, stats_h), 'same block order as clamd_conv3x3_winograd24: identical rows'
     # refused shapes
     with pytest.raises(RuntimeError, match='Cout_p % 64'):
         lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), 32, None, 0, B, H, W, cin_p, 32, 1, None, s)
