@@ -35,6 +35,7 @@ namespace clamd {
 // ---------------------------------------------------------------------------------------------------------------------
 struct W24XformParams {
     const float* x; int x_ldc;
+    const float* scale; const float* shift;      // optional per-channel affine applied on load (a BatchNorm folded into the transform)
     float* v;
     int B, H, W, Kp;
 };
@@ -54,36 +55,65 @@ struct W24XformParams {
         }                                                                                                          \
     } while (0)
 
-// One wave = one (tile block, 8-channel chunk): lane (h = lane >> 5, r = lane & 31) reads the 4 x 6 input patch of tile r,
-// channels 4h..4h+3 of the chunk, and writes its 16 bytes of each of the 24 planes: every store instruction of the wave is
-// one contiguous 1-KB unit [h][r][4] -- exactly what one buffer_load_dwordx4 of wino24g_kernel fetches.
+// One workgroup = one tile block x 32 channels (four 8-channel chunks, one per wave).  The halo of the block is staged in LDS
+// with whole 128-byte lines per pixel (8 lanes x 16 bytes: every global load instruction reads full lines; the overlap with the
+// neighbouring blocks is served by L2), zero padding -- and the optional affine y * scale + shift, i.e. the BatchNorm in front
+// of this convolution, applied to in-image pixels only: padding stays zero AFTER the affine, as nn.Conv2d pads (models/unet.py:15-16)
+// -- materialised at staging.  Then lane (h = lane >> 5, r = lane & 31) of wave w reads the 4 x 6 patch of tile r, channels
+// 4h..4h+3 of chunk w, and writes its 16 bytes of each of the 24 planes: every store instruction of a wave is one contiguous
+// 1-KB unit [h][r][4], exactly what one buffer_load_dwordx4 of wino24g_kernel fetches.
 template <int TXN>
 __global__ void __launch_bounds__(256) wino24_xform_kernel(const W24XformParams p) {
     constexpr int TYN = 32 / TXN, PW = 4 * TXN, PH = 2 * TYN;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int HW_ = PW + 2, HH_ = PH + 2, PIX = HW_ * HH_;
+    constexpr int PITCH = 9;                                           // 16-byte slots per pixel: 8 used + 1 (spreads the tiles over the banks)
+    constexpr int NJ = (PIX * 8 + 255) / 256;
+    __shared__ uint4 sm[PIX * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int nk = p.Kp >> 3, nkg = (nk + 3) >> 2;
+    const int nk = p.Kp >> 3;
     const int tiles_x = (p.W + PW - 1) / PW, tiles_y = (p.H + PH - 1) / PH;
     const int ntm = tiles_x * tiles_y * p.B;
     // neighbouring tile blocks (shared halo rows / columns) get neighbouring ids inside one XCD's range
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int kg = bid / ntm, tm = bid - kg * ntm;
-    const int kc = kg * 4 + w;
-    if (kc >= nk) return;                                              // whole wave; the kernel has no barrier
-    (void)nkg;
     const int x0 = (tm % tiles_x) * PW, y0 = ((tm / tiles_x) % tiles_y) * PH, b = tm / (tiles_x * tiles_y);
-    const int ty = r / TXN, tx = r % TXN;
-    const int py = y0 + 2 * ty - 1, px = x0 + 4 * tx - 1;
     const unsigned img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc * 4u;
     const __amdgpu_buffer_rsrc_t xrs = make_rsrc((const char*)p.x + (size_t)b * img, img);
+    {
+        const int g = tid & 7;                                         // this thread's 4-channel group of the 32 channels, fixed
+        const int ch = kg * 32 + 4 * g;
+        const bool chan_ok = ch < p.Kp;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale && chan_ok) { sc = *reinterpret_cast<const float4*>(p.scale + ch); sh = *reinterpret_cast<const float4*>(p.shift + ch); }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int pix = (tid >> 3) + 32 * j;
+            if (pix < PIX) {
+                const int hy = pix / HW_, hx = pix - hy * HW_;
+                const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+                const bool ok = chan_ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                const uint4 u = buf_ld16(xrs, ok ? (unsigned)(((yy * p.W + xx) * p.x_ldc + ch) * 4) : BUF_OOB, 0u);
+                float4 f = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+                if (p.scale) {
+                    f.x = ok ? fmaf(f.x, sc.x, sh.x) : 0.f; f.y = ok ? fmaf(f.y, sc.y, sh.y) : 0.f;
+                    f.z = ok ? fmaf(f.z, sc.z, sh.z) : 0.f; f.w = ok ? fmaf(f.w, sc.w, sh.w) : 0.f;
+                }
+                sm[pix * PITCH + g] = make_uint4(__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w));
+            }
+        }
+    }
+    __syncthreads();
+    const int kc = kg * 4 + w;
+    if (kc >= nk) return;                                              // whole wave; no barrier below
+    const int ty = r / TXN, tx = r % TXN;
+    const uint4* const src = sm + ((2 * ty) * HW_ + 4 * tx) * PITCH + 2 * w + h;
     float4 d[4][6];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const int yy = py + a, xx = px + c;
-            const unsigned vo = (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) ? (unsigned)(((yy * p.W + xx) * p.x_ldc + kc * 8 + 4 * h) * 4) : BUF_OOB;
-            const uint4 u = buf_ld16(xrs, vo, 0u);
+            const uint4 u = src[(a * HW_ + c) * PITCH];
             d[a][c] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
         }
     float* const dst = p.v + (((size_t)tm * nk + kc) * 24) * 256 + h * 128 + r * 4;
@@ -899,7 +929,9 @@ size_t clamd_winograd24_input_elems(int B, int H, int W, int Cp) {
     return (size_t)w24g_tiles(B, H, W) * (size_t)(Cp / 8) * 24 * 256;
 }
 
-int clamd_winograd24_transform_input(const float* x, int x_ldc, float* v, int B, int H, int W, int Cp, void* stream) {
+int clamd_winograd24_transform_input(const float* x, int x_ldc, const float* scale, const float* shift, float* v, int B, int H, int W,
+                                     int Cp, void* stream) {
+    if ((scale == nullptr) != (shift == nullptr)) return clamd_fail("winograd24_transform_input: scale and shift go together");
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("winograd24_transform_input: empty problem");
     if ((H & 1) || (W & 3)) return clamd_fail("winograd24_transform_input: H must be even and W a multiple of 4 (2x4 output tiles)");
     if (Cp % 8 || x_ldc % 4 || x_ldc < Cp) return clamd_fail("winograd24_transform_input: channel count / pitch must be padded");
@@ -908,7 +940,7 @@ int clamd_winograd24_transform_input(const float* x, int x_ldc, float* v, int B,
     w24g_tile(W, ph, pw);
     const long long ntm = w24g_tiles(B, H, W), nkg = (Cp / 8 + 3) / 4;
     if (ntm * nkg > 0x7fffffff) return clamd_fail("winograd24_transform_input: grid out of range");
-    W24XformParams p{x, x_ldc, v, B, H, W, Cp};
+    W24XformParams p{x, x_ldc, scale, shift, v, B, H, W, Cp};
     if (pw == 32) hipLaunchKernelGGL(wino24_xform_kernel<8>, dim3((unsigned)(ntm * nkg)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(wino24_xform_kernel<4>, dim3((unsigned)(ntm * nkg)), dim3(256), 0, (hipStream_t)stream, p);
     return clamd_check_launch("winograd24_transform_input");

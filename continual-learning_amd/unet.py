@@ -43,6 +43,10 @@ WINOGRAD24_WGRAD = 'auto'
 # 'auto' = where the transform pass pays for itself (see _Engine.unit); False = never.
 PRETRANSFORM = os.environ.get('CLAMD_PRETRANSFORM', 'auto')
 PRETRANSFORM = {'0': False, 'false': False, '1': True, 'true': True}.get(str(PRETRANSFORM).lower(), 'auto')
+# ... and the BatchNorm in front of such a convolution is applied by the transform kernel on load where nothing else reads the
+# BatchNorm output (the first unit of enc3/enc4/dec1/dec2/dec3): one HBM pass less per unit.  False = always run clamd_bn_apply.
+FOLD_BN_INTO_TRANSFORM = os.environ.get('CLAMD_FOLD_BN', '1') != '0'
+NARROW_DIRECT = os.environ.get('CLAMD_NARROW_DIRECT', '1') != '0'
 # Weight-gradient kernels (and the bias-gradient channel sums of the ConvTranspose / head layers) go to a second HIP stream:
 # they are off the critical chain of the backward pass (dgrad -> BatchNorm-backward reduce / finalize / apply -> dgrad ...),
 # and the HBM-bound BatchNorm passes of the NEXT unit fit beside a weight-gradient workgroup on the same CU (one wave per
@@ -344,11 +348,15 @@ class _Engine:
             pt = PRETRANSFORM
             u.pre_w = bool(pt) and u.w24 and u.cin_p % 256 == 0 and u.cout_p % 256 == 0
             u.pre_f = bool(pt) and u.w24 and u.cin_p >= 64 and u.cout_p % 64 == 0 and (
-                pt is True or (u.cin_p >= 256 and (u.pre_w or 2 * u.cout_p > u.cin_p)))
+                pt is True or (u.cin_p >= 256 and (u.pre_w or 2 * u.cout_p > u.cin_p)) or (u.cin_p >= 128 and u.cout_p >= 2 * u.cin_p))
             u.pre_w = u.pre_w and u.pre_f
             u.pre_d = bool(pt) and u.w24d and not first_of_net and u.cout_p >= 64 and u.cin_p % 64 == 0 and (
                 pt is True or (u.cout_p >= 256 and 2 * u.cin_p > u.cout_p))
             u.vx = torch.empty(lib.clamd_winograd24_input_elems(B, u.h, u.w_, u.cin_p), dtype=torch.float32, device=dev) if u.pre_f else None
+            # 64 input channels (8 chunks per tile): the in-kernel-transform kernel with the filters loaded straight into the operand
+            # registers (wino24h_kernel) is 4-6 % faster there and 1-4 % slower on longer K loops (tools/wino24h_ab.py)
+            u.direct_f = NARROW_DIRECT and u.w24 and not u.pre_f and u.cin_p == 64 and u.cout_p % 64 == 0
+            u.direct_d = NARROW_DIRECT and u.w24d and not u.pre_d and not first_of_net and u.cout_p == 64 and u.cin_p % 64 == 0
             ntap = 1 if u.im2col else ((24 if u.w24 else 16) if u.wino else 9)   # Winograd: [Cin_p/8][16|24][Cout_p][8] transformed filters
             ntap_d = (24 if u.w24d else 16) if u.wino else ntap
             u.wf = torch.zeros(ntap * u.cout_p * u.cin_p, dtype=T, device=dev)
@@ -424,6 +432,14 @@ class _Engine:
             tail.bias_p = torch.zeros(tail.cout_p, dtype=torch.float32, device=dev)
             self.stages.append(dict(kind='dec', convs=(a, b), tail=tail))
         self.convs = convs
+        for u in convs:
+            u.apply_folded, u.fold_src = False, None
+        for st in self.stages:
+            a, b = st['convs']
+            # a's BatchNorm output `ua` is read by b's convolution (forward) and by b's weight gradient only: when both run on b's
+            # transformed input, the affine is applied by the transform itself and a's bn_apply pass (and `ua`) disappears
+            if FOLD_BN_INTO_TRANSFORM and b.pre_f and b.pre_w and a.pooled is None and b.xin is a.out:
+                a.apply_folded, b.fold_src = True, a
         for s in self.stages:
             t = s.get('tail')
             if t is not None and t.consumer is not None:
@@ -654,14 +670,18 @@ class _Engine:
                 torch.cuda.current_stream().wait_stream(self.wg_stream)
                 self._pack_pending = 0
             if u.pre_f:
+                # the BatchNorm of the unit in front folded into the transform where nothing else reads its output (u.fold_src)
+                f = u.fold_src
+                xsrc, xldc, fs, fh = (f.y, f.cout_p, f.vec[0], f.vec[1]) if f is not None else (u.xin, u.xin_ldc, None, None)
                 _timed('wino_transform', 0.0, 16 * B * u.h * u.w_ * u.cin_p,        # reads the activation once, writes 3x its size
-                       'clamd_winograd24_transform_input', ptr(u.xin), u.xin_ldc, ptr(u.vx), B, u.h, u.w_, u.cin_p, s)
+                       'clamd_winograd24_transform_input', ptr(xsrc), xldc, ptr(fs), ptr(fh), ptr(u.vx), B, u.h, u.w_, u.cin_p, s)
                 _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
                        'clamd_conv3x3_winograd24_pre', ptr(u.vx), ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
                        ptr(u.stats) if training else None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
             else:
                 _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
-                       'clamd_conv3x3_winograd24' if u.w24 else 'clamd_conv3x3_winograd', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
+                       ('clamd_conv3x3_winograd24_direct_filters' if u.direct_f else 'clamd_conv3x3_winograd24') if u.w24 else 'clamd_conv3x3_winograd',
+                       ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
                        ptr(u.stats) if training else None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
         else:
             _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
@@ -670,8 +690,9 @@ class _Engine:
                    u.m_fastest, dc, tp, s)
         call('clamd_bn_finalize', ptr(u.stats) if training else None, u.stat_rows, ptr(u.gamma), ptr(u.beta), ptr(u.rm), ptr(u.rv),
              ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), u.cout_p, u.cout, float(B * u.h * u.w_), BN_MOMENTUM, BN_EPS, s)
-        call('clamd_bn_apply', ptr(u.y), u.cout_p, ptr(v[0]), ptr(v[1]), ptr(u.out), u.out_ldc,
-             ptr(u.pooled), u.pooled.shape[-1] if u.pooled is not None else 0, B, u.h, u.w_, u.cout_p, dc, s)
+        if not u.apply_folded:      # otherwise the only reader of the BatchNorm output is the next convolution's input transform
+            call('clamd_bn_apply', ptr(u.y), u.cout_p, ptr(v[0]), ptr(v[1]), ptr(u.out), u.out_ldc,
+                 ptr(u.pooled), u.pooled.shape[-1] if u.pooled is not None else 0, B, u.h, u.w_, u.cout_p, dc, s)
 
     # ------------------------------------------------------------------------------------------ backward
     def _wg_stream_ptr(self):
@@ -777,13 +798,14 @@ class _Engine:
             _TIMED_UNIT[:] = [u.name + ' dgrad', self.executed_fraction(u, 'dgrad')]
             if u.g_in is not None and u.pre_d:
                 _timed('wino_transform', 0.0, 16 * B * u.h * u.w_ * u.cout_p,      # reads the gradient once, writes 3x its size
-                       'clamd_winograd24_transform_input', ptr(u.gz), u.cout_p, ptr(self.vg), B, u.h, u.w_, u.cout_p, s)
+                       'clamd_winograd24_transform_input', ptr(u.gz), u.cout_p, None, None, ptr(self.vg), B, u.h, u.w_, u.cout_p, s)
                 _timed('igemm_conv3x3', flops, self._conv_bytes(u),
                        'clamd_conv3x3_winograd24_pre', ptr(self.vg), ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
                        B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
             elif u.g_in is not None and u.wino:
                 _timed('igemm_conv3x3', flops, self._conv_bytes(u),
-                       'clamd_conv3x3_winograd24' if u.w24d else 'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
+                       ('clamd_conv3x3_winograd24_direct_filters' if u.direct_d else 'clamd_conv3x3_winograd24') if u.w24d else 'clamd_conv3x3_winograd',
+                       ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
                        B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
             elif u.g_in is not None:
                 _timed('igemm_conv3x3', flops, self._conv_bytes(u),

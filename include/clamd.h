@@ -123,9 +123,14 @@ int clamd_wgrad_winograd24(const float* gz, int gz_ldc, const float* x, int x_ld
  * tensor (clamd_winograd24_transform_input: x [B,H,W,ldc] -> v, clamd_winograd24_input_elems() floats, 3x the
  * activation) and clamd_conv3x3_winograd24_pre runs a transform-free K loop (48 MFMAs + 18 buffer loads straight into
  * the operand registers, no LDS, no VALU) on the SAME packed filters, tile grid, epilogue and statistics rows:
- * bit-identical to clamd_conv3x3_winograd24.  Needs Cin_p % 32 == 0, Cin_p >= 64, Cout_p % 64 == 0. */
+ * bit-identical to clamd_conv3x3_winograd24.  Needs Cin_p % 32 == 0, Cin_p >= 64, Cout_p % 64 == 0.
+ * scale / shift (optional, [Cp] each): the transform reads x * scale + shift instead of x -- the nn.BatchNorm2d in front of the
+ * convolution (models/unet.py:15-16,30-31: clamd_bn_finalize's scale / shift on the producer's conv+ReLU output) folded into
+ * the load, with the zero padding applied AFTER the affine as nn.Conv2d does; the clamd_bn_apply pass of that unit is then not
+ * needed when nothing else reads its output. */
 size_t clamd_winograd24_input_elems(int B, int H, int W, int Cp);
-int clamd_winograd24_transform_input(const float* x, int x_ldc, float* v, int B, int H, int W, int Cp, void* stream);
+int clamd_winograd24_transform_input(const float* x, int x_ldc, const float* scale, const float* shift, float* v, int B, int H, int W,
+                                     int Cp, void* stream);
 int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const float* bias, float* y, int y_ldc,
                                  float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
                                  const clamd_tuning* tune, void* stream);

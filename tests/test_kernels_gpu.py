@@ -585,7 +585,7 @@ def test_conv3x3_winograd24_pretransformed(C, shape):
         y_p = torch.full((B, H, W, cout_p), 8.0, device='cuda')
         lib.call('clamd_conv3x3_winograd24', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), rows, B, H, W, cin_p, cout_p, 1, tp, s)
         v = torch.full((L.clamd_winograd24_input_elems(B, H, W, cin_p),), float('nan'), device='cuda')
-        lib.call('clamd_winograd24_transform_input', ptr(xt), cin_p, ptr(v), B, H, W, cin_p, s)
+        lib.call('clamd_winograd24_transform_input', ptr(xt), cin_p, None, None, ptr(v), B, H, W, cin_p, s)
         lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), cout_p, ptr(stats_p), rows, B, H, W, cin_p, cout_p, 1, tp, s)
         sync()
         assert not bool(torch.isnan(v).any()), 'the transform must write every element of V'
@@ -606,7 +606,7 @@ def test_conv3x3_winograd24_pretransformed(C, shape):
         gx_p = torch.full((B, H, W, cin_p), 4.0, device='cuda')
         lib.call('clamd_conv3x3_winograd24', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, 0, B, H, W, cout_p, cin_p, 0, tp, s)
         vg = torch.empty(L.clamd_winograd24_input_elems(B, H, W, cout_p), device='cuda')
-        lib.call('clamd_winograd24_transform_input', ptr(gzt), cout_p, ptr(vg), B, H, W, cout_p, s)
+        lib.call('clamd_winograd24_transform_input', ptr(gzt), cout_p, None, None, ptr(vg), B, H, W, cout_p, s)
         lib.call('clamd_conv3x3_winograd24_pre', ptr(vg), ptr(wd), None, ptr(gx_p), cin_p, None, 0, B, H, W, cout_p, cin_p, 0, tp, s)
         sync()
         assert torch.equal(gx, gx_p)
@@ -623,6 +623,17 @@ def test_conv3x3_winograd24_pretransformed(C, shape):
         sync()
         assert torch.equal(y, y_h) and torch.equal(gx, gx_h)
         assert torch.equal(stats, stats_h), 'same block order as clamd_conv3x3_winograd24: identical rows'
+    # BatchNorm folded into the transform: V(raw * scale + shift, zero padding AFTER the affine) == V of the materialised tensor
+    scale = torch.rand(cin_p, device='cuda') + 0.5
+    shift = torch.randn(cin_p, device='cuda')
+    applied = torch.empty_like(xt)                                 # the materialised BatchNorm output: clamd_bn_apply (one fma per element)
+    lib.call('clamd_bn_apply', ptr(xt), cin_p, ptr(scale), ptr(shift), ptr(applied), cin_p, None, 0, B, H, W, cin_p, 0, s)
+    v_ref = torch.empty_like(v)
+    v_fold = torch.full_like(v, float('nan'))
+    lib.call('clamd_winograd24_transform_input', ptr(applied), cin_p, None, None, ptr(v_ref), B, H, W, cin_p, s)
+    lib.call('clamd_winograd24_transform_input', ptr(xt), cin_p, ptr(scale), ptr(shift), ptr(v_fold), B, H, W, cin_p, s)
+    sync()
+    assert torch.equal(v_ref, v_fold)
     # refused shapes
     with pytest.raises(RuntimeError, match='Cout_p % 64'):
         lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), 32, None, 0, B, H, W, cin_p, 32, 1, None, s)
@@ -653,7 +664,7 @@ def test_wgrad_winograd24_pretransformed(C, shape):
     lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
     L = lib.load()
     v = torch.empty(L.clamd_winograd24_input_elems(B, H, W, cin_p), device='cuda')
-    lib.call('clamd_winograd24_transform_input', ptr(xt), cin_p, ptr(v), B, H, W, cin_p, s)
+    lib.call('clamd_winograd24_transform_input', ptr(xt), cin_p, None, None, ptr(v), B, H, W, cin_p, s)
     yt = torch.full((L.clamd_wgrad_winograd24_pre_operand_elems(B, H, W, cout_p),), float('nan'), device='cuda')
     wsb = L.clamd_wgrad_winograd24_pre_workspace_bytes(B, H, W, cout_p, cin_p)
     ws = torch.empty(wsb // 4 + 4, device='cuda')
