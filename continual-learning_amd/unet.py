@@ -47,6 +47,18 @@ PRETRANSFORM = {'0': False, 'false': False, '1': True, 'true': True}.get(str(PRE
 # BatchNorm output (the first unit of enc3/enc4/dec1/dec2/dec3): one HBM pass less per unit.  False = always run clamd_bn_apply.
 FOLD_BN_INTO_TRANSFORM = os.environ.get('CLAMD_FOLD_BN', '1') != '0'
 NARROW_DIRECT = os.environ.get('CLAMD_NARROW_DIRECT', '1') != '0'
+# Forward pass in two half-batches where a half still fills the chip (levels 0-2 at config 2): conv -> BatchNorm statistics ->
+# apply -> conv is a chain through the whole batch, so the HBM-bound passes (bn_apply, the input transforms) have nothing to run
+# beside -- unless the batch is cut in two: the second half's apply / transform runs on the second stream UNDER the first half's
+# next convolution (statistics rows of the two launches are concatenated; BatchNorm still normalises over the whole batch).
+# Same kernels, pointer offsets only; results differ from the unsplit run only in the (fixed) order the statistics rows are summed.
+# BUILT, MEASURED, OFF BY DEFAULT (tools/step_ab.py <dtype> HALF_BATCH False True, interleaved in one process): fp32 21.40 -> 21.67,
+# bf16 6.65 -> 6.93, bf16x3 14.39 -> 14.63 ms per step.  The forward convolution kernels hold a whole CU (one wave per SIMD with
+# 447-512 registers, 120-147 KB of LDS): unlike beside the weight-gradient kernels of the backward pass (88-168 registers free) there
+# is no room for a BatchNorm-pass wave on a CU that runs one, so the "overlapped" pass only takes CUs away from the convolution, and
+# every split convolution pays a second launch ramp and tile tail.
+HALF_BATCH = os.environ.get('CLAMD_HALF_BATCH', '0') != '0'
+HALF_BATCH_MIN_PIXELS = int(os.environ.get('CLAMD_HALF_BATCH_MIN_PIXELS', '32768'))     # pixels of one half: 8 images at 64 x 64
 # Weight-gradient kernels (and the bias-gradient channel sums of the ConvTranspose / head layers) go to a second HIP stream:
 # they are off the critical chain of the backward pass (dgrad -> BatchNorm-backward reduce / finalize / apply -> dgrad ...),
 # and the HBM-bound BatchNorm passes of the NEXT unit fit beside a weight-gradient workgroup on the same CU (one wave per
@@ -355,6 +367,7 @@ class _Engine:
             u.vx = torch.empty(lib.clamd_winograd24_input_elems(B, u.h, u.w_, u.cin_p), dtype=torch.float32, device=dev) if u.pre_f else None
             # 64 input channels (8 chunks per tile): the in-kernel-transform kernel with the filters loaded straight into the operand
             # registers (wino24h_kernel) is 4-6 % faster there and 1-4 % slower on longer K loops (tools/wino24h_ab.py)
+            u.split = HALF_BATCH and B % 2 == 0 and (B // 2) * u.h * u.w_ >= HALF_BATCH_MIN_PIXELS
             u.direct_f = NARROW_DIRECT and u.w24 and not u.pre_f and u.cin_p == 64 and u.cout_p % 64 == 0
             u.direct_d = NARROW_DIRECT and u.w24d and not u.pre_d and not first_of_net and u.cout_p == 64 and u.cin_p % 64 == 0
             ntap = 1 if u.im2col else ((24 if u.w24 else 16) if u.wino else 9)   # Winograd: [Cin_p/8][16|24][Cout_p][8] transformed filters
@@ -440,6 +453,13 @@ class _Engine:
             # transformed input, the affine is applied by the transform itself and a's bn_apply pass (and `ua`) disappears
             if FOLD_BN_INTO_TRANSFORM and b.pre_f and b.pre_w and a.pooled is None and b.xin is a.out:
                 a.apply_folded, b.fold_src = True, a
+        for st in self.stages:      # half-batch pipeline: a's second-half apply may run under b's first-half convolution; across stages
+            a, b = st['convs']     # only along the encoder (b.pooled feeds the next stage's first convolution directly)
+            a.pipe_next = a.split and b.split
+            b.pipe_next = False
+        for k in range(3):
+            b, nxt = self.stages[k]['convs'][1], self.stages[k + 1]['convs'][0]
+            b.pipe_next = b.split and nxt.split and nxt.xin is b.pooled
         for s in self.stages:
             t = s.get('tail')
             if t is not None and t.consumer is not None:
@@ -491,13 +511,15 @@ class _Engine:
         rows = _lib.stat_rows
         sizes = []
         for u in self.convs:
+            Bl = B // 2 if u.split else B          # images per forward launch (half-batch pipeline: two launches, rows concatenated)
             if u.im2col:
-                u.stat_rows = rows(_lib.OP_CONV1X1, B, u.h, u.w_, u.cin_p, u.cout_p, dc)
+                r = rows(_lib.OP_CONV1X1, Bl, u.h, u.w_, u.cin_p, u.cout_p, dc)
             elif u.wino:
-                u.stat_rows = rows(_lib.OP_CONV3X3_WINOGRAD24 if u.w24 else _lib.OP_CONV3X3_WINOGRAD, B, u.h, u.w_, u.cin_p, u.cout_p,
-                                   dc, tuning=tn)
+                r = rows(_lib.OP_CONV3X3_WINOGRAD24 if u.w24 else _lib.OP_CONV3X3_WINOGRAD, Bl, u.h, u.w_, u.cin_p, u.cout_p, dc, tuning=tn)
             else:
-                u.stat_rows = rows(_lib.OP_CONV3X3, B, u.h, u.w_, u.cin_p, u.cout_p, dc, tuning=tn)
+                r = rows(_lib.OP_CONV3X3, Bl, u.h, u.w_, u.cin_p, u.cout_p, dc, tuning=tn)
+            u.stat_rows_launch = r
+            u.stat_rows = 2 * r if u.split else r
             if u.fused_reduce:
                 src = getattr(u, 'sum_src', None)
                 if src is None:       # the 3x3 data-gradient launch of the next conv of this stage (K = its output channels)
@@ -595,12 +617,46 @@ class _Engine:
         else:
             call('clamd_nchw_to_nhwc', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
                  self.x_in.shape[-1], 1.0, dc, s)
+        # two streams only outside the per-launch timing mode; the split itself is structural (statistics rows) and always applies
+        s2 = self.wg_stream if (self.wg_stream is not None and KERNEL_TIMING is None) else None
+        cur = torch.cuda.current_stream()
+        defer = None                      # the producer's second-half apply, waiting for a convolution to run under
         for st in self.stages:
             for u in st['convs']:
-                self._conv_fwd(u, training, s)
+                if not u.split:
+                    self._fwd_pre(u, s, None)
+                    self._fwd_conv(u, training, s, None)
+                    self._fwd_finalize(u, training, s)
+                    self._fwd_post(u, s, None)
+                    continue
+                self._fwd_pre(u, s, 0)
+                if s2 is not None:
+                    ev_a = torch.cuda.Event(); ev_a.record(cur)
+                    s2.wait_event(ev_a)                       # not before the first half's convolution is about to start
+                    sp2 = s2.cuda_stream
+                    if defer is not None:
+                        defer(sp2)
+                    self._fwd_pre(u, sp2, 1)
+                    ev_b = torch.cuda.Event(); ev_b.record(s2)
+                    self._fwd_conv(u, training, s, 0)
+                    cur.wait_event(ev_b)
+                else:
+                    if defer is not None:
+                        defer(s)
+                    self._fwd_pre(u, s, 1)
+                    self._fwd_conv(u, training, s, 0)
+                defer = None
+                self._fwd_conv(u, training, s, 1)
+                self._fwd_finalize(u, training, s)
+                self._fwd_post(u, s, 0)
+                if u.pipe_next:
+                    defer = (lambda sp, u=u: self._fwd_post(u, sp, 1))
+                else:
+                    self._fwd_post(u, s, 1)
             t = st.get('tail')
             if t is None:
-                continue
+                continue               # encoder: the pooled output feeds the next stage's first convolution (defer may be pending)
+            assert defer is None
             h, w = H >> t.level, W >> t.level
             if t.kind == 'convT':
                 call('clamd_convT2x2_fwd', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(t.y_slice), t.y_ldc,
@@ -650,13 +706,43 @@ class _Engine:
         output activation once each, filters (or their gradient) once."""
         return self.esize * (self.B * u.h * u.w_ * (u.cin + u.cout) + 9 * u.cin * u.cout)
 
-    def _conv_fwd(self, u, training, s):
-        B, dc, tp = self.B, self.dcode, tune_ptr(self.tuning)
+    def _hv(self, t, hf):
+        """Half `hf` (0 / 1) of a batch-major activation tensor, or the whole tensor (hf None)."""
+        if hf is None or t is None:
+            return t
+        hb = self.B // 2
+        return t[hf * hb:(hf + 1) * hb]
+
+    def _fwd_pre(self, u, s, hf):
+        """Input transform of a pre-transformed convolution (wino24g.hip) on the whole batch or one half of it."""
+        if not u.pre_f:
+            return
+        Bl = self.B if hf is None else self.B // 2
+        # the BatchNorm of the unit in front folded into the transform where nothing else reads its output (u.fold_src)
+        f = u.fold_src
+        xsrc, xldc, fs, fh = (f.y, f.cout_p, f.vec[0], f.vec[1]) if f is not None else (u.xin, u.xin_ldc, None, None)
+        n = u.vx.numel() // 2
+        vx = u.vx if hf is None else u.vx[hf * n:(hf + 1) * n]              # tile blocks are image-major
         _TIMED_UNIT[:] = [u.name + ' fwd', self.executed_fraction(u, 'fwd')]
-        v = u.vec
+        _timed('wino_transform', 0.0, 16 * Bl * u.h * u.w_ * u.cin_p,        # reads the activation once, writes 3x its size
+               'clamd_winograd24_transform_input', ptr(self._hv(xsrc, hf)), xldc, ptr(fs), ptr(fh), ptr(vx), Bl, u.h, u.w_, u.cin_p, s)
+
+    def _fwd_conv(self, u, training, s, hf):
+        """conv3x3 + bias + ReLU (+ BatchNorm statistics rows) of unit u on the whole batch or one half of it."""
+        dc, tp = self.dcode, tune_ptr(self.tuning)
+        Bl = self.B if hf is None else self.B // 2
+        _TIMED_UNIT[:] = [u.name + ' fwd', self.executed_fraction(u, 'fwd')]
+        rows = u.stat_rows_launch
+        st = None
+        if training:
+            k = rows * 2 * u.cout_p
+            st = u.stats if hf is None else u.stats[hf * k:(hf + 1) * k]
+        xin, y = self._hv(u.xin, hf), self._hv(u.y, hf)
+        flops = 2.0 * Bl * u.h * u.w_ * 9 * u.cin * u.cout
+        nbytes = self.esize * (Bl * u.h * u.w_ * (u.cin + u.cout) + 9 * u.cin * u.cout)
         if u.im2col:
-            call('clamd_conv1x1', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
-                 ptr(u.stats) if training else None, None, None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
+            call('clamd_conv1x1', ptr(xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p,
+                 ptr(st), None, None, rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
         elif u.wino:
             if self._pack_pending == 2:
                 # the late transforms (HBM-bound, 0.15 ms) start here, under this MFMA-bound convolution, instead of beside the
@@ -670,29 +756,32 @@ class _Engine:
                 torch.cuda.current_stream().wait_stream(self.wg_stream)
                 self._pack_pending = 0
             if u.pre_f:
-                # the BatchNorm of the unit in front folded into the transform where nothing else reads its output (u.fold_src)
-                f = u.fold_src
-                xsrc, xldc, fs, fh = (f.y, f.cout_p, f.vec[0], f.vec[1]) if f is not None else (u.xin, u.xin_ldc, None, None)
-                _timed('wino_transform', 0.0, 16 * B * u.h * u.w_ * u.cin_p,        # reads the activation once, writes 3x its size
-                       'clamd_winograd24_transform_input', ptr(xsrc), xldc, ptr(fs), ptr(fh), ptr(u.vx), B, u.h, u.w_, u.cin_p, s)
-                _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
-                       'clamd_conv3x3_winograd24_pre', ptr(u.vx), ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
-                       ptr(u.stats) if training else None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
+                n = u.vx.numel() // 2
+                vx = u.vx if hf is None else u.vx[hf * n:(hf + 1) * n]
+                _timed('igemm_conv3x3', flops, nbytes, 'clamd_conv3x3_winograd24_pre', ptr(vx), ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p,
+                       ptr(st), rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
             else:
-                _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
+                _timed('igemm_conv3x3', flops, nbytes,
                        ('clamd_conv3x3_winograd24_direct_filters' if u.direct_f else 'clamd_conv3x3_winograd24') if u.w24 else 'clamd_conv3x3_winograd',
-                       ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
-                       ptr(u.stats) if training else None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
+                       ptr(xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p, ptr(st), rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
         else:
-            _timed('igemm_conv3x3', 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout, self._conv_bytes(u),
-                   'clamd_conv3x3', ptr(u.xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(u.y), u.cout_p,
-                   ptr(u.stats) if training else None, None, None, u.stat_rows, B, u.h, u.w_, u.cin_p, u.cout_p, 1,
-                   u.m_fastest, dc, tp, s)
+            _timed('igemm_conv3x3', flops, nbytes, 'clamd_conv3x3', ptr(xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p,
+                   ptr(st), None, None, rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, u.m_fastest, dc, tp, s)
+
+    def _fwd_finalize(self, u, training, s):
+        v = u.vec
         call('clamd_bn_finalize', ptr(u.stats) if training else None, u.stat_rows, ptr(u.gamma), ptr(u.beta), ptr(u.rm), ptr(u.rv),
-             ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), u.cout_p, u.cout, float(B * u.h * u.w_), BN_MOMENTUM, BN_EPS, s)
-        if not u.apply_folded:      # otherwise the only reader of the BatchNorm output is the next convolution's input transform
-            call('clamd_bn_apply', ptr(u.y), u.cout_p, ptr(v[0]), ptr(v[1]), ptr(u.out), u.out_ldc,
-                 ptr(u.pooled), u.pooled.shape[-1] if u.pooled is not None else 0, B, u.h, u.w_, u.cout_p, dc, s)
+             ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), u.cout_p, u.cout, float(self.B * u.h * u.w_), BN_MOMENTUM, BN_EPS, s)
+
+    def _fwd_post(self, u, s, hf):
+        """BatchNorm apply (+ max-pool, concat placement) of unit u on the whole batch or one half of it."""
+        if u.apply_folded:          # the only reader of the BatchNorm output is the next convolution's input transform
+            return
+        v = u.vec
+        Bl = self.B if hf is None else self.B // 2
+        pooled = self._hv(u.pooled, hf)
+        call('clamd_bn_apply', ptr(self._hv(u.y, hf)), u.cout_p, ptr(v[0]), ptr(v[1]), ptr(self._hv(u.out, hf)), u.out_ldc,
+             ptr(pooled), u.pooled.shape[-1] if u.pooled is not None else 0, Bl, u.h, u.w_, u.cout_p, self.dcode, s)
 
     # ------------------------------------------------------------------------------------------ backward
     def _wg_stream_ptr(self):

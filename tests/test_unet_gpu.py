@@ -662,6 +662,34 @@ def test_misuse_errors(C):
         assert torch.equal(big.predict(xb), torch.max(big(xb), 1)[1])
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'bf16x3'])
+def test_half_batch_forward_pipeline(C, dtype, monkeypatch):
+    """unet.HALF_BATCH: the forward pass of the wide-image levels runs as two half-batch launches per convolution (statistics
+    rows concatenated, BatchNorm still over the whole batch) so that the second half's bn_apply / input transform runs on the
+    second stream under the first half's next convolution.  Forced on for every unit here (threshold 1 pixel): the same
+    kernels on pointer offsets -> the same step up to the summation order of the statistics rows; bit-identical run after
+    run; and identical whether the second stream is used or not (per-launch timing mode keeps everything on one stream)."""
+    from continual_learning_amd import unet as U
+    monkeypatch.setattr(U, 'HALF_BATCH', False)
+    ref = _one_step(C, dtype, 6, 16, 4, 64, steps=2)
+    assert not any(u.split for u in next(iter(ref[3]._engines.values())).convs)
+    monkeypatch.setattr(U, 'HALF_BATCH', True)
+    monkeypatch.setattr(U, 'HALF_BATCH_MIN_PIXELS', 1)
+    a, a2 = _one_step(C, dtype, 6, 16, 4, 64, steps=2), _one_step(C, dtype, 6, 16, 4, 64, steps=2)
+    eng = next(iter(a[3]._engines.values()))
+    assert all(u.split for u in eng.convs) and sum(u.pipe_next for u in eng.convs) >= 9
+    assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1]) and torch.equal(a[2], a2[2])
+    assert abs(float(a[0]) - float(ref[0])) < (1e-5 if dtype != 'bf16' else 2e-3) * abs(float(ref[0]))
+    assert float((a[1] - ref[1]).norm() / ref[1].norm()) < (5e-3 if dtype != 'bf16' else 3e-2)
+    monkeypatch.setattr(U, 'KERNEL_TIMING', [])              # one-stream mode: same launches, same results
+    b = _one_step(C, dtype, 6, 16, 4, 64, steps=2)
+    monkeypatch.setattr(U, 'KERNEL_TIMING', None)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    # odd batch: no split, still works
+    c = _one_step(C, dtype, 6, 16, 3, 64, steps=1)
+    assert not any(u.split for u in next(iter(c[3]._engines.values())).convs) and bool(torch.isfinite(c[0]))
+
+
 def test_engine_buffers_are_released_with_the_model(C):
     """A model's engine (activations, gradients, workspaces: GBs at full size) must go when the model goes, by reference
     counting -- not whenever the cyclic garbage collector next runs (a trainer that rebuilds models, or begin_task2's
