@@ -62,6 +62,8 @@ SIGNATURES = {
     'clamd_conv1x1_argmax': (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_convT2x2_fwd': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_convT2x2_dgrad': (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_convT2x2_fwd_direct': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_convT2x2_dgrad_direct': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_wgrad_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
     'clamd_wgrad': (_I, [_I, _P, _I, _P, _I, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_bn_finalize': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _P]),

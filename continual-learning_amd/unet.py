@@ -47,6 +47,9 @@ PRETRANSFORM = {'0': False, 'false': False, '1': True, 'true': True}.get(str(PRE
 # BatchNorm output (the first unit of enc3/enc4/dec1/dec2/dec3): one HBM pass less per unit.  False = always run clamd_bn_apply.
 FOLD_BN_INTO_TRANSFORM = os.environ.get('CLAMD_FOLD_BN', '1') != '0'
 NARROW_DIRECT = os.environ.get('CLAMD_NARROW_DIRECT', '1') != '0'
+# fp32 path: ConvTranspose2d forward / data gradient as register-blocked GEMMs with operands loaded straight into the MFMA operand
+# registers (csrc/pw_direct.hip) instead of the LDS-staged 256-pixel x 64-channel tiles of igemm_kernel.  False = igemm_kernel.
+CONVT_DIRECT = os.environ.get('CLAMD_CONVT_DIRECT', '1') != '0'
 # Forward pass in two half-batches where a half still fills the chip (levels 0-2 at config 2): conv -> BatchNorm statistics ->
 # apply -> conv is a chain through the whole batch, so the HBM-bound passes (bn_apply, the input transforms) have nothing to run
 # beside -- unless the batch is cut in two: the second half's apply / transform runs on the second stream UNDER the first half's
@@ -437,6 +440,12 @@ class _Engine:
                 tail.y_slice = up[..., tail.cout_p:]               # second half of the concat buffer one level up
                 tail.gy_slice = self.gcat[level - 1][..., tail.cout_p:]
                 tail.y_ldc = up.shape[-1]
+                # tools/convt_direct_ab.py: the data gradient gains on every shape (0.64 -> 0.57 ms per step), the forward only where
+                # K = Cin is long (1024 / 512 channels: 0.73 -> 0.77, 0.63 -> 0.81 of the pipe); with 256 / 128 input channels the
+                # scattered pixel-shuffle stores of the short tiles cost what the loop gains
+                tail.direct = (CONVT_DIRECT and self.dcode == _lib.F32 and tail.cin_p % 128 == 0 and tail.cout_p % 32 == 0
+                               and tail.consumer is None)
+                tail.direct_f = tail.direct and tail.cin_p >= 512
             else:
                 tail.cout_p = self.Kp
                 tail.wf = torch.zeros(tail.cout_p * tail.cin_p, dtype=T, device=dev)
@@ -658,7 +667,10 @@ class _Engine:
                 continue               # encoder: the pooled output feeds the next stage's first convolution (defer may be pending)
             assert defer is None
             h, w = H >> t.level, W >> t.level
-            if t.kind == 'convT':
+            if t.kind == 'convT' and t.direct_f:
+                call('clamd_convT2x2_fwd_direct', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(t.y_slice), t.y_ldc,
+                     B, h, w, t.cin_p, t.cout_p, s)
+            elif t.kind == 'convT':
                 call('clamd_convT2x2_fwd', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(t.y_slice), t.y_ldc,
                      B, h, w, t.cin_p, t.cout_p, dc, s)
             elif predict and t.cout_p <= 64:      # arg-max fused into the head's epilogue: the logits never reach HBM
@@ -837,6 +849,9 @@ class _Engine:
                          t.cout, t.cout_p, t.cin, t.cin_p, dc, tp, sw)
                     call('clamd_channel_sum', ptr(self.dl), self.Kp, g[t.keys[1]], B * h * w, self.Kp, t.cout, dc,
                          ptr(self.ws), self.ws_bytes, tp, sw)
+                elif t.direct:
+                    call('clamd_convT2x2_dgrad_direct', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
+                         B, h, w, t.cin_p, t.cout_p, s)
                 else:
                     call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
                          ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,

@@ -179,6 +179,15 @@ int clamd_convT2x2_fwd(const void* x, int x_ldc, const void* w_packed, const flo
 int clamd_convT2x2_dgrad(const void* gy, int gy_ldc, const void* w_packed, void* gx, int gx_ldc, const void* bn_y,
                          float* bn_sums, int stat_rows, int B, int h, int w, int Cin_p, int Cout_p, int dtype, void* stream);
 
+/* The same two GEMMs on the exact-fp32 path with both operands loaded straight into the MFMA operand registers (pw_direct.hip:
+ * every wave owns a (32..128)-pixel x 128-column tile, MT + 4 buffer loads per 16 MT MFMAs, no LDS, no barrier).  Same packed
+ * weights, same results to fp32 rounding (another summation order inside 32-channel blocks).  Cin_p % 32 == 0 (forward) /
+ * Cin_p % 128 == 0 (data gradient), Cout_p % 32 == 0, activation pitches multiples of 32 channels. */
+int clamd_convT2x2_fwd_direct(const float* x, int x_ldc, const float* w_packed, const float* bias, float* y, int y_ldc, int B,
+                              int h, int w, int Cin_p, int Cout_p, void* stream);
+int clamd_convT2x2_dgrad_direct(const float* gy, int gy_ldc, const float* w_packed, float* gx, int gx_ldc, int B, int h, int w,
+                                int Cin_p, int Cout_p, void* stream);
+
 /* ---- weight gradients (wgrad.hip) --------------------------------------------------------------------------
  * out[r][c][t] = sum_pixels a[p, r] * b[nbr_t(p), c]  written in the parameter's own fp32 layout:
  *   CONV3: a = d(conv output), b = conv input  -> d weight [Cout][Cin][3][3]

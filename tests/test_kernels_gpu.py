@@ -691,6 +691,50 @@ def test_wgrad_winograd24_pretransformed(C, shape):
     assert rel_l2(outs[0].cpu().numpy(), gw2.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('shape', [(2, 128, 64, 8, 8), (1, 256, 100, 6, 10), (3, 128, 32, 5, 7), (2, 512, 256, 16, 16)],
+                         ids=lambda sh: f'{sh[0]}x{sh[1]}->{sh[2]}@{sh[3]}x{sh[4]}')
+def test_convT2x2_direct_fp32(C, shape):
+    """pw_direct.hip: nn.ConvTranspose2d(k2,s2) forward (into a concat slice) and data gradient with operands loaded straight
+    into the MFMA operand registers (every row-tile size: 32 / 64 / 128 pixels per wave, ragged pixel counts), against the oracle
+    at the fp32 bound and against igemm_kernel (same products, other summation order)."""
+    B, cin, cout, h, w_ = shape
+    rng = np.random.default_rng(14)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    cin_p, cout_p = C.ops.cpad(cin), C.ops.cpad(cout)
+    x = rnd(rng, B, cin, h, w_)
+    w = rnd(rng, cin, cout, 2, 2) * (1 / np.sqrt(cin))
+    b = rnd(rng, cout)
+    xt, wt, bt = C.ops.to_nhwc(dev(x), 0), dev(w), dev(b)
+    wf = torch.zeros(4 * cout_p * cin_p, device='cuda'); wd = torch.zeros(cin_p * 4 * cout_p, device='cuda')
+    bp = torch.zeros(cout_p, device='cuda')
+    tab = C.ops.PackTable(0); tab.convT(wt, wf, wd, cin, cout); tab.vector(bt, bp, cout); tab.finalize('cuda').run(0)
+    cat = torch.full((B, 2 * h, 2 * w_, 2 * cout_p), 3.0, device='cuda')
+    cat_old = torch.full((B, 2 * h, 2 * w_, 2 * cout_p), 3.0, device='cuda')
+    lib.call('clamd_convT2x2_fwd_direct', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(cat[..., cout_p:]), 2 * cout_p, B, h, w_, cin_p, cout_p, s)
+    lib.call('clamd_convT2x2_fwd', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(cat_old[..., cout_p:]), 2 * cout_p, B, h, w_, cin_p, cout_p, 0, s)
+    sync()
+    ref = O.convT2x2_fwd(x, w, b)
+    got = cat[..., cout_p:cout_p + cout].cpu().numpy().transpose(0, 3, 1, 2)
+    assert rel_l2(got, ref) < TOL[0]
+    assert float((cat[..., :cout_p] - 3.0).abs().max()) == 0.0                    # the other half of the concat buffer: untouched
+    assert float(cat[..., cout_p + cout:].abs().max()) == 0.0 if cout < cout_p else True   # padded channels: zero weights + zero bias
+    assert rel_l2(cat.cpu().numpy(), cat_old.cpu().numpy()) < 2e-6
+    gy = rnd(rng, B, cout, 2 * h, 2 * w_)
+    gfull = np.zeros((B, 2 * h, 2 * w_, 2 * cout_p), np.float32)
+    gfull[..., cout_p:cout_p + cout] = gy.transpose(0, 2, 3, 1)
+    gcat = dev(gfull)
+    gx = torch.full((B, h, w_, cin_p), 7.0, device='cuda')
+    gx2 = torch.full((B, h, w_, cin_p), 8.0, device='cuda')
+    for o_ in (gx, gx2):
+        lib.call('clamd_convT2x2_dgrad_direct', ptr(gcat[..., cout_p:]), 2 * cout_p, ptr(wd), ptr(o_), cin_p, B, h, w_, cin_p, cout_p, s)
+    sync()
+    assert torch.equal(gx, gx2)
+    rgx = O.convT2x2_bwd(x, w, gy)[0]
+    assert rel_l2(C.ops.from_nhwc(gx, cin, 0).cpu().numpy(), rgx) < TOL[0]
+    with pytest.raises(RuntimeError, match='Cin_p % 128'):
+        lib.call('clamd_convT2x2_dgrad_direct', ptr(gcat[..., cout_p:]), 2 * cout_p, ptr(wd), ptr(gx), 64, B, h, w_, 64, cout_p, s)
+
+
 def _random_conv_shapes(n, seed):
     """Seeded random problem sizes that hit ragged tiles, several channel slabs, K-step pairs / fours / odd counts and
     the split-K tail of every 3x3 kernel."""
