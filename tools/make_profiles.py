@@ -37,7 +37,18 @@ if sq:
         "# rocprofv3 --pmc passes (one counter set per run) of: python3 bench.py --steps 1 --warmup 1 --dtype fp32 --no-cpu-baseline --also '' --no-kernel-timing\n"
         '# per-kernel means over launches (tools/pmc_sq.py); SQ_VALU_MFMA_BUSY_CYCLES is summed over the 4 SIMDs of a CU: pipe utilisation = MFMA_BUSY / (4 x BUSY_CU)\n'
         + ''.join(sq))
-for f in ('cu_steal.jsonl', 'layers_fp32.txt', 'layers_bf16.txt', 'layers_bf16x3.txt'):
+sqb = []
+for i in (1, 2, 3):
+    d = f'{G}/{src}_sq{i}_bf16'
+    if os.path.isdir(d):
+        for sub in ('igemm', 'wgrad'):
+            sqb.append(subprocess.run([sys.executable, f'{ROOT}/tools/pmc_sq.py', d, sub], capture_output=True, text=True, check=True).stdout)
+if sqb:
+    open(f'{P}/{dst}_sq_counters_bf16.txt', 'w').write(
+        "# rocprofv3 --pmc passes (one counter set per run) of: python3 bench.py --steps 1 --warmup 1 --dtype bf16 --no-cpu-baseline --no-parity --also '' --no-kernel-timing\n"
+        '# per-kernel means over launches (tools/pmc_sq.py); MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)\n'
+        + ''.join(sqb))
+for f in ('cu_steal.jsonl', 'layers_fp32.txt', 'layers_bf16.txt', 'layers_bf16x3.txt', 'trace_gaps_fp32.txt', 'trace_gaps_bf16.txt'):
     if os.path.exists(f'{G}/{src}_{f}'):
         shutil.copy(f'{G}/{src}_{f}', f'{P}/{dst}_{f}')
 c5 = None
