@@ -366,7 +366,7 @@ class _Engine:
                 pt is True or (u.cin_p >= 256 and (u.pre_w or 2 * u.cout_p > u.cin_p)) or (u.cin_p >= 128 and u.cout_p >= 2 * u.cin_p))
             u.pre_w = u.pre_w and u.pre_f
             u.pre_d = bool(pt) and u.w24d and not first_of_net and u.cout_p >= 64 and u.cin_p % 64 == 0 and (
-                pt is True or (u.cout_p >= 256 and 2 * u.cin_p > u.cout_p))
+                pt is True or (u.cout_p >= 256 and (2 * u.cin_p > u.cout_p or (2 * u.cin_p == u.cout_p and u.cin_p >= 256))))
             u.vx = torch.empty(lib.clamd_winograd24_input_elems(B, u.h, u.w_, u.cin_p), dtype=torch.float32, device=dev) if u.pre_f else None
             # 64 input channels (8 chunks per tile): the in-kernel-transform kernel with the filters loaded straight into the operand
             # registers (wino24h_kernel) is 4-6 % faster there and 1-4 % slower on longer K loops (tools/wino24h_ab.py)
