@@ -9,12 +9,15 @@
 namespace clamd {
 
 // ------------------------------------------------------------------------------------------------
-// Fixed-order sum of partial rows [row][NK][Cp] for the 8 channels c0..c0+7 of this block (256 threads): thread
+constexpr int FIN_THREADS = 1024;
+// Fixed-order sum of partial rows [row][NK][Cp] for the 8 channels c0..c0+7 of this block (FIN_THREADS threads): thread
 // (row lane, column) adds its rows in ascending order into four interleaved fp64 chains, the row lanes are then added in
 // ascending order.  The result depends only on (nrows, data): two runs are bit-identical (no float atomics anywhere).
 template <int NK>
 __device__ inline void sum_partial_rows(const float* __restrict__ rows, int nrows, int Cp, int c0, double* red, double* out) {
-    constexpr int COLS = NK * 8, RL = 256 / COLS;
+    // FIN_THREADS threads: the row loop is a chain of dependent-latency loads and a finalize launch sits on the critical chain between
+    // two HBM-bound passes; with 256 threads the 1024 rows of a 64-channel level-0 reduction took 49 us under load
+    constexpr int COLS = NK * 8, RL = FIN_THREADS / COLS;
     const int t = threadIdx.x, col = t % COLS, rl = t / COLS;
     if (rl < RL) {
         const float* p = rows + (size_t)(col >> 3) * Cp + c0 + (col & 7);
@@ -40,11 +43,11 @@ __device__ inline void sum_partial_rows(const float* __restrict__ rows, int nrow
 // BN finalise: partial rows of (sum, sumsq) -> mean / invstd / scale / shift, running-stat update.  One block per 8 channels.
 // Reference: nn.BatchNorm2d train mode, models/unet.py:15 (momentum 0.1, eps 1e-5, unbiased running var).
 // Mean and variance are formed in fp64 from the fp64 row sums (E[x^2] - mean^2 cancels in fp32 on low-variance channels).
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ stats, int nrows, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(FIN_THREADS) bn_finalize_kernel(const float* __restrict__ stats, int nrows, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    float* scale, float* shift, float* save_mean, float* save_istd,
                                    int Cp, int C, double count, double momentum, double eps) {
-    __shared__ double red[256], tot[16];
+    __shared__ double red[FIN_THREADS], tot[16];
     const int c0 = blockIdx.x * 8;
     if (stats) sum_partial_rows<2>(stats, nrows, Cp, c0, red, tot);
     if (threadIdx.x >= 8) return;
@@ -226,11 +229,11 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
 
 // partial rows of the five sums -> k0,k1,k2 per channel, and the parameter gradients d_gamma, d_beta, d_convbias.
 // One block per 8 channels; fixed-order fp64 row sums (sum_partial_rows), coefficients formed in fp64.
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ sums, int nrows, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(FIN_THREADS) bn_bwd_finalize_kernel(const float* __restrict__ sums, int nrows, const float* __restrict__ gamma,
                                        const float* __restrict__ save_mean, const float* __restrict__ save_istd,
                                        float* k012, float* dgamma, float* dbeta, float* dbias, int Cp, int C,
                                        double count) {
-    __shared__ double red[256], tot[NSUM * 8];
+    __shared__ double red[FIN_THREADS], tot[NSUM * 8];
     const int c0 = blockIdx.x * 8;
     sum_partial_rows<NSUM>(sums, nrows, Cp, c0, red, tot);
     if (threadIdx.x >= 8) return;
@@ -345,8 +348,8 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const T* __restrict__ 
     }
 }
 
-__global__ void __launch_bounds__(256) channel_sum_final_kernel(const float* __restrict__ partial, int nrows, float* out, int Cp, int C) {
-    __shared__ double red[256], tot[8];
+__global__ void __launch_bounds__(FIN_THREADS) channel_sum_final_kernel(const float* __restrict__ partial, int nrows, float* out, int Cp, int C) {
+    __shared__ double red[FIN_THREADS], tot[8];
     const int c0 = blockIdx.x * 8;
     sum_partial_rows<1>(partial, nrows, Cp, c0, red, tot);
     if (threadIdx.x < 8 && c0 + threadIdx.x < C) out[c0 + threadIdx.x] = (float)tot[threadIdx.x];
@@ -449,7 +452,7 @@ int clamd_bn_finalize(const float* stats, int stat_rows, const float* gamma, con
                       int Cp, int C, double count, double momentum, double eps, void* stream) {
     if (Cp <= 0 || Cp % 8 || C > Cp) return clamd_fail("bn_finalize: bad channel counts");
     if (stats && stat_rows <= 0) return clamd_fail("bn_finalize: stat_rows must be the row count the producing launch wrote");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(Cp / 8), dim3(256), 0, (hipStream_t)stream, stats, stat_rows, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(Cp / 8), dim3(FIN_THREADS), 0, (hipStream_t)stream, stats, stat_rows, gamma,
                        beta, running_mean, running_var, scale, shift, save_mean, save_istd, Cp, C, count, momentum, eps);
     return clamd_check_launch("bn_finalize");
 }
@@ -502,7 +505,7 @@ int clamd_bn_bwd_finalize(const float* sums, int sum_rows, const float* gamma, c
                           void* stream) {
     if (Cp <= 0 || Cp % 8 || C > Cp) return clamd_fail("bn_bwd_finalize: bad channel counts");
     if (sum_rows <= 0) return clamd_fail("bn_bwd_finalize: sum_rows must be the row count the producing launch wrote");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(Cp / 8), dim3(256), 0, (hipStream_t)stream, sums, sum_rows,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(Cp / 8), dim3(FIN_THREADS), 0, (hipStream_t)stream, sums, sum_rows,
                        gamma, save_mean, save_istd, k012, dgamma, dbeta, dbias, Cp, C, count);
     return clamd_check_launch("bn_bwd_finalize");
 }
@@ -551,7 +554,7 @@ int clamd_channel_sum(const void* g, int ldc, float* out, long long npix, int Cp
     else if (dtype == CLAMD_SPLIT)
         hipLaunchKernelGGL(channel_sum_kernel<split_t>, gr, b, 0, s, (const split_t*)g, ldc, workspace, npix, Cp);
     else return clamd_fail("channel_sum: bad dtype");
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(Cp / 8), b, 0, s, workspace, (int)gb, out, Cp, C);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(Cp / 8), dim3(FIN_THREADS), 0, s, workspace, (int)gb, out, Cp, C);
     return clamd_check_launch("channel_sum");
 }
 
