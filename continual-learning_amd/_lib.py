@@ -88,8 +88,8 @@ SIGNATURES = {
     'clamd_conv3x3_winograd24': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_winograd24_input_elems': (_SZ, [_I, _I, _I, _I]),
     'clamd_winograd24_transform_input': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
-    'clamd_conv3x3_winograd24_pre': (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    'clamd_conv3x3_winograd24_direct_filters': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'clamd_conv3x3_winograd24_pre': (_I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'clamd_conv3x3_winograd24_direct_filters': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_wgrad_winograd24_pre_operand_elems': (_SZ, [_I, _I, _I, _I]),
     'clamd_wgrad_winograd24_pre_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I]),
     'clamd_wgrad_winograd24_pre': (_I, [_P, _I, _P, _P, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),

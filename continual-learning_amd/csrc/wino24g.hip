@@ -138,9 +138,70 @@ __global__ void __launch_bounds__(256) wino24_xform_kernel(const W24XformParams 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel on the transformed input
 // ---------------------------------------------------------------------------------------------------------------------
+// The five per-channel sums of the fused ReLU / BatchNorm backward (elementwise.hip, bn_bwd_reduce_kernel) taken in the epilogue of the
+// data-gradient launch that PRODUCES the gradient g_u: s0 = sum g_u, s1 = sum g_u y, s2 = sum g_u [y > 0], s3 = sum [y > 0], s4 = sum y.
+// The separate reduce pass reads g_u and y again from HBM (107 us per 64-channel 256 x 256 unit, on the critical chain of the backward
+// pass); here y is prefetched under the accumulator exchange and g_u is in registers.  Partial rows exactly like the statistics rows
+// of the forward launches (per workgroup of the persistent grid, registers across the tiles of one slab): fixed order, bit-reproducible.
+struct W24Sums {
+    float v[5][2][4];
+    __device__ inline void clear() {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[k][i >> 2][i & 3] = 0.f;
+    }
+    __device__ inline void add1(int nt, int c, float g, float y) {
+        const float m = y > 0.f ? 1.f : 0.f;
+        v[0][nt][c] += g;
+        v[1][nt][c] = fmaf(g, y, v[1][nt][c]);
+        v[2][nt][c] = fmaf(g, m, v[2][nt][c]);
+        v[3][nt][c] += m;
+        v[4][nt][c] += y;
+    }
+    __device__ inline void add(int nt, const float4& g, const float4& y) {
+        add1(nt, 0, g.x, y.x); add1(nt, 1, g.y, y.y); add1(nt, 2, g.z, y.z); add1(nt, 3, g.w, y.w);
+    }
+    // every thread of the workgroup; LDS free.  Threads with equal (tid & 7) own the same channels: fold the 8 tiles of a wave (lane
+    // bits 3-5), then the four waves through LDS; word (kind, channel) of the row is owned by ONE thread for the whole launch.
+    __device__ inline void fold(float* sb, float* rows, bool per_wg, int slab, int tile, int Np) {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float a = v[k][nt][c];
+                    a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+                    if (lane < 8) sb[(w * 5 + k) * 64 + 32 * nt + 4 * lane + c] = a;
+                    v[k][nt][c] = 0.f;
+                }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 320; idx += 256) {
+            const int k = idx >> 6, c = idx & 63;
+            if (slab * 64 + c >= Np) continue;
+            const float t = (sb[(0 * 5 + k) * 64 + c] + sb[(1 * 5 + k) * 64 + c]) + (sb[(2 * 5 + k) * 64 + c] + sb[(3 * 5 + k) * 64 + c]);
+            if (!per_wg) rows[((size_t)tile * 5 + k) * Np + slab * 64 + c] = t;                       // row = pixel tile, written once
+            else {
+                float* dst = rows + ((size_t)blockIdx.x * 5 + k) * Np + slab * 64 + c;
+                // this thread's own earlier store to the word (zero fill or an earlier fold) must have reached L2: drain, read from L2
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const float old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst, old + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
+    __device__ static inline void zero_rows(float* rows, int Np) {        // per-workgroup rows of the persistent grid: the owners zero their words
+        for (int idx = threadIdx.x; idx < 320; idx += 256)
+            for (int n = idx & 63; n < Np; n += 64) rows[((size_t)blockIdx.x * 5 + (idx >> 6)) * Np + n] = 0.f;
+    }
+};
+
 constexpr int W24G_EXP = 36;                                  // row pitch (floats) of the epilogue exchange block
 
-template <int TXN, bool RAGGED, int NSET>
+template <int TXN, bool RAGGED, int NSET, bool SUMS>
 __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
     constexpr int TYN = 32 / TXN;
     constexpr int PW = 4 * TXN, PH = 2 * TYN;
@@ -168,6 +229,14 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) { st1[i >> 2][i & 3] = 0.f; st2[i >> 2][i & 3] = 0.f; }
     int cur_tn = -1, cur_tm = 0;
+    // fused BatchNorm-backward sums of a data-gradient launch (SUMS): rows like the statistics rows
+    const bool sums_per_wg = SUMS && gridDim.x < (unsigned)p.nblk;
+    W24Sums bsum;
+    int sum_tn = -1, sum_tm = 0;
+    if constexpr (SUMS) {
+        bsum.clear();
+        if (sums_per_wg) W24Sums::zero_rows(p.bn_sums, p.Np);
+    }
     auto fold_stats = [&]() {
         float* sb = reinterpret_cast<float*>(smem);                            // [wave][2][64]
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -223,7 +292,9 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
         decode(v, tn, tm);
         const int x0 = (tm % tiles_x) * PW, y0 = ((tm / tiles_x) % tiles_y) * PH, b = tm / (tiles_x * tiles_y);
         const int n0 = tn * 64;
-        if (cur_tn >= 0 && (tn != cur_tn || !per_wg_rows)) fold_stats();      // workgroup-uniform
+        if (cur_tn >= 0 && (tn != cur_tn || !per_wg_rows)) fold_stats();
+        if constexpr (SUMS)
+            if (sum_tn >= 0 && (tn != sum_tn || !sums_per_wg)) { bsum.fold(reinterpret_cast<float*>(smem), p.bn_sums, sums_per_wg, sum_tn, sum_tm, p.Np); sum_tn = -1; }      // workgroup-uniform
 
         // the tile after this one (the load stream does not stop at a tile boundary)
         const int vn = v + (int)gridDim.x;
@@ -293,8 +364,25 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
         }
 
         // ---- epilogue: wino24_kernel's.  Y = A4^T M A6: A6^T in-lane (j -> q), A4^T across the four waves through LDS ----------
-        float* const ex = reinterpret_cast<float*>(smem);
         const int tl = tid >> 3, ng = tid & 7;                                // reader: tile, 4-channel group
+        // SUMS: the saved activation at this thread's output positions, one output-channel half (8 x 16 bytes) at a time: the first half
+        // is requested here and lands under the accumulator exchange, the second under the read-back of the first
+        float4 yv[SUMS ? 8 : 1];
+        auto load_y = [&](int nt) {
+            if constexpr (SUMS) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const int yy = y0 + 2 * (tl / TXN) + pp, xx = x0 + 4 * (tl % TXN) + q;
+                        const bool ok = !RAGGED || (yy < p.H && xx < p.W);
+                        yv[q * 2 + pp] = ok ? *reinterpret_cast<const float4*>(p.bn_y + (((size_t)b * p.H + yy) * p.W + xx) * p.Np + n0 + 32 * nt + 4 * ng)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+            }
+        };
+        load_y(0);
+        float* const ex = reinterpret_cast<float*>(smem);                                // reader: tile, 4-channel group
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();
         const bool plain = !p.relu && !p.bias && !p.stats;
 #pragma unroll
@@ -342,6 +430,7 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
                     const int yy = y0 + 2 * oty + pp, xx = x0 + 4 * otx + q;
                     if (!RAGGED || (yy < p.H && xx < p.W)) {
                         *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = o;
+                        if constexpr (SUMS) bsum.add(nt, o, yv[q * 2 + pp]);
                         if (!plain) {
                             st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
                             st2[nt][0] = fmaf(o.x, o.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, o.y, st2[nt][1]);
@@ -350,11 +439,15 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
                     }
                 }
             }
+            if constexpr (SUMS) { if (nt == 0) load_y(1); }
         }
         if (p.stats) { cur_tn = tn; cur_tm = tm; }
+        if constexpr (SUMS) { sum_tn = tn; sum_tm = tm; }
         __syncthreads();                                                   // exchange / statistics blocks are free again
     }
     if (cur_tn >= 0) fold_stats();
+    if constexpr (SUMS)
+        if (sum_tn >= 0) bsum.fold(reinterpret_cast<float*>(smem), p.bn_sums, sums_per_wg, sum_tn, sum_tm, p.Np);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -367,7 +460,7 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
 // input alternates between two register sets (no copies), the filter sets are refilled two chunks ahead behind their MFMAs and the
 // stream runs on into the next tile.  Same V formulas, same MFMA chains, same epilogue: bit-identical to wino24_kernel.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TXN, bool RAGGED>
+template <int TXN, bool RAGGED, bool SUMS>
 __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
     constexpr int TYN = 32 / TXN;
     constexpr int PW = 4 * TXN, PH = 2 * TYN;
@@ -398,6 +491,14 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) { st1[i >> 2][i & 3] = 0.f; st2[i >> 2][i & 3] = 0.f; }
     int cur_tn = -1, cur_tm = 0;
+    // fused BatchNorm-backward sums of a data-gradient launch (SUMS): rows like the statistics rows
+    const bool sums_per_wg = SUMS && gridDim.x < (unsigned)p.nblk;
+    W24Sums bsum;
+    int sum_tn = -1, sum_tm = 0;
+    if constexpr (SUMS) {
+        bsum.clear();
+        if (sums_per_wg) W24Sums::zero_rows(p.bn_sums, p.Np);
+    }
     auto fold_stats = [&]() {
         float* sb = reinterpret_cast<float*>(smem);
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -456,6 +557,8 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
         const int x0 = (tm % tiles_x) * PW, y0 = ((tm / tiles_x) % tiles_y) * PH, b = tm / (tiles_x * tiles_y);
         const int n0 = tn * 64;
         if (cur_tn >= 0 && (tn != cur_tn || !per_wg_rows)) fold_stats();
+        if constexpr (SUMS)
+            if (sum_tn >= 0 && (tn != sum_tn || !sums_per_wg)) { bsum.fold(reinterpret_cast<float*>(smem), p.bn_sums, sums_per_wg, sum_tn, sum_tm, p.Np); sum_tn = -1; }
 
         const int vn = v + (int)gridDim.x;
         const bool has_next = vn < p.nblk;
@@ -590,8 +693,25 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
         }
 
         // ---- epilogue: wino24_kernel's -----------------------------------------------------------------------------------------
+        const int tl = tid >> 3, ng = tid & 7;                                // reader: tile, 4-channel group
+        // SUMS: the saved activation at this thread's output positions, one output-channel half (8 x 16 bytes) at a time: the first half
+        // is requested here and lands under the accumulator exchange, the second under the read-back of the first
+        float4 yv[SUMS ? 8 : 1];
+        auto load_y = [&](int nt) {
+            if constexpr (SUMS) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const int yy = y0 + 2 * (tl / TXN) + pp, xx = x0 + 4 * (tl % TXN) + q;
+                        const bool ok = !RAGGED || (yy < p.H && xx < p.W);
+                        yv[q * 2 + pp] = ok ? *reinterpret_cast<const float4*>(p.bn_y + (((size_t)b * p.H + yy) * p.W + xx) * p.Np + n0 + 32 * nt + 4 * ng)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+            }
+        };
+        load_y(0);
         float* const ex = reinterpret_cast<float*>(smem);
-        const int tl = tid >> 3, ng = tid & 7;
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();
         const bool plain = !p.relu && !p.bias && !p.stats;
 #pragma unroll
@@ -639,6 +759,7 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
                     const int yy = y0 + 2 * oty + pp, xx = x0 + 4 * otx + q;
                     if (!RAGGED || (yy < p.H && xx < p.W)) {
                         *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = o;
+                        if constexpr (SUMS) bsum.add(nt, o, yv[q * 2 + pp]);
                         if (!plain) {
                             st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
                             st2[nt][0] = fmaf(o.x, o.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, o.y, st2[nt][1]);
@@ -647,11 +768,15 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
                     }
                 }
             }
+            if constexpr (SUMS) { if (nt == 0) load_y(1); }
         }
         if (p.stats) { cur_tn = tn; cur_tm = tm; }
+        if constexpr (SUMS) { sum_tn = tn; sum_tm = tm; }
         __syncthreads();                                                   // exchange / statistics blocks are free again
     }
     if (cur_tn >= 0) fold_stats();
+    if constexpr (SUMS)
+        if (sum_tn >= 0) bsum.fold(reinterpret_cast<float*>(smem), p.bn_sums, sums_per_wg, sum_tn, sum_tm, p.Np);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -947,8 +1072,9 @@ int clamd_winograd24_transform_input(const float* x, int x_ldc, const float* sca
 }
 
 int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const float* bias, float* y, int y_ldc,
-                                 float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
-                                 const clamd_tuning* tune, void* stream) {
+                                 float* stats, int stat_rows, const float* bn_y, float* bn_sums, int B, int H, int W, int Cin_p,
+                                 int Cout_p, int relu, const clamd_tuning* tune, void* stream) {
+    if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("conv3x3_winograd24_pre: bn_y and bn_sums go together");
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("conv3x3_winograd24_pre: empty problem");
     if ((H & 1) || (W & 3)) return clamd_fail("conv3x3_winograd24_pre: H must be even and W a multiple of 4 (2x4 output tiles)");
     if (Cin_p % 32 || Cin_p < 64 || Cout_p % 64 || y_ldc % 8) return clamd_fail("conv3x3_winograd24_pre: needs Cin_p % 32 == 0, Cin_p >= 64, Cout_p % 64 == 0");
@@ -958,9 +1084,10 @@ int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const floa
     if (tiles * ntn > 0x7fffffff) return clamd_fail("conv3x3_winograd24_pre: grid out of range");
     if ((unsigned long long)tiles * (Cin_p / 8) * 24 * 1024 >= (1ull << 32) || (long long)24 * Cout_p * Cin_p * 4 >= (1ll << 31))
         return clamd_fail("conv3x3_winograd24_pre: transformed input exceeds 2^32 bytes or filter 2^31 bytes");
-    if (stats && stat_rows != clamd_winograd24_stat_rows(B, H, W, Cout_p, tn))
+    if ((stats || bn_sums) && stat_rows != clamd_winograd24_stat_rows(B, H, W, Cout_p, tn))
         return clamd_fail("conv3x3_winograd24_pre: stat_rows does not match clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD24, ...)");
     WinoParams p{v, 0, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 1, 0};
+    p.bn_y = bn_y; p.bn_sums = bn_sums;
     p.band = wino_band(tiles, ntn, 3.0 * B * H * W * Cin_p, 24.0 * Cin_p * Cout_p, tn.wino_band);
     p.nblk = (int)(tiles * ntn);
     const unsigned grid = tn.wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_usable_cus(tn)) : (unsigned)p.nblk;
@@ -968,7 +1095,11 @@ int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const floa
     w24g_tile(W, ph, pw);
     const bool ragged = (H % ph) != 0 || (W % pw) != 0;
     hipStream_t s = (hipStream_t)stream;
-#define W24G_LAUNCH(TXN_, RG_) hipLaunchKernelGGL((wino24g_kernel<TXN_, RG_, 2>), dim3(grid), dim3(256), 0, s, p)
+#define W24G_LAUNCH(TXN_, RG_)                                                                                         \
+    do {                                                                                                               \
+        if (bn_sums) hipLaunchKernelGGL((wino24g_kernel<TXN_, RG_, 2, true>), dim3(grid), dim3(256), 0, s, p);         \
+        else hipLaunchKernelGGL((wino24g_kernel<TXN_, RG_, 2, false>), dim3(grid), dim3(256), 0, s, p);                \
+    } while (0)
     if (pw == 32) { if (ragged) W24G_LAUNCH(8, true); else W24G_LAUNCH(8, false); }
     else { if (ragged) W24G_LAUNCH(4, true); else W24G_LAUNCH(4, false); }
 #undef W24G_LAUNCH
@@ -976,8 +1107,9 @@ int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const floa
 }
 
 int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
-                                            float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
-                                            const clamd_tuning* tune, void* stream) {
+                                            float* stats, int stat_rows, const float* bn_y, float* bn_sums, int B, int H, int W,
+                                            int Cin_p, int Cout_p, int relu, const clamd_tuning* tune, void* stream) {
+    if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("conv3x3_winograd24_direct_filters: bn_y and bn_sums go together");
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("conv3x3_winograd24_direct_filters: empty problem");
     if ((H & 1) || (W & 3)) return clamd_fail("conv3x3_winograd24_direct_filters: H must be even and W a multiple of 4 (2x4 output tiles)");
     if (Cin_p % 32 || Cout_p % 64 || x_ldc % 8 || y_ldc % 8) return clamd_fail("conv3x3_winograd24_direct_filters: needs Cin_p % 32 == 0, Cout_p % 64 == 0");
@@ -987,9 +1119,10 @@ int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const flo
     const clamd_tuning& tn = clamd_tune(tune);
     const long long tiles = w24g_tiles(B, H, W), ntn = Cout_p / 64;
     if (tiles * ntn > 0x7fffffff) return clamd_fail("conv3x3_winograd24_direct_filters: grid out of range");
-    if (stats && stat_rows != clamd_winograd24_stat_rows(B, H, W, Cout_p, tn))
+    if ((stats || bn_sums) && stat_rows != clamd_winograd24_stat_rows(B, H, W, Cout_p, tn))
         return clamd_fail("conv3x3_winograd24_direct_filters: stat_rows does not match clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD24, ...)");
     WinoParams p{x, x_ldc, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 1, 0};
+    p.bn_y = bn_y; p.bn_sums = bn_sums;
     p.band = wino_band(tiles, ntn, (double)B * H * W * Cin_p, 24.0 * Cin_p * Cout_p, tn.wino_band);
     p.nblk = (int)(tiles * ntn);
     const unsigned grid = tn.wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_usable_cus(tn)) : (unsigned)p.nblk;
@@ -997,7 +1130,11 @@ int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const flo
     w24g_tile(W, ph, pw);
     const bool ragged = (H % ph) != 0 || (W % pw) != 0;
     hipStream_t s = (hipStream_t)stream;
-#define W24H_LAUNCH(TXN_, RG_) hipLaunchKernelGGL((wino24h_kernel<TXN_, RG_>), dim3(grid), dim3(256), 0, s, p)
+#define W24H_LAUNCH(TXN_, RG_)                                                                                         \
+    do {                                                                                                               \
+        if (bn_sums) hipLaunchKernelGGL((wino24h_kernel<TXN_, RG_, true>), dim3(grid), dim3(256), 0, s, p);            \
+        else hipLaunchKernelGGL((wino24h_kernel<TXN_, RG_, false>), dim3(grid), dim3(256), 0, s, p);                   \
+    } while (0)
     if (pw == 32) { if (ragged) W24H_LAUNCH(8, true); else W24H_LAUNCH(8, false); }
     else { if (ragged) W24H_LAUNCH(4, true); else W24H_LAUNCH(4, false); }
 #undef W24H_LAUNCH

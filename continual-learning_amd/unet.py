@@ -50,6 +50,12 @@ NARROW_DIRECT = os.environ.get('CLAMD_NARROW_DIRECT', '1') != '0'
 # fp32 path: ConvTranspose2d forward / data gradient as register-blocked GEMMs with operands loaded straight into the MFMA operand
 # registers (csrc/pw_direct.hip) instead of the LDS-staged 256-pixel x 64-channel tiles of igemm_kernel.  False = igemm_kernel.
 CONVT_DIRECT = os.environ.get('CLAMD_CONVT_DIRECT', '1') != '0'
+# fp32 path: the five BatchNorm-backward sums of the first unit of a stage taken in the epilogue of the Winograd data-gradient launch that
+# produces its gradient (wino24g.hip: pre-transformed and direct-filter kernels) instead of the separate bn_bwd_reduce pass.
+# BUILT, MEASURED, OFF BY DEFAULT: tools/step_ab.py fp32 FUSE_WINO_SUMS False True -> 21.19 vs 21.22 ms per step.  The 40 running sums
+# live across the K loop of kernels that already use all 512 registers (45 / 77 registers spill around the loop, none inside it), and the
+# reduce passes they replace mostly ran beside a weight-gradient kernel of the second stream anyway.
+FUSE_WINO_SUMS = os.environ.get('CLAMD_FUSE_WINO_SUMS', '0') != '0'
 # Forward pass in two half-batches where a half still fills the chip (levels 0-2 at config 2): conv -> BatchNorm statistics ->
 # apply -> conv is a chain through the whole batch, so the HBM-bound passes (bn_apply, the input transforms) have nothing to run
 # beside -- unless the batch is cut in two: the second half's apply / transform runs on the second stream UNDER the first half's
@@ -533,7 +539,10 @@ class _Engine:
                 src = getattr(u, 'sum_src', None)
                 if src is None:       # the 3x3 data-gradient launch of the next conv of this stage (K = its output channels)
                     b = next(c for c in self.convs if c.consumer is u)
-                    u.sum_rows = rows(_lib.OP_CONV3X3, B, b.h, b.w_, b.cout_p, b.cin_p, dc, fused_bn=True, tuning=tn)
+                    if b.wino:
+                        u.sum_rows = rows(_lib.OP_CONV3X3_WINOGRAD24, B, b.h, b.w_, b.cout_p, b.cin_p, dc, tuning=tn)
+                    else:
+                        u.sum_rows = rows(_lib.OP_CONV3X3, B, b.h, b.w_, b.cout_p, b.cin_p, dc, fused_bn=True, tuning=tn)
                 elif src.kind == 'head':
                     u.sum_rows = rows(_lib.OP_CONV1X1, B, u.h, u.w_, src.cout_p, src.cin_p, dc, fused_bn=True)
                 else:                 # ConvTranspose2d data gradient: the launch runs on the convT INPUT grid (= this unit's)
@@ -771,11 +780,12 @@ class _Engine:
                 n = u.vx.numel() // 2
                 vx = u.vx if hf is None else u.vx[hf * n:(hf + 1) * n]
                 _timed('igemm_conv3x3', flops, nbytes, 'clamd_conv3x3_winograd24_pre', ptr(vx), ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p,
-                       ptr(st), rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
+                       ptr(st), rows, None, None, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
             else:
-                _timed('igemm_conv3x3', flops, nbytes,
-                       ('clamd_conv3x3_winograd24_direct_filters' if u.direct_f else 'clamd_conv3x3_winograd24') if u.w24 else 'clamd_conv3x3_winograd',
-                       ptr(xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p, ptr(st), rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
+                name = ('clamd_conv3x3_winograd24_direct_filters' if u.direct_f else 'clamd_conv3x3_winograd24') if u.w24 else 'clamd_conv3x3_winograd'
+                extra = (None, None) if u.direct_f else ()           # bn_y, bn_sums: data-gradient launches only
+                _timed('igemm_conv3x3', flops, nbytes, name, ptr(xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p, ptr(st), rows,
+                       *extra, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
         else:
             _timed('igemm_conv3x3', flops, nbytes, 'clamd_conv3x3', ptr(xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p,
                    ptr(st), None, None, rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, u.m_fastest, dc, tp, s)
@@ -874,8 +884,8 @@ class _Engine:
     def _fuse_sums(self, b):
         """Does the data-gradient launch of conv `b` (3x3, K = b.cout_p gradient channels) also reduce the BN-backward sums
         of the unit in front of it?"""
-        if b.wino:                     # the Winograd data-gradient kernel has no BatchNorm-sums epilogue
-            return False
+        if b.wino:                     # Winograd data gradient: only the wino24g.hip kernels have the BatchNorm-sums epilogue
+            return bool(FUSE_WINO_SUMS) and (b.pre_d or b.direct_d)
         if FUSE_BN_SUMS == 'auto':     # persistent bf16 kernel: <= 256 input channels, K-steps in pairs (64 channels)
             return self.dcode == _lib.BF16 and b.cout_p <= 256 and b.cout_p % 64 == 0
         return bool(FUSE_BN_SUMS)
@@ -904,12 +914,18 @@ class _Engine:
                 _timed('wino_transform', 0.0, 16 * B * u.h * u.w_ * u.cout_p,      # reads the gradient once, writes 3x its size
                        'clamd_winograd24_transform_input', ptr(u.gz), u.cout_p, None, None, ptr(self.vg), B, u.h, u.w_, u.cout_p, s)
                 _timed('igemm_conv3x3', flops, self._conv_bytes(u),
-                       'clamd_conv3x3_winograd24_pre', ptr(self.vg), ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
+                       'clamd_conv3x3_winograd24_pre', ptr(self.vg), ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
+                       u.consumer.sum_rows if u.consumer is not None else 0,
+                       ptr(u.consumer.y) if u.consumer is not None else None, ptr(u.consumer.sums) if u.consumer is not None else None,
                        B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
             elif u.g_in is not None and u.wino:
                 _timed('igemm_conv3x3', flops, self._conv_bytes(u),
-                       ('clamd_conv3x3_winograd24_direct_filters' if u.direct_d else 'clamd_conv3x3_winograd24') if u.w24d else 'clamd_conv3x3_winograd',
-                       ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
+                       *((('clamd_conv3x3_winograd24_direct_filters', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
+                           u.consumer.sum_rows if u.consumer is not None else 0,
+                           ptr(u.consumer.y) if u.consumer is not None else None, ptr(u.consumer.sums) if u.consumer is not None else None)
+                          if u.direct_d else
+                          ('clamd_conv3x3_winograd24' if u.w24d else 'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in),
+                           u.g_in.shape[-1], None, 0))),
                        B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
             elif u.g_in is not None:
                 _timed('igemm_conv3x3', flops, self._conv_bytes(u),

@@ -127,20 +127,24 @@ int clamd_wgrad_winograd24(const float* gz, int gz_ldc, const float* x, int x_ld
  * scale / shift (optional, [Cp] each): the transform reads x * scale + shift instead of x -- the nn.BatchNorm2d in front of the
  * convolution (models/unet.py:15-16,30-31: clamd_bn_finalize's scale / shift on the producer's conv+ReLU output) folded into
  * the load, with the zero padding applied AFTER the affine as nn.Conv2d does; the clamd_bn_apply pass of that unit is then not
- * needed when nothing else reads its output. */
+ * needed when nothing else reads its output.
+ * bn_y / bn_sums (optional, data-gradient launches, also of clamd_conv3x3_winograd24_direct_filters): as for clamd_conv3x3 -- when y of
+ * this launch is the gradient w.r.t. a BatchNorm output, the five per-channel sums of clamd_bn_bwd_reduce are accumulated in the
+ * epilogue (bn_y = that unit's saved activation [B,H,W,Cout_p], dense; bn_sums = [stat_rows][5][Cout_p]) and the separate
+ * reduce pass over the gradient and the activation is not needed. */
 size_t clamd_winograd24_input_elems(int B, int H, int W, int Cp);
 int clamd_winograd24_transform_input(const float* x, int x_ldc, const float* scale, const float* shift, float* v, int B, int H, int W,
                                      int Cp, void* stream);
 int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const float* bias, float* y, int y_ldc,
-                                 float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
-                                 const clamd_tuning* tune, void* stream);
+                                 float* stats, int stat_rows, const float* bn_y, float* bn_sums, int B, int H, int W, int Cin_p,
+                                 int Cout_p, int relu, const clamd_tuning* tune, void* stream);
 /* The narrow layers (64 / 128 channels, levels 0-1 of models/unet.py:49-72, where 3x the activation bytes through HBM would
  * cost more than the in-kernel transform): clamd_conv3x3_winograd24 with the FILTER fragments loaded straight into the MFMA
  * operand registers instead of being staged through LDS (wino24h_kernel, wino24g.hip).  Same arguments, same packed filters,
  * bit-identical results and statistics rows; needs Cout_p % 64 == 0 and Cin_p % 32 == 0. */
 int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
-                                            float* stats, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p, int relu,
-                                            const clamd_tuning* tune, void* stream);
+                                            float* stats, int stat_rows, const float* bn_y, float* bn_sums, int B, int H, int W,
+                                            int Cin_p, int Cout_p, int relu, const clamd_tuning* tune, void* stream);
 /* Weight gradient of the same convolution as a batched GEMM over the 24 Winograd planes (K = tiles) on operands transformed
  * once: v = the forward image of the convolution INPUT (clamd_winograd24_transform_input, kept from the forward pass: it is
  * read in place as the x-side operand), yt = caller-provided scratch of clamd_wgrad_winograd24_pre_operand_elems(B,H,W,Rp)

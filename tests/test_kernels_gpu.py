@@ -586,7 +586,7 @@ def test_conv3x3_winograd24_pretransformed(C, shape):
         lib.call('clamd_conv3x3_winograd24', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), rows, B, H, W, cin_p, cout_p, 1, tp, s)
         v = torch.full((L.clamd_winograd24_input_elems(B, H, W, cin_p),), float('nan'), device='cuda')
         lib.call('clamd_winograd24_transform_input', ptr(xt), cin_p, None, None, ptr(v), B, H, W, cin_p, s)
-        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), cout_p, ptr(stats_p), rows, B, H, W, cin_p, cout_p, 1, tp, s)
+        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), cout_p, ptr(stats_p), rows, None, None, B, H, W, cin_p, cout_p, 1, tp, s)
         sync()
         assert not bool(torch.isnan(v).any()), 'the transform must write every element of V'
         assert torch.equal(y, y_p)
@@ -597,7 +597,7 @@ def test_conv3x3_winograd24_pretransformed(C, shape):
         if tn is not None and (tn.wino_band == 1 or tn.wino_persist == 0):
             assert torch.equal(stats, stats_p)
         stats_q = torch.full_like(stats, float('nan'))
-        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), cout_p, ptr(stats_q), rows, B, H, W, cin_p, cout_p, 1, tp, s)
+        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), cout_p, ptr(stats_q), rows, None, None, B, H, W, cin_p, cout_p, 1, tp, s)
         sync()
         assert torch.equal(stats_p, stats_q), 'statistics rows differ between two identical launches'
         assert rel_l2(C.ops.from_nhwc(y_p, cout, 0).cpu().numpy(), ref) < TOL[0]
@@ -607,7 +607,7 @@ def test_conv3x3_winograd24_pretransformed(C, shape):
         lib.call('clamd_conv3x3_winograd24', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, 0, B, H, W, cout_p, cin_p, 0, tp, s)
         vg = torch.empty(L.clamd_winograd24_input_elems(B, H, W, cout_p), device='cuda')
         lib.call('clamd_winograd24_transform_input', ptr(gzt), cout_p, None, None, ptr(vg), B, H, W, cout_p, s)
-        lib.call('clamd_conv3x3_winograd24_pre', ptr(vg), ptr(wd), None, ptr(gx_p), cin_p, None, 0, B, H, W, cout_p, cin_p, 0, tp, s)
+        lib.call('clamd_conv3x3_winograd24_pre', ptr(vg), ptr(wd), None, ptr(gx_p), cin_p, None, 0, None, None, B, H, W, cout_p, cin_p, 0, tp, s)
         sync()
         assert torch.equal(gx, gx_p)
         got_gx = gx_p.cpu().numpy().transpose(0, 3, 1, 2)
@@ -615,13 +615,32 @@ def test_conv3x3_winograd24_pretransformed(C, shape):
         # the narrow-layer variant: in-kernel transform, filters straight into the operand registers -- bit-identical as well
         y_h = torch.full((B, H, W, cout_p), 9.0, device='cuda')
         stats_h = torch.full_like(stats, float('nan'))
-        lib.call('clamd_conv3x3_winograd24_direct_filters', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y_h), cout_p, ptr(stats_h), rows, B, H, W,
-                 cin_p, cout_p, 1, tp, s)
+        lib.call('clamd_conv3x3_winograd24_direct_filters', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y_h), cout_p, ptr(stats_h), rows, None, None,
+                 B, H, W, cin_p, cout_p, 1, tp, s)
         gx_h = torch.full((B, H, W, cin_p), 5.0, device='cuda')
-        lib.call('clamd_conv3x3_winograd24_direct_filters', ptr(gzt), cout_p, ptr(wd), None, ptr(gx_h), cin_p, None, 0, B, H, W, cout_p, cin_p,
-                 0, tp, s)
+        lib.call('clamd_conv3x3_winograd24_direct_filters', ptr(gzt), cout_p, ptr(wd), None, ptr(gx_h), cin_p, None, 0, None, None, B, H, W,
+                 cout_p, cin_p, 0, tp, s)
         sync()
         assert torch.equal(y, y_h) and torch.equal(gx, gx_h)
+        # the five BatchNorm-backward sums of the unit in front, taken in the epilogue of the data-gradient launch (both kernels): the
+        # gradient itself unchanged, the sums equal to the stand-alone clamd_bn_bwd_reduce pass (other partial rows, same totals)
+        if cin_p % 64 == 0:
+            ya = torch.relu(torch.randn(B, H, W, cin_p, device='cuda'))             # the consumer's saved post-ReLU activation
+            sc, sh = torch.rand(cin_p, device='cuda') + 0.5, torch.randn(cin_p, device='cuda')
+            rrows = lib.stat_rows(lib.OP_BN_BWD_REDUCE, B, H, W, 0, cin_p, 0, tuning=tn)
+            ref_sums = torch.full((rrows, 5, cin_p), float('nan'), device='cuda')
+            lib.call('clamd_bn_bwd_reduce', ptr(gx), cin_p, None, 0, ptr(ya), cin_p, ptr(sc), ptr(sh), ptr(ref_sums), rrows, B, H, W, cin_p, 0, tp, s)
+            srows = lib.stat_rows(lib.OP_CONV3X3_WINOGRAD24, B, H, W, cout_p, cin_p, 0, tuning=tn)
+            for name, a0, a1 in (('clamd_conv3x3_winograd24_pre', (ptr(vg),), ()), ('clamd_conv3x3_winograd24_direct_filters', (ptr(gzt), cout_p), ())):
+                gx_s = torch.full((B, H, W, cin_p), 6.0, device='cuda')
+                sums, sums2 = (torch.full((srows, 5, cin_p), float('nan'), device='cuda') for _ in range(2))
+                for sm_ in (sums, sums2):
+                    lib.call(name, *a0, ptr(wd), None, ptr(gx_s), cin_p, None, srows, ptr(ya), ptr(sm_), B, H, W, cout_p, cin_p, 0, tp, s)
+                sync()
+                assert torch.equal(gx_s, gx), name
+                assert torch.equal(sums, sums2), f'{name}: the sums rows differ between two identical launches'
+                got, want = sums.double().sum(0).cpu().numpy(), ref_sums.double().sum(0).cpu().numpy()
+                np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-3 * float(np.abs(want).max() ** 0.5 + 1))
         assert torch.equal(stats, stats_h), 'same block order as clamd_conv3x3_winograd24: identical rows'
     # BatchNorm folded into the transform: V(raw * scale + shift, zero padding AFTER the affine) == V of the materialised tensor
     scale = torch.rand(cin_p, device='cuda') + 0.5
@@ -636,7 +655,7 @@ def test_conv3x3_winograd24_pretransformed(C, shape):
     assert torch.equal(v_ref, v_fold)
     # refused shapes
     with pytest.raises(RuntimeError, match='Cout_p % 64'):
-        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), 32, None, 0, B, H, W, cin_p, 32, 1, None, s)
+        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), 32, None, 0, None, None, B, H, W, cin_p, 32, 1, None, s)
 
 
 W24G_WGRAD_SHAPES = [  # B, Cin segs, Cout, H, W (Cin_p, Cout_p multiples of 256)
