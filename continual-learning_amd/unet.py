@@ -48,8 +48,12 @@ PRETRANSFORM = {'0': False, 'false': False, '1': True, 'true': True}.get(str(PRE
 FOLD_BN_INTO_TRANSFORM = os.environ.get('CLAMD_FOLD_BN', '1') != '0'
 NARROW_DIRECT = os.environ.get('CLAMD_NARROW_DIRECT', '1') != '0'
 # fp32 path: ConvTranspose2d forward / data gradient as register-blocked GEMMs with operands loaded straight into the MFMA operand
-# registers (csrc/pw_direct.hip) instead of the LDS-staged 256-pixel x 64-channel tiles of igemm_kernel.  False = igemm_kernel.
-CONVT_DIRECT = os.environ.get('CLAMD_CONVT_DIRECT', '1') != '0'
+# registers (csrc/pw_direct.hip) instead of the LDS-staged 256-pixel x 64-channel tiles of igemm_kernel.
+# BUILT, MEASURED, OFF BY DEFAULT.  Alone the kernels are faster (tools/convt_direct_ab.py: forward 0.67 -> 0.64 ms, data gradient
+# 0.64 -> 0.57 ms per step), inside the step they are slower (tools/step_ab.py fp32 CONVT_DIRECT 0 fwd dgrad 1: 21.44 / 21.50 / 21.84 /
+# 21.74 ms): one wave per SIMD with all 512 registers leaves no room on a CU for the other stream's HBM-bound passes, which the
+# two-workgroups-per-CU igemm_kernel (fewer registers per wave) does -- the same lesson as the half-batch pipeline.
+CONVT_DIRECT = os.environ.get('CLAMD_CONVT_DIRECT', '0')          # '0' | '1' (both) | 'fwd' | 'dgrad'
 # fp32 path: the five BatchNorm-backward sums of the first unit of a stage taken in the epilogue of the Winograd data-gradient launch that
 # produces its gradient (wino24g.hip: pre-transformed and direct-filter kernels) instead of the separate bn_bwd_reduce pass.
 # BUILT, MEASURED, OFF BY DEFAULT: tools/step_ab.py fp32 FUSE_WINO_SUMS False True -> 21.19 vs 21.22 ms per step.  The 40 running sums
@@ -449,9 +453,10 @@ class _Engine:
                 # tools/convt_direct_ab.py: the data gradient gains on every shape (0.64 -> 0.57 ms per step), the forward only where
                 # K = Cin is long (1024 / 512 channels: 0.73 -> 0.77, 0.63 -> 0.81 of the pipe); with 256 / 128 input channels the
                 # scattered pixel-shuffle stores of the short tiles cost what the loop gains
-                tail.direct = (CONVT_DIRECT and self.dcode == _lib.F32 and tail.cin_p % 128 == 0 and tail.cout_p % 32 == 0
-                               and tail.consumer is None)
-                tail.direct_f = tail.direct and tail.cin_p >= 512
+                ok = self.dcode == _lib.F32 and tail.cin_p % 128 == 0 and tail.cout_p % 32 == 0 and tail.consumer is None
+                cd_ = str(CONVT_DIRECT).lower()
+                tail.direct = ok and cd_ in ('1', 'true', 'dgrad')
+                tail.direct_f = ok and cd_ in ('1', 'true', 'fwd') and tail.cin_p >= 512
             else:
                 tail.cout_p = self.Kp
                 tail.wf = torch.zeros(tail.cout_p * tail.cin_p, dtype=T, device=dev)
@@ -859,13 +864,14 @@ class _Engine:
                          t.cout, t.cout_p, t.cin, t.cin_p, dc, tp, sw)
                     call('clamd_channel_sum', ptr(self.dl), self.Kp, g[t.keys[1]], B * h * w, self.Kp, t.cout, dc,
                          ptr(self.ws), self.ws_bytes, tp, sw)
-                elif t.direct:
-                    call('clamd_convT2x2_dgrad_direct', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
-                         B, h, w, t.cin_p, t.cout_p, s)
                 else:
-                    call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
-                         ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
-                         t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cin_p, t.cout_p, dc, s)
+                    if t.direct:
+                        call('clamd_convT2x2_dgrad_direct', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
+                             B, h, w, t.cin_p, t.cout_p, s)
+                    else:
+                        call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
+                             ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
+                             t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cin_p, t.cout_p, dc, s)
                     sw = self._wg_stream_ptr()
                     call('clamd_wgrad', _lib.WGRAD_UP2, ptr(t.x), t.x.shape[-1], ptr(t.gy_slice), t.y_ldc, ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cin_p, t.cout_p, t.cin, t.cout,

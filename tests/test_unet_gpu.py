@@ -690,6 +690,23 @@ def test_half_batch_forward_pipeline(C, dtype, monkeypatch):
     assert not any(u.split for u in next(iter(c[3]._engines.values())).convs) and bool(torch.isfinite(c[0]))
 
 
+def test_winograd_dgrad_with_fused_bn_backward_sums(C, monkeypatch):
+    """unet.FUSE_WINO_SUMS (opt-in): the five BatchNorm-backward sums of a stage's first unit taken in the epilogue of the Winograd
+    data-gradient launch (pre-transformed and direct-filter kernels of wino24g.hip) instead of the separate bn_bwd_reduce pass: the
+    same sums over other partial rows -> the same step up to fp32 rounding of the rows; bit-identical to itself."""
+    from continual_learning_amd import unet as U
+    ref = _one_step(C, 'fp32', 6, 64, 16, 128)
+    assert not any(u.fused_reduce for u in next(iter(ref[3]._engines.values())).convs)
+    monkeypatch.setattr(U, 'FUSE_WINO_SUMS', True)
+    a, a2 = _one_step(C, 'fp32', 6, 64, 16, 128), _one_step(C, 'fp32', 6, 64, 16, 128)
+    eng = next(iter(a[3]._engines.values()))
+    fused = [u.name for u in eng.convs if u.fused_reduce]
+    assert 'enc1.0' in fused and 'last.0' in fused and len(fused) >= 3, fused         # direct-filter kernel (64 ch) and pre-transformed ones
+    assert torch.equal(a[1], a2[1]) and torch.equal(a[2], a2[2])
+    assert abs(float(a[0]) - float(ref[0])) < 1e-6 * abs(float(ref[0]))                # the forward pass is the same launches
+    assert float((a[1] - ref[1]).norm() / ref[1].norm()) < 5e-3
+
+
 def test_engine_buffers_are_released_with_the_model(C):
     """A model's engine (activations, gradients, workspaces: GBs at full size) must go when the model goes, by reference
     counting -- not whenever the cyclic garbage collector next runs (a trainer that rebuilds models, or begin_task2's
@@ -761,18 +778,20 @@ def test_checkpoint_roundtrip_and_resume(C, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16x3'])
-def test_graphed_step_matches_eager(C, dtype):
+@pytest.mark.parametrize('dtype,cd,size', [('fp32', 8, 64), ('bf16x3', 8, 64), ('fp32', 64, 64)])
+def test_graphed_step_matches_eager(C, dtype, cd, size):
     """The whole train step captured in ONE HIP graph (graph.GraphedStep) replays the same kernels as the eager loop:
     the SAME loss sequence, bit for bit (every reduction is a fixed-order sum); the LambdaLR schedule still reaches the
     captured Adam kernel (lr is read from device memory), and the host-side step counter follows the replays."""
     dev = torch.device('cuda', 0)
-    x = torch.from_numpy(C.synth.images(5, 2, 3, 64, 64)).to(dev)
-    y = torch.from_numpy(C.synth.labels(5, 2, 64, 64, 5)).to(dev)
+    # (fp32, 64, 64): 256-channel layers at 16 x 16 -- the pre-transformed Winograd kernels, the BatchNorm folded into their input
+    # transform and the direct ConvTranspose GEMMs are inside the captured graph
+    x = torch.from_numpy(C.synth.images(5, 2, 3, size, size)).to(dev)
+    y = torch.from_numpy(C.synth.labels(5, 2, size, size, 5)).to(dev)
 
     def make():
         torch.manual_seed(3)
-        m = C.UNet(5, 3, 8, compute_dtype=dtype).to(dev).train()
+        m = C.UNet(5, 3, cd, compute_dtype=dtype).to(dev).train()
         o = C.FusedAdam(m.parameters(), lr=1e-3, betas=[0.5, 0.99])
         sch = torch.optim.lr_scheduler.LambdaLR(o, lambda n: 0.5 ** n)
         return m, o, sch, C.CrossEntropyLoss()
@@ -786,6 +805,9 @@ def test_graphed_step_matches_eager(C, dtype):
             s1.step()                                    # halve the learning rate after the 4th step
     m2, o2, s2, c2 = make()
     step = C.GraphedStep(m2, o2, c2, x, y, warmup=3)     # 3 eager steps, then the capture (not executed)
+    if cd == 64:
+        eng = next(iter(m2._engines.values()))
+        assert any(u.pre_f for u in eng.convs) and any(u.pre_w for u in eng.convs) and any(u.apply_folded for u in eng.convs)
     got = [float(l) for l in step.eager_losses]
     flat = lambda m: torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
     moved = []
