@@ -91,6 +91,7 @@ SIGNATURES = {
     'clamd_conv3x3_winograd24_pre': (_I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_conv3x3_winograd24_direct_filters': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_wgrad_winograd24_pre_operand_elems': (_SZ, [_I, _I, _I, _I]),
+    'clamd_wgrad_winograd24_pre_transform': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     'clamd_wgrad_winograd24_pre_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I]),
     'clamd_wgrad_winograd24_pre': (_I, [_P, _I, _P, _P, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_ce_workspace_bytes': (_SZ, []),

@@ -1161,7 +1161,7 @@ int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, floa
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("wgrad_winograd24_pre: empty problem");
     if ((H & 1) || (W & 3)) return clamd_fail("wgrad_winograd24_pre: H must be even and W a multiple of 4");
     if (Rp % 256 || Cp % 256 || Rp <= 0 || Cp <= 0 || gz_ldc % 4) return clamd_fail("wgrad_winograd24_pre: needs Rp and Cp multiples of 256");
-    if ((long long)H * W * gz_ldc * 4 >= (1ll << 31)) return clamd_fail("wgrad_winograd24_pre: one image exceeds 2^31 bytes");
+    if (gz && (long long)H * W * gz_ldc * 4 >= (1ll << 31)) return clamd_fail("wgrad_winograd24_pre: one image exceeds 2^31 bytes");
     const clamd_tuning& tn = clamd_tune(tune);
     const long long ntm = w24g_tiles(B, H, W), Tp = ntm * 32;
     if (Tp * Rp * 4 >= (1ll << 32) || (unsigned long long)ntm * (Cp / 8) * 24 * 1024 >= (1ull << 32))
@@ -1170,7 +1170,7 @@ int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, floa
     const int nsplit = w24g_wg_plan(Tp, Rp, Cp, tn, &per);
     if ((size_t)nsplit * 24 * Rp * Cp * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd24_pre: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    {
+    if (gz) {                                  // gz == NULL: yt already holds the transformed gradient (clamd_wgrad_winograd24_pre_transform)
         W24WgXformParams pa{gz, gz_ldc, yt, B, H, W, Rp, (int)Tp};
         const long long na = (Tp * (Rp / 4) + 255) / 256;
         const unsigned g = (unsigned)std::min<long long>(na, 1 << 20);
@@ -1194,6 +1194,22 @@ int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, floa
     else W24G_REDUCE(1);
 #undef W24G_REDUCE
     return clamd_check_launch("wgrad_winograd24_pre_reduce");
+}
+
+// The gradient-side transform alone (A4 dY A6^T of gz into yt, tiles in the order of the forward image): a caller with several
+// streams can run it beside another launch's GEMM and then call clamd_wgrad_winograd24_pre with gz == NULL.
+int clamd_wgrad_winograd24_pre_transform(const float* gz, int gz_ldc, float* yt, int B, int H, int W, int Rp, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || !gz || !yt) return clamd_fail("wgrad_winograd24_pre_transform: bad arguments");
+    if ((H & 1) || (W & 3)) return clamd_fail("wgrad_winograd24_pre_transform: H must be even and W a multiple of 4");
+    if (Rp % 4 || Rp <= 0 || gz_ldc % 4) return clamd_fail("wgrad_winograd24_pre_transform: channel count / pitch must be padded");
+    const long long Tp = w24g_tiles(B, H, W) * 32;
+    if ((long long)H * W * gz_ldc * 4 >= (1ll << 31) || Tp * Rp * 4 >= (1ll << 32)) return clamd_fail("wgrad_winograd24_pre_transform: operand too large");
+    W24WgXformParams pa{gz, gz_ldc, yt, B, H, W, Rp, (int)Tp};
+    const long long na = (Tp * (Rp / 4) + 255) / 256;
+    const unsigned g = (unsigned)std::min<long long>(na, 1 << 20);
+    if (W >= 32) hipLaunchKernelGGL(wino24g_wgrad_xform_kernel<8>, dim3(g), dim3(256), 0, (hipStream_t)stream, pa);
+    else hipLaunchKernelGGL(wino24g_wgrad_xform_kernel<4>, dim3(g), dim3(256), 0, (hipStream_t)stream, pa);
+    return clamd_check_launch("wgrad_winograd24_pre_transform");
 }
 
 }  // extern "C"

@@ -60,6 +60,10 @@ CONVT_DIRECT = os.environ.get('CLAMD_CONVT_DIRECT', '0')          # '0' | '1' (b
 # live across the K loop of kernels that already use all 512 registers (45 / 77 registers spill around the loop, none inside it), and the
 # reduce passes they replace mostly ran beside a weight-gradient kernel of the second stream anyway.
 FUSE_WINO_SUMS = os.environ.get('CLAMD_FUSE_WINO_SUMS', '0') != '0'
+# fp32 path, pre-transformed weight gradients: the gradient-side transform (HBM-bound) on a THIRD stream, so that it runs beside the
+# weight-gradient GEMM of the unit before (which leaves 188 registers per SIMD free) instead of in front of its own GEMM on the second
+# stream, and that GEMM can start the moment the data gradient of its unit has finished.
+WGRAD_XFORM_STREAM = os.environ.get('CLAMD_WGRAD_XFORM_STREAM', '1') != '0'
 # Forward pass in two half-batches where a half still fills the chip (levels 0-2 at config 2): conv -> BatchNorm statistics ->
 # apply -> conv is a chain through the whole batch, so the HBM-bound passes (bn_apply, the input transforms) have nothing to run
 # beside -- unless the batch is cut in two: the second half's apply / transform runs on the second stream UNDER the first half's
@@ -102,6 +106,16 @@ def _second_stream(dev):
         # measurable (tools/cu_steal.py, base and held-CU cases within 0.5 %)
         _SECOND_STREAM[key] = torch.cuda.Stream(device=dev)
     return _SECOND_STREAM[key]
+
+
+_THIRD_STREAM = {}
+
+
+def _third_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _THIRD_STREAM:
+        _THIRD_STREAM[key] = torch.cuda.Stream(device=dev)
+    return _THIRD_STREAM[key]
 
 
 def _timed(tag, flops, nbytes, name, *args):
@@ -511,6 +525,12 @@ class _Engine:
         nyt = max([lib.clamd_wgrad_winograd24_pre_operand_elems(B, u.h, u.w_, u.cout_p) for u in convs if u.pre_w] + [0])
         self.vg = torch.empty(nvg, dtype=torch.float32, device=dev) if nvg else None
         self.yt = torch.empty(nyt, dtype=torch.float32, device=dev) if nyt else None
+        # third stream + a second operand buffer: the transform of unit u runs while the GEMM of unit u+1 still reads the other buffer
+        self.x3_stream = (_third_stream(dev) if (WGRAD_XFORM_STREAM and WGRAD_STREAM and dev.type == 'cuda' and nyt) else None)
+        self.yt2 = torch.empty(nyt, dtype=torch.float32, device=dev) if (nyt and self.x3_stream is not None) else None
+        self._yt_flip = 0
+        self._yt_ev = [None, None]
+        self._x3_ev = None
         self.wg_stream = _second_stream(dev) if (WGRAD_STREAM and dev.type == 'cuda') else None
         self._wg_used = False
         self._pack_pending = 0
@@ -824,6 +844,8 @@ class _Engine:
         s = _lib.stream_ptr()
         self._wg_used = False
         self._pack_pending = 0
+        self._yt_ev = [None, None]      # events of THIS backward pass only (the previous one was joined before it returned; a captured
+        self._x3_ev = None              # graph must not wait on an event recorded outside the capture)
         B, H, W, dc = self.B, self.H, self.W, self.dcode
         if not self.fwd_training:
             raise RuntimeError('UNet.backward after an eval-mode forward is not supported (BatchNorm backward uses batch statistics)')
@@ -887,6 +909,18 @@ class _Engine:
         gf = self.gflat
         return [gf[o:o + k].view(self.gshape[n]) for n, (o, k) in ((n, self.goffset[n]) for n in self.param_names)]
 
+    def _x3_allowed(self):
+        """The third stream only where it cannot end up on a hardware queue with RCCL's kernels: HIP multiplexes streams onto
+        GPU_MAX_HW_QUEUES queues (4 by default) and a kernel waits behind whatever shares its queue.  A data-parallel rank has the default
+        stream, the second and third streams, GradSync's stream and RCCL's: five -- so under ddp.GradSync the third stream needs the 8 queues
+        bench.py / ddp.init_rccl set before the runtime starts."""
+        if self.model.grad_sync is None:
+            return True
+        try:
+            return int(os.environ.get('GPU_MAX_HW_QUEUES', '4')) >= 8
+        except ValueError:
+            return False
+
     def _fuse_sums(self, b):
         """Does the data-gradient launch of conv `b` (3x3, K = b.cout_p gradient channels) also reduce the BN-backward sums
         of the unit in front of it?"""
@@ -914,6 +948,20 @@ class _Engine:
         else:
             c_seg0, c_seg0p = u.cin, u.cin_p
         flops = 2.0 * B * u.h * u.w_ * 9 * u.cin * u.cout
+        self._x3_ev = None
+        if (u.pre_w and self.x3_stream is not None and self.wg_stream is not None and KERNEL_TIMING is None and self._x3_allowed()
+                and not torch.cuda.is_current_stream_capturing()):      # hipStreamEndCapture crashes on this three-stream pattern (ROCm 7.2):
+            #                                                            a captured step keeps the transform on the second stream
+            # gz is complete on the current stream: its weight-gradient transform goes to the third stream NOW (it runs beside whatever
+            # weight-gradient GEMM the second stream is in), into the operand buffer the previous GEMM is not reading
+            self._yt_flip ^= 1
+            self._x3_buf = self.yt2 if self._yt_flip else self.yt
+            x3 = self.x3_stream
+            x3.wait_stream(torch.cuda.current_stream())
+            if self._yt_ev[self._yt_flip] is not None:      # the GEMM that read this buffer last (two pre-transformed units back)
+                x3.wait_event(self._yt_ev[self._yt_flip])
+            call('clamd_wgrad_winograd24_pre_transform', ptr(u.gz), u.cout_p, ptr(self._x3_buf), B, u.h, u.w_, u.cout_p, x3.cuda_stream)
+            self._x3_ev = torch.cuda.Event(); self._x3_ev.record(x3)
         def dgrad():
             _TIMED_UNIT[:] = [u.name + ' dgrad', self.executed_fraction(u, 'dgrad')]
             if u.g_in is not None and u.pre_d:
@@ -954,7 +1002,15 @@ class _Engine:
                  g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, 9 * u.cin, u.cout, u.cout_p, 9 * u.cin, u.cin_p, dc, tp, sw)
             return
         _TIMED_UNIT[:] = [u.name + ' wgrad', self.executed_fraction(u, 'wgrad')]
-        if u.pre_w:
+        if u.pre_w and self._x3_ev is not None:
+            # the gradient-side operand was transformed on the third stream (enqueued when gz became ready, see below)
+            self.wg_stream.wait_event(self._x3_ev)
+            call('clamd_wgrad_winograd24_pre', None, u.cout_p, ptr(u.vx), ptr(self._x3_buf), ptr(self.ws), self.ws_bytes,
+                 g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, tp, sw)
+            ev = torch.cuda.Event(); ev.record(self.wg_stream)
+            self._yt_ev[self._yt_flip] = ev
+            self._x3_ev = None
+        elif u.pre_w:
             _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
                    'clamd_wgrad_winograd24_pre', ptr(u.gz), u.cout_p, ptr(u.vx), ptr(self.yt), ptr(self.ws), self.ws_bytes,
                    g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, tp, sw)

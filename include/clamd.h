@@ -152,6 +152,9 @@ int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const flo
  * two 16-byte loads, no LDS); split-K slabs in `workspace` (>= clamd_wgrad_winograd24_pre_workspace_bytes), fixed-order
  * reduce with G4^T . G6: deterministic.  Rp and Cp multiples of 256; other arguments as clamd_wgrad_winograd24. */
 size_t clamd_wgrad_winograd24_pre_operand_elems(int B, int H, int W, int Rp);
+/* the gradient-side transform alone (a caller with several streams can run it beside another launch's GEMM); clamd_wgrad_winograd24_pre
+ * with gz == NULL then takes yt as already transformed */
+int clamd_wgrad_winograd24_pre_transform(const float* gz, int gz_ldc, float* yt, int B, int H, int W, int Rp, void* stream);
 size_t clamd_wgrad_winograd24_pre_workspace_bytes(int B, int H, int W, int Rp, int Cp);
 int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, float* yt, float* workspace, size_t ws_bytes, float* out,
                                int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p,

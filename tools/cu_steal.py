@@ -73,4 +73,6 @@ if __name__ == '__main__':
     held = int(a[1]) if len(a) > 1 else 8
     extra = [('fine', held, dict(wino_persist=0, wgrad_blocks=896)), ('fine_base', 0, dict(wino_persist=0, wgrad_blocks=896)),
              ('fine2', held, dict(wino_persist=0, wgrad_blocks=1024)), ('fine2_base', 0, dict(wino_persist=0, wgrad_blocks=1024))]
+    if len(a) > 3 and a[3] == 'basic':
+        extra = []
     print(json.dumps(measure(dt, held, int(a[2]) if len(a) > 2 else 6, extra=extra)))
