@@ -388,8 +388,11 @@ class _Engine:
             u.pre_w = bool(pt) and u.w24 and u.cin_p % 256 == 0 and u.cout_p % 256 == 0
             u.pre_f = bool(pt) and u.w24 and u.cin_p >= 64 and u.cout_p % 64 == 0 and (
                 pt is True or (u.cin_p >= 256 and (u.pre_w or 2 * u.cout_p > u.cin_p)) or (u.cin_p >= 128 and u.cout_p >= 2 * u.cin_p))
-            u.pre_w = u.pre_w and u.pre_f
-            u.pre_d = bool(pt) and u.w24d and not first_of_net and u.cout_p >= 64 and u.cin_p % 64 == 0 and (
+            # one buffer descriptor spans a whole transformed tensor: below 2^32 bytes (config 2: <= 0.4 GB; 512 x 512 bs32 fp32: 3.2 GB)
+            fits = lambda c: lib.clamd_winograd24_input_elems(B, u.h, u.w_, c) * 4 < (1 << 32)
+            u.pre_f = u.pre_f and fits(u.cin_p)
+            u.pre_w = u.pre_w and u.pre_f and lib.clamd_wgrad_winograd24_pre_operand_elems(B, u.h, u.w_, u.cout_p) * 4 // 24 < (1 << 32)
+            u.pre_d = bool(pt) and u.w24d and not first_of_net and u.cout_p >= 64 and u.cin_p % 64 == 0 and fits(u.cout_p) and (
                 pt is True or (u.cout_p >= 256 and (2 * u.cin_p > u.cout_p or (2 * u.cin_p == u.cout_p and u.cin_p >= 256))))
             u.vx = torch.empty(lib.clamd_winograd24_input_elems(B, u.h, u.w_, u.cin_p), dtype=torch.float32, device=dev) if u.pre_f else None
             # 64 input channels (8 chunks per tile): the in-kernel-transform kernel with the filters loaded straight into the operand
