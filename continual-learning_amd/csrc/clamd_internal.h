@@ -51,3 +51,9 @@ inline int clamd_usable_cus(const clamd_tuning& t) {
 // workgroups of the BatchNorm-backward reduction (elementwise.hip)
 long long clamd_winograd_stat_rows(int B, int H, int W, int Cout_p, const clamd_tuning& tn);
 long long clamd_bn_bwd_reduce_rows(int B, int H, int W, int Cp, bool pooled, const clamd_tuning& tn);
+
+// the three filter-pack launches with an optional border-class bias table appended (grid = total_blocks + Cout_p; bnfold.hip)
+namespace clamd { struct FoldBias; }
+int clamd_launch_pack(const void* jobs_dev, int njobs, int total_blocks, int dtype, const clamd::FoldBias* fold, hipStream_t stream);
+int clamd_launch_wino_pack(const void* jobs_dev, int njobs, int total_blocks, const clamd::FoldBias* fold, hipStream_t stream);
+int clamd_launch_wino24_pack(const void* jobs_dev, int njobs, int total_blocks, const clamd::FoldBias* fold, hipStream_t stream);

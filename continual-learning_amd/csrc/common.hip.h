@@ -209,10 +209,44 @@ __device__ inline int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// Border class of an output pixel of a zero-padded 3x3 convolution: 3 * (0 top row, 1 interior, 2 bottom row) + (0 left column, 1 interior,
+// 2 right column).  Which of the nine taps read padding depends on nothing else (H, W >= 2).
+__device__ inline int border_class(int yy, int xx, int H, int W) {
+    return (yy == 0 ? 0 : (yy == H - 1 ? 6 : 3)) + (xx == 0 ? 0 : (xx == W - 1 ? 2 : 1));
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
+}
+
+// Border-class bias table of a BatchNorm folded into the convolution behind it (bnfold.hip): table[class][co] = bias[co] + the sum of
+// T[co][tap] = sum_ci w[co][ci][tap] * shift[ci] over the taps of that class which read inside the image.  Appended to the filter-pack launch
+// of the same convolution (blocks beyond the pack's own: one per physical output channel, 256 threads).
+struct FoldBias { const float* w; const float* shift; const float* bias; float* table; int Cout, Cin, Cout_p; };
+__device__ inline void fold_bias_block(const FoldBias& f, int co, float* T /* __shared__ [9] */) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int tap = wv; tap < 9; tap += 4) {         // a wave per tap: lanes stride 64 over the input channels, then the xor butterfly
+        float a = 0.f;
+        if (co < f.Cout)
+            for (int ci = lane; ci < f.Cin; ci += 64) a = fmaf(f.w[((size_t)co * f.Cin + ci) * 9 + tap], f.shift[ci], a);
+        a = wave_sum(a);
+        if (lane == 0) T[tap] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const int rc = threadIdx.x / 3, cc = threadIdx.x % 3;       // row class: 0 top (tap row 0 reads padding), 2 bottom (tap row 2 does)
+        float s = (co < f.Cout && f.bias) ? f.bias[co] : 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const bool out = (rc == 0 && ky == 0) || (rc == 2 && ky == 2) || (cc == 0 && kx == 0) || (cc == 2 && kx == 2);
+                if (!out) s += T[ky * 3 + kx];
+            }
+        f.table[(size_t)threadIdx.x * f.Cout_p + co] = co < f.Cout ? s : 0.f;
+    }
 }
 
 // Issue-order hint for a software-pipelined MFMA loop: NM MFMAs of the current step interleaved with the NR LDS reads

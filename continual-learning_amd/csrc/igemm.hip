@@ -551,22 +551,33 @@ static int check_rows(const IgemmParams& p, int have, int need, const char* who)
 int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
                   float* stats, const void* bn_y, float* bn_sums, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p,
                   int relu, int m_fastest, int dtype, const clamd_tuning* tune, void* stream) {
-    IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, m_fastest, bn_y, bn_sums};
+    if (relu & ~3) return clamd_fail("conv3x3: bad relu flags");
+    IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu & 1, 0, m_fastest, bn_y, bn_sums};
+    p.bias_classes = (relu & CLAMD_BIAS_BORDER_CLASSES) ? 1 : 0;
     if (int e = check_common(p, "conv3x3", dtype)) return e;
     if (int e = clamd_check_tuning(tune)) return e;
     if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("conv3x3: bn_y and bn_sums go together");
     const clamd_tuning& tn = clamd_tune(tune);
     const Conv3Plan pl = plan_conv3x3(p, dtype, tn);
     if (pl.rows <= 0) return clamd_fail("conv3x3: grid out of range");
+    if (p.bias_classes && (pl.kind != 2 || !bias || H < 2 || W < 2))
+        return clamd_fail("conv3x3: the border-class bias table needs the persistent kernel (ask clamd_conv3x3_border_bias_ok), a table and H, W >= 2");
     if (int e = check_rows(p, stat_rows, pl.rows, "conv3x3")) return e;
     if (pl.kind == 2) return launch_igemm_pws(p, dtype, (hipStream_t)stream, tn);
     if (pl.kind == 1) return launch_igemm_ws(p, dtype, (hipStream_t)stream, pl.mt);
     return launch<MODE_CONV3, EPI_NHWC>(p, dtype, (hipStream_t)stream, tn.igemm_variant);
 }
 
+int clamd_conv3x3_border_bias_ok(int B, int H, int W, int Cin_p, int Cout_p, int dtype, const clamd_tuning* tune) {
+    if (B <= 0 || H < 2 || W < 2 || clamd_check_tuning(tune)) return 0;
+    IgemmParams p{nullptr, Cin_p, nullptr, nullptr, nullptr, Cout_p, nullptr, B, H, W, Cin_p, Cout_p, 1, 0, 0, nullptr, nullptr};
+    return plan_conv3x3(p, dtype, clamd_tune(tune)).kind == 2 ? 1 : 0;
+}
+
 int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
                   float* stats, const void* bn_y, float* bn_sums, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p,
                   int relu, int dtype, void* stream) {
+    if (relu & ~1) return clamd_fail("conv1x1: relu must be 0 or 1");
     IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 0, 0, bn_y, bn_sums};
     if (int e = check_common(p, "conv1x1", dtype)) return e;
     if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("conv1x1: bn_y and bn_sums go together");

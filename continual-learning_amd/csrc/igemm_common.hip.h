@@ -28,6 +28,8 @@ struct IgemmParams {
     // EPI_NCHW only: arg-max over the logical classes per pixel (first maximum wins, as torch.max), int64 [B,H,W]; y may
     // then be null (eval forward, trainer.py:279: the logits are never materialised)
     long long* pred;
+    // MODE_CONV3 forward launches behind a folded BatchNorm (bnfold.hip): bias is a [9][Np] table indexed by the border class of the pixel
+    int bias_classes;
 };
 
 #ifndef IGEMM_PW_NT

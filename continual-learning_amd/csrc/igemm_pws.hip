@@ -34,7 +34,7 @@ __device__ unsigned long long g_pws_diag[8];
 // RAGGED = false (image height and width are multiples of the tile): no edge masks anywhere.  With one kernel for both
 // cases hipcc merged the `full` and the ragged branch of the epilogue into one select-per-element version (16 compares,
 // 30 v_cndmask, 18 s_and per 32x64 block: 283 instead of ~215 instructions for EVERY tile).
-template <typename T, int TW, bool RAGGED>
+template <typename T, int TW, bool RAGGED, bool CLS = false>      // CLS: bias from a border-class table (IgemmParams::bias_classes)
 __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, const int gm, const int w_resident) {
     constexpr int MT = 2;
     using G = WsGeo<TW, MT>;
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int n = n0 + 32 * nt + r;
-            bcol[nt] = (p.bias && n < p.Np) ? p.bias[n] : 0.f;
+            bcol[nt] = (p.bias && n < p.Np) ? p.bias[(CLS ? 4 * p.Np : 0) + n] : 0.f;      // class 4: interior pixels
         }
         float* const wbuf = reinterpret_cast<float*>(smem + 2 * STAGE) + cw * 32 * EPW;   // this wave's transposition block
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();
@@ -361,6 +361,8 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             const __amdgpu_buffer_rsrc_t yrs = make_rsrc((const char*)p.y + (size_t)b * y_img, y_img);
             const unsigned y_so = (unsigned)((y0 * p.W + x0) * p.y_ldc) * (unsigned)sizeof(T);
             const bool full = !RAGGED || (y0 + TH <= p.H && x0 + TW <= p.W);           // wave-uniform
+            // a folded BatchNorm's shift term depends on which taps read padding: tiles on the image border take the bias per pixel
+            const bool edge_tile = CLS && (y0 == 0 || x0 == 0 || y0 + TH >= p.H || x0 + TW >= p.W);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const unsigned long long e0 = PWD_T(); (void)e0;
@@ -372,6 +374,49 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) wbuf[acc_row(e, h) * EPW + 32 * nt + r] = acc[mt][nt][e];
+                } else if (edge_tile) {
+                    // an MFMA row tile is 32 / TW image rows of the tile: the row class is wave-uniform, the column class differs from
+                    // "interior" in at most the first / last pixel of a row -- three table entries per row and channel.  Where the tile is
+                    // whole along x, WHICH accumulator registers hold those two pixels is known at compile time (acc_row): the other
+                    // registers cost what they cost in an interior tile.
+                    constexpr int RPM = 32 / TW;
+                    const bool whole_x = x0 + TW <= p.W;
+                    const bool first_col = x0 == 0 && h == 0, last_col = x0 + TW == p.W && h == 1;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const int n = n0 + 32 * nt + r;
+                        const float* const bt = p.bias + (n < p.Np ? n : 0);
+                        float bl[RPM], bm[RPM], br[RPM];
+#pragma unroll
+                        for (int rr = 0; rr < RPM; ++rr) {
+                            const int yy = y0 + (MT * cw + mt) * RPM + rr;
+                            const int rc = yy == 0 ? 0 : (yy == p.H - 1 ? 6 : 3);
+                            bl[rr] = n < p.Np ? bt[(rc + 0) * p.Np] : 0.f;
+                            bm[rr] = n < p.Np ? bt[(rc + 1) * p.Np] : 0.f;
+                            br[rr] = n < p.Np ? bt[(rc + 2) * p.Np] : 0.f;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int rr = TW == 32 ? 0 : (e >> 3);                 // acc_row(e, h) / TW
+                            const int yy = y0 + (MT * cw + mt) * RPM + rr;
+                            float bv = bm[rr];
+                            bool in = yy < p.H;
+                            if (whole_x) {      // wave-uniform
+                                const int ec = TW == 32 ? (e >> 2) : ((e >> 2) & 1);            // acc_row = (e & 3) + 8 * (e >> 2) + 4 * h
+                                if ((e & 3) == 0 && ec == 0) bv = first_col ? bl[rr] : bv;         // column 0 of the tile: h == 0 lanes
+                                if ((e & 3) == 3 && ec == TW / 8 - 1) bv = last_col ? br[rr] : bv;  // column TW - 1: h == 1 lanes
+                            } else {
+                                const int xx = x0 + acc_row(e, h) - rr * TW;
+                                bv = xx == 0 ? bl[rr] : (xx == p.W - 1 ? br[rr] : bv);
+                                in = in && xx < p.W;
+                            }
+                            const float v = fmaxf(acc[mt][nt][e] + bv, relu_lo);
+                            const float vs = (full || in) ? v : 0.f;
+                            st1[nt] += vs;
+                            st2[nt] = fmaf(vs, vs, st2[nt]);
+                            wbuf[acc_row(e, h) * EPW + 32 * nt + r] = v;
+                        }
+                    }
                 } else if (full) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
@@ -532,7 +577,11 @@ static int launch_pws_t(const IgemmParams& p, hipStream_t s, int dtype, const cl
     const long long nblk = gm * ntn;
     if (ntm > 0x7fffffff) return clamd_fail("igemm_pws: grid out of range");
     const bool ragged = (p.H % TH) != 0 || (p.W % TW) != 0;
-#define PWS_LAUNCH(TW_, RG_) hipLaunchKernelGGL((igemm_pws_kernel<T, TW_, RG_>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm, tn.pws_wres)
+#define PWS_LAUNCH(TW_, RG_)                                                                                                      \
+    do {                                                                                                                           \
+        if (p.bias_classes) hipLaunchKernelGGL((igemm_pws_kernel<T, TW_, RG_, true>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm, tn.pws_wres); \
+        else hipLaunchKernelGGL((igemm_pws_kernel<T, TW_, RG_, false>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm, tn.pws_wres);              \
+    } while (0)
     if (wide) { if (ragged) PWS_LAUNCH(32, true); else PWS_LAUNCH(32, false); }
     else { if (ragged) PWS_LAUNCH(16, true); else PWS_LAUNCH(16, false); }
 #undef PWS_LAUNCH

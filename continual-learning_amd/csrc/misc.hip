@@ -55,6 +55,8 @@ struct PackJob {
     int block0;                  // first block of this job in the fused launch
     int kc;                      // 0: dst = t*dt + n*dn + k*dk;  >0: K-chunk-major  ((k/kc)*T + t)*Np*kc + n*kc + k%kc
                                  // (the 3x3 kernels read whole [tap][n] slabs of one K-chunk: contiguous 128-B lines)
+    const float* kscale;         // optional [Kp]: every element is multiplied by kscale[physical k] (a BatchNorm folded into the
+                                 // filters of the convolution behind it, bnfold.hip)
 };
 
 __device__ inline int phys2log(int p, int seg0, int seg0p, int L) {
@@ -69,8 +71,12 @@ __device__ inline int phys2log(int p, int seg0, int seg0p, int L) {
 // coalesced (the first version read with a 36-byte lane stride and fetched ~9x the bytes it needed).
 constexpr int PACK_TILE = 32;
 template <typename T>
-__global__ void __launch_bounds__(256) pack_kernel(const PackJob* __restrict__ jobs, int njobs) {
+__global__ void __launch_bounds__(256) pack_kernel(const PackJob* __restrict__ jobs, int njobs, int nblocks, const FoldBias fold) {
     __shared__ float tile[9][PACK_TILE][PACK_TILE + 1];
+    if ((int)blockIdx.x >= nblocks) {       // appended blocks: the border-class bias table of a folded BatchNorm (common.hip.h)
+        fold_bias_block(fold, (int)blockIdx.x - nblocks, &tile[0][0][0]);
+        return;
+    }
     int lo = 0, hi = njobs - 1;          // locate the job of this block (jobs are sorted by block0)
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -94,7 +100,8 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackJob* __restrict__ j
         }
         const bool ok = nl >= 0 && kl >= 0;
         const float* src = j.src + (ok ? nl * j.sn + kl * j.sk : 0);
-        for (int t = 0; t < j.T; ++t) tile[t][nn][kk] = ok ? src[(j.flip ? j.T - 1 - t : t) * j.st] : 0.f;
+        const float ks = (ok && j.kscale) ? j.kscale[k] : 1.f;
+        for (int t = 0; t < j.T; ++t) tile[t][nn][kk] = ok ? src[(j.flip ? j.T - 1 - t : t) * j.st] * ks : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -466,6 +473,20 @@ __global__ void fill_kernel(float* p, long long n, float v) {
 
 using namespace clamd;
 
+int clamd_launch_pack(const void* jobs_dev, int njobs, int total_blocks, int dtype, const FoldBias* fold, hipStream_t stream) {
+    if (njobs <= 0 || total_blocks <= 0) return clamd_fail("pack: empty job table");
+    const FoldBias f = fold ? *fold : FoldBias{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    const dim3 grid(total_blocks + (fold ? fold->Cout_p : 0));
+    if (dtype == CLAMD_BF16)
+        hipLaunchKernelGGL(pack_kernel<bf16_t>, grid, dim3(256), 0, stream, (const PackJob*)jobs_dev, njobs, total_blocks, f);
+    else if (dtype == CLAMD_F32)
+        hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(256), 0, stream, (const PackJob*)jobs_dev, njobs, total_blocks, f);
+    else if (dtype == CLAMD_SPLIT)
+        hipLaunchKernelGGL(pack_kernel<split_t>, grid, dim3(256), 0, stream, (const PackJob*)jobs_dev, njobs, total_blocks, f);
+    else return clamd_fail("pack: bad dtype");
+    return clamd_check_launch("pack");
+}
+
 extern "C" {
 
 const char* clamd_last_error(void) { return g_err; }
@@ -477,15 +498,7 @@ int clamd_pack_tile(void) { return PACK_TILE; }
 int clamd_bn_bwd_nsums(void) { return 5; }
 
 int clamd_pack(const void* jobs_dev, int njobs, int total_blocks, int dtype, void* stream) {
-    if (njobs <= 0 || total_blocks <= 0) return clamd_fail("pack: empty job table");
-    if (dtype == CLAMD_BF16)
-        hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs_dev, njobs);
-    else if (dtype == CLAMD_F32)
-        hipLaunchKernelGGL(pack_kernel<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs_dev, njobs);
-    else if (dtype == CLAMD_SPLIT)
-        hipLaunchKernelGGL(pack_kernel<split_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs_dev, njobs);
-    else return clamd_fail("pack: bad dtype");
-    return clamd_check_launch("pack");
+    return clamd_launch_pack(jobs_dev, njobs, total_blocks, dtype, nullptr, (hipStream_t)stream);
 }
 
 size_t clamd_ce_workspace_bytes(void) { return (size_t)(2 * 2048 + 4) * sizeof(float); }

@@ -351,7 +351,12 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(const WinoParams p) {
 // One job = one GEMM operand: dst[(k/8)*16 + xi][n][k%8] = (G g G^T)[xi] with g = w[n_l][k_l] (forward) or the tap-flipped
 // w[k_l][n_l] (data gradient); physical -> logical channel maps as in clamd_pack (two segments for concat inputs, zero
 // padding).  One thread per (n, k): consecutive threads write consecutive floats of every xi row.
-__global__ void __launch_bounds__(256) wino_pack_kernel(const WinoPackJob* __restrict__ jobs, int njobs) {
+__global__ void __launch_bounds__(256) wino_pack_kernel(const WinoPackJob* __restrict__ jobs, int njobs, int nblocks, const FoldBias fold) {
+    if ((int)blockIdx.x >= nblocks) {       // appended blocks: the border-class bias table of a folded BatchNorm (common.hip.h)
+        __shared__ float T[9];
+        fold_bias_block(fold, (int)blockIdx.x - nblocks, T);
+        return;
+    }
     int ji = 0;
     while (ji + 1 < njobs && (int)blockIdx.x >= jobs[ji + 1].block0) ++ji;     // few jobs: linear search
     const WinoPackJob J = jobs[ji];
@@ -365,8 +370,9 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const WinoPackJob* __res
     for (int i = 0; i < 9; ++i) g[i / 3][i % 3] = 0.f;
     if (nl >= 0 && kl >= 0) {
         const float* s = J.dgrad ? J.w + ((size_t)kl * J.N + nl) * 9 : J.w + ((size_t)nl * J.K + kl) * 9;
+        const float ks = J.kscale ? J.kscale[k] : 1.f;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) g[i / 3][i % 3] = J.dgrad ? s[8 - i] : s[i];
+        for (int i = 0; i < 9; ++i) g[i / 3][i % 3] = (J.dgrad ? s[8 - i] : s[i]) * ks;
     }
     // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
     float t[4][3];
@@ -428,14 +434,20 @@ long long clamd_winograd_stat_rows(int B, int H, int W, int Cout_p, const clamd_
     return (tn.wino_persist && nblk > clamd_usable_cus(tn)) ? clamd_usable_cus(tn) : tiles;
 }
 
+int clamd_launch_wino_pack(const void* jobs_dev, int njobs, int total_blocks, const clamd::FoldBias* fold, hipStream_t stream) {
+    if (njobs <= 0 || total_blocks <= 0) return clamd_fail("wino_pack: empty job table");
+    const clamd::FoldBias f = fold ? *fold : clamd::FoldBias{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    hipLaunchKernelGGL(clamd::wino_pack_kernel, dim3(total_blocks + (fold ? fold->Cout_p : 0)), dim3(256), 0, stream, (const clamd::WinoPackJob*)jobs_dev, njobs,
+                       total_blocks, f);
+    return clamd_check_launch("wino_pack");
+}
+
 extern "C" {
 
 int clamd_sizeof_wino_pack_job(void) { return (int)sizeof(WinoPackJob); }
 
 int clamd_wino_pack(const void* jobs_dev, int njobs, int total_blocks, void* stream) {
-    if (njobs <= 0 || total_blocks <= 0) return clamd_fail("wino_pack: empty job table");
-    hipLaunchKernelGGL(wino_pack_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const WinoPackJob*)jobs_dev, njobs);
-    return clamd_check_launch("wino_pack");
+    return clamd_launch_wino_pack(jobs_dev, njobs, total_blocks, nullptr, (hipStream_t)stream);
 }
 
 int clamd_conv3x3_winograd(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
@@ -448,6 +460,7 @@ int clamd_conv3x3_winograd(const float* x, int x_ldc, const float* w_wino, const
         return clamd_fail("conv3x3_winograd: image or filter exceeds 2^31 bytes");
     if (int e = clamd_check_tuning(tune)) return e;
     const clamd_tuning& tn = clamd_tune(tune);
+    if (relu & ~1) return clamd_fail("conv3x3_winograd: relu must be 0 or 1 (no border-class bias here)");
     WinoParams p{x, x_ldc, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 1, 0};
     const long long ntn = (Cout_p + 63) / 64, nblk2 = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ntn;
     const long long nblk1 = (long long)B * ((H + 7) / 8) * ((W + 15) / 16) * ntn;

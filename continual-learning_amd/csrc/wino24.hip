@@ -40,7 +40,7 @@ constexpr int W24_WG = 66;                                    // padded rows per
 constexpr int W24_WT_SLOTS = 24 * 2 * W24_WG;
 constexpr int W24_EXP = 36;                                   // row pitch (floats) of the epilogue exchange block
 
-template <int TXN, bool RAGGED>
+template <int TXN, bool RAGGED, bool CLS = false>      // CLS: bias from a border-class table (WinoParams::bias_classes)
 __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
     constexpr int TYN = 32 / TXN;                                         // tiles down x tiles across
     constexpr int PW = 4 * TXN, PH = 2 * TYN;                             // output pixels of the workgroup tile
@@ -334,6 +334,7 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
         // data-gradient launches have no bias, ReLU or statistics: 16 VALU per stored float4 less (the wave owns its SIMD, so
         // every VALU instruction of the epilogue is time the matrix pipe idles)
         const bool plain = !p.relu && !p.bias && !p.stats;
+        const bool edge_tile = CLS && (y0 == 0 || x0 == 0 || y0 + PH >= p.H || x0 + PW >= p.W);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             float* const exb = ex + nt * EXB;
@@ -357,7 +358,13 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
             const float* const exb = ex + nt * EXB;
             const int n = n0 + 32 * nt + 4 * ng;
             float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias && n < p.Np) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+            if (p.bias && n < p.Np) bias4 = *reinterpret_cast<const float4*>(p.bias + (CLS ? 4 * p.Np : 0) + n);   // 4: interior
+            float4 bm1 = bias4;                 // bias of the thread's two output rows (pp = 0: bias4, pp = 1: bm1), interior column class
+            if (edge_tile && n < p.Np) {        // tile-uniform branch: a folded BatchNorm's shift term depends on which taps read padding
+                const int ya = y0 + 2 * (tl / TXN);
+                bias4 = *reinterpret_cast<const float4*>(p.bias + ((ya == 0 ? 0 : (ya == p.H - 1 ? 6 : 3)) + 1) * p.Np + n);
+                bm1 = *reinterpret_cast<const float4*>(p.bias + ((ya + 1 == p.H - 1 ? 6 : 3) + 1) * p.Np + n);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 R[4];
@@ -373,11 +380,14 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
                         o.x = R[1].x - R[2].x - R[3].x; o.y = R[1].y - R[2].y - R[3].y;
                         o.z = R[1].z - R[2].z - R[3].z; o.w = R[1].w - R[2].w - R[3].w;
                     }
-                    if (!plain) {
-                        o.x = fmaxf(o.x + bias4.x, relu_lo); o.y = fmaxf(o.y + bias4.y, relu_lo);
-                        o.z = fmaxf(o.z + bias4.z, relu_lo); o.w = fmaxf(o.w + bias4.w, relu_lo);
-                    }
                     const int yy = y0 + 2 * oty + pp, xx = x0 + 4 * otx + q;
+                    if (!plain) {
+                        float4 b4 = pp ? bm1 : bias4;
+                        if (edge_tile && n < p.Np && (q == 0 || q == 3) && (xx == 0 || xx == p.W - 1))      // first / last pixel of an image row
+                            b4 = *reinterpret_cast<const float4*>(p.bias + border_class(yy, xx, p.H, p.W) * p.Np + n);
+                        o.x = fmaxf(o.x + b4.x, relu_lo); o.y = fmaxf(o.y + b4.y, relu_lo);
+                        o.z = fmaxf(o.z + b4.z, relu_lo); o.w = fmaxf(o.w + b4.w, relu_lo);
+                    }
                     if (!RAGGED || (yy < p.H && xx < p.W && n < p.Np)) {
 #ifndef W24_ABLATE_ST
                         *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = o;
@@ -403,7 +413,12 @@ __global__ void __launch_bounds__(256, 1) wino24_kernel(const WinoParams p) {
 }
 
 // ---- filter transform: dst[(k/8)*24 + 6i + j][n][k%8] = (G4 g G6^T)[i][j], row 2 negated (jobs as in wino.hip) ---------
-__global__ void __launch_bounds__(256) wino24_pack_kernel(const WinoPackJob* __restrict__ jobs, int njobs) {
+__global__ void __launch_bounds__(256) wino24_pack_kernel(const WinoPackJob* __restrict__ jobs, int njobs, int nblocks, const FoldBias fold) {
+    if ((int)blockIdx.x >= nblocks) {       // appended blocks: the border-class bias table of a folded BatchNorm (common.hip.h)
+        __shared__ float T[9];
+        fold_bias_block(fold, (int)blockIdx.x - nblocks, T);
+        return;
+    }
     int ji = 0;
     while (ji + 1 < njobs && (int)blockIdx.x >= jobs[ji + 1].block0) ++ji;
     const WinoPackJob J = jobs[ji];
@@ -417,8 +432,9 @@ __global__ void __launch_bounds__(256) wino24_pack_kernel(const WinoPackJob* __r
     for (int i = 0; i < 9; ++i) g[i / 3][i % 3] = 0.f;
     if (nl >= 0 && kl >= 0) {
         const float* s = J.dgrad ? J.w + ((size_t)kl * J.N + nl) * 9 : J.w + ((size_t)nl * J.K + kl) * 9;
+        const float ks = J.kscale ? J.kscale[k] : 1.f;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) g[i / 3][i % 3] = J.dgrad ? s[8 - i] : s[i];
+        for (int i = 0; i < 9; ++i) g[i / 3][i % 3] = (J.dgrad ? s[8 - i] : s[i]) * ks;
     }
     // rows: G4 = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] (row 2 carries the sign of the kernel's row transform)
     float t[4][3];
@@ -448,12 +464,18 @@ __global__ void __launch_bounds__(256) wino24_pack_kernel(const WinoPackJob* __r
 
 using namespace clamd;
 
+int clamd_launch_wino24_pack(const void* jobs_dev, int njobs, int total_blocks, const clamd::FoldBias* fold, hipStream_t stream) {
+    if (njobs <= 0 || total_blocks <= 0) return clamd_fail("wino24_pack: empty job table");
+    const clamd::FoldBias f = fold ? *fold : clamd::FoldBias{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    hipLaunchKernelGGL(clamd::wino24_pack_kernel, dim3(total_blocks + (fold ? fold->Cout_p : 0)), dim3(256), 0, stream, (const clamd::WinoPackJob*)jobs_dev, njobs,
+                       total_blocks, f);
+    return clamd_check_launch("wino24_pack");
+}
+
 extern "C" {
 
 int clamd_wino24_pack(const void* jobs_dev, int njobs, int total_blocks, void* stream) {
-    if (njobs <= 0 || total_blocks <= 0) return clamd_fail("wino24_pack: empty job table");
-    hipLaunchKernelGGL(wino24_pack_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const WinoPackJob*)jobs_dev, njobs);
-    return clamd_check_launch("wino24_pack");
+    return clamd_launch_wino24_pack(jobs_dev, njobs, total_blocks, nullptr, (hipStream_t)stream);
 }
 
 #ifdef CLAMD_DIAG
@@ -473,7 +495,9 @@ int clamd_conv3x3_winograd24(const float* x, int x_ldc, const float* w_wino, con
     if ((long long)H * W * x_ldc * 4 >= (1ll << 31) || (long long)24 * Cout_p * Cin_p * 4 >= (1ll << 31))
         return clamd_fail("conv3x3_winograd24: image or filter exceeds 2^31 bytes");
     if (int e = clamd_check_tuning(tune)) return e;
-    WinoParams p{x, x_ldc, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 1, 0};
+    if ((relu & ~3) || ((relu & CLAMD_BIAS_BORDER_CLASSES) && !bias)) return clamd_fail("conv3x3_winograd24: bad relu flags (bit 1 needs the [9][Cout_p] bias table)");
+    WinoParams p{x, x_ldc, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu & 1, 1, 0};
+    p.bias_classes = (relu & CLAMD_BIAS_BORDER_CLASSES) ? 1 : 0;
     return launch_wino24(p, clamd_tune(tune), stat_rows, (hipStream_t)stream);
 }
 
@@ -507,7 +531,11 @@ int launch_wino24(WinoParams p, const clamd_tuning& tn, int stat_rows, hipStream
     p.nblk = (int)(tiles * ntn);
     const unsigned grid = tn.wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_usable_cus(tn)) : (unsigned)p.nblk;
     const bool ragged = (p.H % ph) != 0 || (p.W % pw) != 0 || (p.Np % 64) != 0;
-#define W24_LAUNCH(TXN_, RG_) hipLaunchKernelGGL((wino24_kernel<TXN_, RG_>), dim3(grid), dim3(256), 0, stream, p)
+#define W24_LAUNCH(TXN_, RG_)                                                                                          \
+    do {                                                                                                               \
+        if (p.bias_classes) hipLaunchKernelGGL((wino24_kernel<TXN_, RG_, true>), dim3(grid), dim3(256), 0, stream, p);  \
+        else hipLaunchKernelGGL((wino24_kernel<TXN_, RG_, false>), dim3(grid), dim3(256), 0, stream, p);               \
+    } while (0)
     if (pw == 32) { if (ragged) W24_LAUNCH(8, true); else W24_LAUNCH(8, false); }
     else { if (ragged) W24_LAUNCH(4, true); else W24_LAUNCH(4, false); }
 #undef W24_LAUNCH

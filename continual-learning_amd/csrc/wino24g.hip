@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
 // input alternates between two register sets (no copies), the filter sets are refilled two chunks ahead behind their MFMAs and the
 // stream runs on into the next tile.  Same V formulas, same MFMA chains, same epilogue: bit-identical to wino24_kernel.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TXN, bool RAGGED, bool SUMS>
+template <int TXN, bool RAGGED, bool SUMS, bool CLS = false>      // CLS: bias from a border-class table (WinoParams::bias_classes)
 __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
     constexpr int TYN = 32 / TXN;
     constexpr int PW = 4 * TXN, PH = 2 * TYN;
@@ -714,6 +714,7 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
         float* const ex = reinterpret_cast<float*>(smem);
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();
         const bool plain = !p.relu && !p.bias && !p.stats;
+        const bool edge_tile = CLS && (y0 == 0 || x0 == 0 || y0 + PH >= p.H || x0 + PW >= p.W);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             float* const exb = ex + nt * EXB;
@@ -736,7 +737,13 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
             const float* const exb = ex + nt * EXB;
             const int n = n0 + 32 * nt + 4 * ng;
             float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias && n < p.Np) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+            if (p.bias && n < p.Np) bias4 = *reinterpret_cast<const float4*>(p.bias + (CLS ? 4 * p.Np : 0) + n);   // 4: interior
+            float4 bm1 = bias4;                 // bias of the thread's two output rows (pp = 0: bias4, pp = 1: bm1), interior column class
+            if (edge_tile && n < p.Np) {        // tile-uniform branch: a folded BatchNorm's shift term depends on which taps read padding
+                const int ya = y0 + 2 * (tl / TXN);
+                bias4 = *reinterpret_cast<const float4*>(p.bias + ((ya == 0 ? 0 : (ya == p.H - 1 ? 6 : 3)) + 1) * p.Np + n);
+                bm1 = *reinterpret_cast<const float4*>(p.bias + ((ya + 1 == p.H - 1 ? 6 : 3) + 1) * p.Np + n);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 R[4];
@@ -752,11 +759,14 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
                         o.x = R[1].x - R[2].x - R[3].x; o.y = R[1].y - R[2].y - R[3].y;
                         o.z = R[1].z - R[2].z - R[3].z; o.w = R[1].w - R[2].w - R[3].w;
                     }
-                    if (!plain) {
-                        o.x = fmaxf(o.x + bias4.x, relu_lo); o.y = fmaxf(o.y + bias4.y, relu_lo);
-                        o.z = fmaxf(o.z + bias4.z, relu_lo); o.w = fmaxf(o.w + bias4.w, relu_lo);
-                    }
                     const int yy = y0 + 2 * oty + pp, xx = x0 + 4 * otx + q;
+                    if (!plain) {
+                        float4 b4 = pp ? bm1 : bias4;
+                        if (edge_tile && n < p.Np && (q == 0 || q == 3) && (xx == 0 || xx == p.W - 1))      // first / last pixel of an image row
+                            b4 = *reinterpret_cast<const float4*>(p.bias + border_class(yy, xx, p.H, p.W) * p.Np + n);
+                        o.x = fmaxf(o.x + b4.x, relu_lo); o.y = fmaxf(o.y + b4.y, relu_lo);
+                        o.z = fmaxf(o.z + b4.z, relu_lo); o.w = fmaxf(o.w + b4.w, relu_lo);
+                    }
                     if (!RAGGED || (yy < p.H && xx < p.W)) {
                         *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = o;
                         if constexpr (SUMS) bsum.add(nt, o, yv[q * 2 + pp]);
@@ -1086,6 +1096,7 @@ int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const floa
         return clamd_fail("conv3x3_winograd24_pre: transformed input exceeds 2^32 bytes or filter 2^31 bytes");
     if ((stats || bn_sums) && stat_rows != clamd_winograd24_stat_rows(B, H, W, Cout_p, tn))
         return clamd_fail("conv3x3_winograd24_pre: stat_rows does not match clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD24, ...)");
+    if (relu & ~1) return clamd_fail("conv3x3_winograd24_pre: relu must be 0 or 1 (no border-class bias here)");
     WinoParams p{v, 0, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 1, 0};
     p.bn_y = bn_y; p.bn_sums = bn_sums;
     p.band = wino_band(tiles, ntn, 3.0 * B * H * W * Cin_p, 24.0 * Cin_p * Cout_p, tn.wino_band);
@@ -1121,8 +1132,12 @@ int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const flo
     if (tiles * ntn > 0x7fffffff) return clamd_fail("conv3x3_winograd24_direct_filters: grid out of range");
     if ((stats || bn_sums) && stat_rows != clamd_winograd24_stat_rows(B, H, W, Cout_p, tn))
         return clamd_fail("conv3x3_winograd24_direct_filters: stat_rows does not match clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD24, ...)");
-    WinoParams p{x, x_ldc, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 1, 0};
+    if ((relu & ~3) || ((relu & CLAMD_BIAS_BORDER_CLASSES) && !bias))
+        return clamd_fail("conv3x3_winograd24_direct_filters: bad relu flags (bit 1 needs the [9][Cout_p] bias table)");
+    WinoParams p{x, x_ldc, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu & 1, 1, 0};
     p.bn_y = bn_y; p.bn_sums = bn_sums;
+    p.bias_classes = (relu & CLAMD_BIAS_BORDER_CLASSES) ? 1 : 0;
+    if (p.bias_classes && bn_sums) return clamd_fail("conv3x3_winograd24_direct_filters: the border-class bias (forward) and bn_sums (data gradient) exclude each other");
     p.band = wino_band(tiles, ntn, (double)B * H * W * Cin_p, 24.0 * Cin_p * Cout_p, tn.wino_band);
     p.nblk = (int)(tiles * ntn);
     const unsigned grid = tn.wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_usable_cus(tn)) : (unsigned)p.nblk;
@@ -1133,6 +1148,7 @@ int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const flo
 #define W24H_LAUNCH(TXN_, RG_)                                                                                         \
     do {                                                                                                               \
         if (bn_sums) hipLaunchKernelGGL((wino24h_kernel<TXN_, RG_, true>), dim3(grid), dim3(256), 0, s, p);            \
+        else if (p.bias_classes) hipLaunchKernelGGL((wino24h_kernel<TXN_, RG_, false, true>), dim3(grid), dim3(256), 0, s, p); \
         else hipLaunchKernelGGL((wino24h_kernel<TXN_, RG_, false>), dim3(grid), dim3(256), 0, s, p);                   \
     } while (0)
     if (pw == 32) { if (ragged) W24H_LAUNCH(8, true); else W24H_LAUNCH(8, false); }

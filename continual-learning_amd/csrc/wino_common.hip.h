@@ -18,6 +18,8 @@ struct WinoParams {
     // post-ReLU activation [B,H,W,Np] (dense), bn_sums = partial rows [row][5][Np] of the five sums of bn_bwd_reduce_kernel
     const float* bn_y = nullptr;
     float* bn_sums = nullptr;
+    // forward launches behind a folded BatchNorm (clamd_bn_fold_bias): bias is a [9][Np] table indexed by the border class of the output pixel
+    int bias_classes = 0;
 };
 
 // One filter-transform job = one GEMM operand: dst[(k/8)*P + xi][n][k%8] = (G g G^T)[xi] (P = 16 or 24 planes) with
@@ -29,6 +31,7 @@ struct WinoPackJob {
     int n_seg0, n_seg0p, k_seg0, k_seg0p;
     int dgrad;                        // 0: g = w[n][k], src [N][K][3][3]; 1: g = flip(w[k][n]), src [K][N][3][3]
     int block0;                       // first workgroup of this job
+    const float* kscale;              // optional [Kp]: g is multiplied by kscale[physical k] before the transform (bnfold.hip)
 };
 
 __device__ inline int wn_phys2log(int p, int seg0, int seg0p, int L) {

@@ -11,11 +11,11 @@ from ._lib import call, ptr
 TORCH_DT = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.SPLIT: torch.float32}
 
 _PACK_DT = np.dtype({'names': ['src', 'dst', 'T', 'Np', 'Kp', 'N', 'K', 'st', 'sn', 'sk', 'dt', 'dn', 'dk',
-                               'n_seg0', 'n_seg0p', 'k_seg0', 'k_seg0p', 'flip', 'dst_f32', 'block0', 'kc'],
+                               'n_seg0', 'n_seg0p', 'k_seg0', 'k_seg0p', 'flip', 'dst_f32', 'block0', 'kc', 'kscale'],
                      'formats': ['u8', 'u8', 'i4', 'i4', 'i4', 'i4', 'i4', 'i8', 'i8', 'i8', 'i8', 'i8', 'i8',
-                                 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4'],
-                     'offsets': [0, 8, 16, 20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 88, 92, 96, 100, 104, 108, 112, 116],
-                     'itemsize': 120})
+                                 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'u8'],
+                     'offsets': [0, 8, 16, 20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 88, 92, 96, 100, 104, 108, 112, 116, 120],
+                     'itemsize': 128})
 
 
 def cpad(c):
@@ -34,22 +34,24 @@ class PackTable:
         self.dcode = dcode
         self.kc = self.KC[dcode]
 
-    def add(self, src, dst, T, Np, Kp, N, K, st, sn, sk, dt, dn, dk, nseg=None, kseg=None, flip=0, f32=0, kc=0):
+    def add(self, src, dst, T, Np, Kp, N, K, st, sn, sk, dt, dn, dk, nseg=None, kseg=None, flip=0, f32=0, kc=0, kscale=None):
         nseg = nseg or (N, Np)
         kseg = kseg or (K, Kp)
         self.jobs.append((src.data_ptr(), dst.data_ptr(), T, Np, Kp, N, K, st, sn, sk, dt, dn, dk,
-                          nseg[0], nseg[1], kseg[0], kseg[1], flip, f32, 0, kc))
+                          nseg[0], nseg[1], kseg[0], kseg[1], flip, f32, 0, kc, kscale.data_ptr() if kscale is not None else 0))
 
     # ---- the layouts of include/clamd.h ----
-    def conv3x3(self, w, wf, wd, cin_segs, cout):
+    def conv3x3(self, w, wf, wd, cin_segs, cout, kscale=None):
         """w [Cout][Cin][3][3] fp32 -> wf [Cin_p/kc][9][Cout_p][kc] (forward) and wd [Cout_p/kc][9][Cin_p][kc] (data
         gradient, taps flipped): K-chunk-major, so the [tap][n] slab of one 64-byte K-chunk is contiguous.
-        cin_segs: [(logical, physical), ...] one or two channel segments (concat inputs)."""
+        cin_segs: [(logical, physical), ...] one or two channel segments (concat inputs).
+        kscale (fp32 [Cin_p], optional): the forward filters are multiplied by kscale[ci] (a folded BatchNorm, bnfold.hip)."""
         cin = sum(s[0] for s in cin_segs)
         cin_p = sum(s[1] for s in cin_segs)
         cout_p = cpad(cout)
         seg = (cin_segs[0][0], cin_segs[0][1]) if len(cin_segs) == 2 else None
-        self.add(w, wf, 9, cout_p, cin_p, cout, cin, 1, cin * 9, 9, cout_p * cin_p, cin_p, 1, kseg=seg, kc=self.kc)
+        if wf is not None:
+            self.add(w, wf, 9, cout_p, cin_p, cout, cin, 1, cin * 9, 9, cout_p * cin_p, cin_p, 1, kseg=seg, kc=self.kc, kscale=kscale)
         if wd is not None:
             self.add(w, wd, 9, cin_p, cout_p, cin, cout, 1, 9, cin * 9, cin_p * cout_p, cout_p, 1, nseg=seg, flip=1,
                      kc=self.kc)
@@ -92,9 +94,9 @@ class PackTable:
         call('clamd_pack', ptr(self.dev_table), len(self.jobs), self.nblocks, self.dcode, stream or _lib.stream_ptr())
 
 
-_WINO_DT = np.dtype({'names': ['w', 'dst', 'Np', 'Kp', 'N', 'K', 'n_seg0', 'n_seg0p', 'k_seg0', 'k_seg0p', 'dgrad', 'block0'],
-                     'formats': ['u8', 'u8', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4'],
-                     'offsets': [0, 8, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52], 'itemsize': 56})
+_WINO_DT = np.dtype({'names': ['w', 'dst', 'Np', 'Kp', 'N', 'K', 'n_seg0', 'n_seg0p', 'k_seg0', 'k_seg0p', 'dgrad', 'block0', 'kscale'],
+                     'formats': ['u8', 'u8', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'u8'],
+                     'offsets': [0, 8, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56], 'itemsize': 64})
 
 
 class WinoPackTable:
@@ -106,17 +108,18 @@ class WinoPackTable:
         self.jobs = []
         self.planes = planes
 
-    def conv3x3(self, w, wf, wd, cin_segs, cout):
+    def conv3x3(self, w, wf, wd, cin_segs, cout, kscale=None):
         """w [Cout][Cin][3][3] fp32 -> wf [Cin_p/8][planes][Cout_p][8] (forward) and wd [Cout_p/8][planes][Cin_p][8] (data
-        gradient: tap-flipped, transposed).  cin_segs as in PackTable.conv3x3."""
+        gradient: tap-flipped, transposed).  cin_segs and kscale as in PackTable.conv3x3."""
         cin = sum(s[0] for s in cin_segs)
         cin_p = sum(s[1] for s in cin_segs)
         cout_p = cpad(cout)
         seg = (cin_segs[0][0], cin_segs[0][1]) if len(cin_segs) == 2 else (cin, cin_p)
         if wf is not None:
-            self.jobs.append((w.data_ptr(), wf.data_ptr(), cout_p, cin_p, cout, cin, cout, cout_p, seg[0], seg[1], 0, 0))
+            self.jobs.append((w.data_ptr(), wf.data_ptr(), cout_p, cin_p, cout, cin, cout, cout_p, seg[0], seg[1], 0, 0,
+                              kscale.data_ptr() if kscale is not None else 0))
         if wd is not None:
-            self.jobs.append((w.data_ptr(), wd.data_ptr(), cin_p, cout_p, cin, cout, seg[0], seg[1], cout, cout_p, 1, 0))
+            self.jobs.append((w.data_ptr(), wd.data_ptr(), cin_p, cout_p, cin, cout, seg[0], seg[1], cout, cout_p, 1, 0, 0))
 
     def finalize(self, device):
         lib = _lib.load()

@@ -47,6 +47,17 @@ PRETRANSFORM = {'0': False, 'false': False, '1': True, 'true': True}.get(str(PRE
 # BatchNorm output (the first unit of enc3/enc4/dec1/dec2/dec3): one HBM pass less per unit.  False = always run clamd_bn_apply.
 FOLD_BN_INTO_TRANSFORM = os.environ.get('CLAMD_FOLD_BN', '1') != '0'
 NARROW_DIRECT = os.environ.get('CLAMD_NARROW_DIRECT', '1') != '0'
+# The narrow layers (in-kernel transform / bf16 direct kernels) cannot take the affine on load -- their loops are VALU-bound -- so there
+# the BatchNorm between the two convolutions of a block (models/unet.py:13-18) is folded ALGEBRAICALLY into the second one
+# (csrc/bnfold.hip): filters packed with scale[ci] once the statistics are final, the shift as a border-class bias table in the
+# epilogue, the weight gradient fixed up from the gradient's border sums.  The normalised tensor is never written: the bn_apply pass
+# of the first unit of enc1 / enc2 / dec4 / last (268 + 268 MB at level 0 in fp32) leaves the forward pass.  Up to
+# FOLD_FILTERS_MAX_CHANNELS input channels: the per-step filter pack is on the critical path, the apply pass shrinks with depth.
+# Interleaved A/B against the previous build (bench.py, ms per step): fp32 21.30 -> 21.08, bf16x3 15.39 -> 15.19, bf16 6.73 -> 6.79: in bf16 the
+# apply passes are half the bytes while the pack launch (12 us), the table lookups of the border tiles and the two fix-up launches cost the
+# same, so 'auto' folds on the fp32-storage paths only; True = every compute dtype; False = never.
+FOLD_BN_INTO_FILTERS = {'0': False, 'false': False, 'all': True, 'true': True}.get(os.environ.get('CLAMD_FOLD_FILTERS', 'auto').lower(), 'auto')
+FOLD_FILTERS_MAX_CHANNELS = int(os.environ.get('CLAMD_FOLD_FILTERS_MAX_CHANNELS', '128'))
 # fp32 path: ConvTranspose2d forward / data gradient as register-blocked GEMMs with operands loaded straight into the MFMA operand
 # registers (csrc/pw_direct.hip) instead of the LDS-staged 256-pixel x 64-channel tiles of igemm_kernel.
 # BUILT, MEASURED, OFF BY DEFAULT.  Alone the kernels are faster (tools/convt_direct_ab.py: forward 0.67 -> 0.64 ms, data gradient
@@ -490,6 +501,17 @@ class _Engine:
             # transformed input, the affine is applied by the transform itself and a's bn_apply pass (and `ua`) disappears
             if FOLD_BN_INTO_TRANSFORM and b.pre_f and b.pre_w and a.pooled is None and b.xin is a.out:
                 a.apply_folded, b.fold_src = True, a
+        for st in self.stages:
+            a, b = st['convs']
+            # ... and where b transforms inside its kernel (or is a bf16 direct kernel): the algebraic fold of bnfold.hip
+            b.fold_a, a.fold_a, a.fold_on, b.fold_on, a.apply_in_filters, b.apply_in_filters = None, None, False, False, False, False
+            if ((FOLD_BN_INTO_FILTERS is True or (FOLD_BN_INTO_FILTERS == 'auto' and self.dcode != _lib.BF16))
+                    and not a.apply_folded and not b.pre_f and a.pooled is None and b.xin is a.out and len(b.cin_segs) == 1
+                    and not a.split and not b.split and min(b.h, b.w_) >= 2 and b.cin_p <= FOLD_FILTERS_MAX_CHANNELS):
+                b.fold_a = a      # one direction only: a cycle between units would keep the engine's buffers alive until the garbage collector runs
+                b.cb = torch.zeros(9, b.cout_p, dtype=torch.float32, device=dev)
+        nfw = max([lib.clamd_bn_fold_wgrad_workspace_bytes(B, u.cout_p) // 4 for u in convs if u.fold_a is not None] + [0])
+        self.fold_ws = torch.empty(nfw, dtype=torch.float32, device=dev) if nfw else None
         for st in self.stages:      # half-batch pipeline: a's second-half apply may run under b's first-half convolution; across stages
             a, b = st['convs']     # only along the encoder (b.pooled feeds the next stage's first convolution directly)
             a.pipe_next = a.split and b.split
@@ -529,7 +551,7 @@ class _Engine:
         self.vg = torch.empty(nvg, dtype=torch.float32, device=dev) if nvg else None
         self.yt = torch.empty(nyt, dtype=torch.float32, device=dev) if nyt else None
         # third stream + a second operand buffer: the transform of unit u runs while the GEMM of unit u+1 still reads the other buffer
-        self.x3_stream = (_third_stream(dev) if (WGRAD_XFORM_STREAM and WGRAD_STREAM and dev.type == 'cuda' and nyt) else None)
+        self.x3_stream = (_third_stream(dev) if (WGRAD_XFORM_STREAM and WGRAD_STREAM and dev.type == 'cuda' and (nyt or nfw)) else None)
         self.yt2 = torch.empty(nyt, dtype=torch.float32, device=dev) if (nyt and self.x3_stream is not None) else None
         self._yt_flip = 0
         self._yt_ev = [None, None]
@@ -553,6 +575,11 @@ class _Engine:
         B, dc, tn = self.B, self.dcode, self.tuning
         rows = _lib.stat_rows
         sizes = []
+        for u in self.convs:      # which kernel runs a fold candidate depends on the tuning: F(2x4) Winograd / the persistent direct kernel take the table
+            u.fold_on = u.fold_a is not None and (u.w24 if u.wino else
+                                                  bool(_lib.load().clamd_conv3x3_border_bias_ok(B, u.h, u.w_, u.cin_p, u.cout_p, dc, tune_ptr(tn))))
+            if u.fold_a is not None:
+                u.fold_a.apply_in_filters = u.fold_on      # the producer's bn_apply pass is skipped
         for u in self.convs:
             Bl = B // 2 if u.split else B          # images per forward launch (half-batch pipeline: two launches, rows concatenated)
             if u.im2col:
@@ -598,12 +625,21 @@ class _Engine:
             if u.im2col:
                 tab.head(u.w, u.wf, None, 9 * u.cin, u.cout)     # [Cout][Cin*9] is already the (c*9 + tap) K order
             elif u.wino:
-                wtab[(24 if u.w24 else 16, u.pack_late)].conv3x3(u.w, u.wf, None, u.cin_segs, u.cout)
+                if u.fold_a is None:
+                    wtab[(24 if u.w24 else 16, u.pack_late)].conv3x3(u.w, u.wf, None, u.cin_segs, u.cout)
                 if u.wd is not None:
                     wtab[(24 if u.w24d else 16, u.pack_late)].conv3x3(u.w, None, u.wd, u.cin_segs, u.cout)
             else:
-                tab.conv3x3(u.w, u.wf, u.wd, u.cin_segs, u.cout)
+                tab.conv3x3(u.w, None if u.fold_a is not None else u.wf, u.wd, u.cin_segs, u.cout)
             tab.vector(u.b, u.bias_p, u.cout)
+            if u.fold_a is not None:
+                # the forward filters of a fold candidate are packed inside the step, behind the producer's bn_finalize: with its scale
+                # (fold on) or plain (a tuning that runs a kernel without the border-class epilogue)
+                u.fold_table, u.plain_table = [
+                    (WinoPackTable(24 if u.w24 else 16) if u.wino else PackTable(self.dcode)) for _ in range(2)]
+                u.fold_table.conv3x3(u.w, u.wf, None, u.cin_segs, u.cout, kscale=u.fold_a.vec[0])
+                u.plain_table.conv3x3(u.w, u.wf, None, u.cin_segs, u.cout)
+                u.fold_table.finalize(self.dev); u.plain_table.finalize(self.dev)
         for s in self.stages:
             t = s.get('tail')
             if t is None:
@@ -671,6 +707,7 @@ class _Engine:
             for u in st['convs']:
                 if not u.split:
                     self._fwd_pre(u, s, None)
+                    self._fwd_fold(u, s)
                     self._fwd_conv(u, training, s, None)
                     self._fwd_finalize(u, training, s)
                     self._fwd_post(u, s, None)
@@ -776,6 +813,20 @@ class _Engine:
         _timed('wino_transform', 0.0, 16 * Bl * u.h * u.w_ * u.cin_p,        # reads the activation once, writes 3x its size
                'clamd_winograd24_transform_input', ptr(self._hv(xsrc, hf)), xldc, ptr(fs), ptr(fh), ptr(vx), Bl, u.h, u.w_, u.cin_p, s)
 
+    def _fwd_fold(self, u, s):
+        """Forward filters of a fold candidate (bnfold.hip): packed here, behind the producer's bn_finalize -- with its scale and the
+        border-class bias table when the fold is on, plain otherwise."""
+        a = u.fold_a
+        if a is None:
+            return
+        if not u.fold_on:
+            t = u.plain_table
+            t.run(s) if u.wino else t.run(self.dcode, s)
+            return
+        t = u.fold_table        # one launch: the filters times the producer's scale, and the bias table from its shift
+        call('clamd_bn_fold_pack', (24 if u.w24 else 16) if u.wino else 0, ptr(t.dev_table), len(t.jobs), t.nblocks, self.dcode,
+             ptr(u.w), ptr(a.vec[1]), ptr(u.b), ptr(u.cb), u.cout, u.cin, u.cout_p, s)
+
     def _fwd_conv(self, u, training, s, hf):
         """conv3x3 + bias + ReLU (+ BatchNorm statistics rows) of unit u on the whole batch or one half of it."""
         dc, tp = self.dcode, tune_ptr(self.tuning)
@@ -787,6 +838,9 @@ class _Engine:
             k = rows * 2 * u.cout_p
             st = u.stats if hf is None else u.stats[hf * k:(hf + 1) * k]
         xin, y = self._hv(u.xin, hf), self._hv(u.y, hf)
+        xin_ldc, bias, relu = u.xin_ldc, u.bias_p, 1
+        if u.fold_on:      # reads the producer's conv+ReLU output; its BatchNorm lives in the filters and in the bias table
+            xin, xin_ldc, bias, relu = u.fold_a.y, u.fold_a.cout_p, u.cb, 3
         flops = 2.0 * Bl * u.h * u.w_ * 9 * u.cin * u.cout
         nbytes = self.esize * (Bl * u.h * u.w_ * (u.cin + u.cout) + 9 * u.cin * u.cout)
         if u.im2col:
@@ -812,11 +866,11 @@ class _Engine:
             else:
                 name = ('clamd_conv3x3_winograd24_direct_filters' if u.direct_f else 'clamd_conv3x3_winograd24') if u.w24 else 'clamd_conv3x3_winograd'
                 extra = (None, None) if u.direct_f else ()           # bn_y, bn_sums: data-gradient launches only
-                _timed('igemm_conv3x3', flops, nbytes, name, ptr(xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p, ptr(st), rows,
-                       *extra, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
+                _timed('igemm_conv3x3', flops, nbytes, name, ptr(xin), xin_ldc, ptr(u.wf), ptr(bias), ptr(y), u.cout_p, ptr(st), rows,
+                       *extra, Bl, u.h, u.w_, u.cin_p, u.cout_p, relu, tp, s)
         else:
-            _timed('igemm_conv3x3', flops, nbytes, 'clamd_conv3x3', ptr(xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p,
-                   ptr(st), None, None, rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, u.m_fastest, dc, tp, s)
+            _timed('igemm_conv3x3', flops, nbytes, 'clamd_conv3x3', ptr(xin), xin_ldc, ptr(u.wf), ptr(bias), ptr(y), u.cout_p,
+                   ptr(st), None, None, rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, relu, u.m_fastest, dc, tp, s)
 
     def _fwd_finalize(self, u, training, s):
         v = u.vec
@@ -826,6 +880,8 @@ class _Engine:
     def _fwd_post(self, u, s, hf):
         """BatchNorm apply (+ max-pool, concat placement) of unit u on the whole batch or one half of it."""
         if u.apply_folded:          # the only reader of the BatchNorm output is the next convolution's input transform
+            return
+        if u.apply_in_filters:      # ... or its filters and bias table (bnfold.hip)
             return
         v = u.vec
         Bl = self.B if hf is None else self.B // 2
@@ -846,6 +902,7 @@ class _Engine:
         m = self.model
         s = _lib.stream_ptr()
         self._wg_used = False
+        self._x3_fold = False
         self._pack_pending = 0
         self._yt_ev = [None, None]      # events of THIS backward pass only (the previous one was joined before it returned; a captured
         self._x3_ev = None              # graph must not wait on an event recorded outside the capture)
@@ -906,7 +963,12 @@ class _Engine:
             for u in reversed(st['convs']):
                 self._conv_bwd(u, s)
             if sync is not None:
+                if self._x3_fold:       # the stage's fixed-up weight gradients belong to the bucket: the second stream (which stage_done waits for) joins the third
+                    self.wg_stream.wait_stream(self.x3_stream)
+                    self._x3_fold = False
                 sync.stage_done(self, st)
+        if self._x3_fold:
+            self.wg_stream.wait_stream(self.x3_stream)
         if self._wg_used:
             torch.cuda.current_stream().wait_stream(self.wg_stream)       # every gradient is complete for whoever comes next
         gf = self.gflat
@@ -1018,10 +1080,26 @@ class _Engine:
                    'clamd_wgrad_winograd24_pre', ptr(u.gz), u.cout_p, ptr(u.vx), ptr(self.yt), ptr(self.ws), self.ws_bytes,
                    g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, tp, sw)
         elif u.wino:
+            xin, xin_ldc = (u.fold_a.y, u.fold_a.cout_p) if u.fold_on else (u.xin, u.xin_ldc)
             _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
-                   'clamd_wgrad_winograd24' if u.w24g else 'clamd_wgrad_winograd', ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
+                   'clamd_wgrad_winograd24' if u.w24g else 'clamd_wgrad_winograd', ptr(u.gz), u.cout_p, ptr(xin), xin_ldc, ptr(self.ws), self.ws_bytes,
                    g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, tp, sw)
         else:
+            xin, xin_ldc = (u.fold_a.y, u.fold_a.cout_p) if u.fold_on else (u.xin, u.xin_ldc)
             _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
-                   'clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
+                   'clamd_wgrad', _lib.WGRAD_CONV3, ptr(u.gz), u.cout_p, ptr(xin), xin_ldc, ptr(self.ws), self.ws_bytes,
                    g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, dc, tp, sw)
+        if u.fold_on:
+            # the weight gradient ran on the producer's conv+ReLU output r instead of x = scale * r + shift: dW = scale * dWr + shift * S, S from
+            # the border sums of gz and the conv-bias gradient bn_bwd_finalize wrote above (bnfold.hip); same stream, in place
+            a = u.fold_a
+            fs = sw
+            if (self.x3_stream is not None and self.wg_stream is not None and KERNEL_TIMING is None and self._x3_allowed()
+                    and not torch.cuda.is_current_stream_capturing()):
+                # two latency-bound launches of a few microseconds: on the third stream they run beside the next unit's weight gradient
+                # instead of in front of it (the second stream is the longer one at the end of the bf16 backward pass)
+                ev = torch.cuda.Event(); ev.record(self.wg_stream)
+                self.x3_stream.wait_event(ev)
+                fs, self._x3_fold = self.x3_stream.cuda_stream, True
+            call('clamd_bn_fold_wgrad', ptr(u.gz), u.cout_p, g[u.keys[1]], ptr(a.vec[0]), ptr(a.vec[1]), g[u.keys[0]], ptr(self.fold_ws),
+                 4 * self.fold_ws.numel(), B, u.h, u.w_, u.cout_p, u.cout, u.cin, dc, fs)

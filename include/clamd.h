@@ -90,10 +90,38 @@ int clamd_stat_rows(int op, int B, int H, int W, int Cin_p, int Cout_p, int dtyp
  *   bn_y/bn_sums (optional, data-gradient launches): when y of THIS launch is the gradient w.r.t. a BatchNorm output,
  *   also accumulate the five per-channel sums of clamd_bn_bwd_reduce (bn_y = that unit's saved activation
  *   [B,H,W,Cout_p], bn_sums = [row][5][Cout_p]) in the epilogue, so the separate reduce pass is not needed.
- *   stat_rows = clamd_stat_rows(CLAMD_OP_CONV3X3, ...) (ignored when neither stats nor bn_sums is given). */
+ *   stat_rows = clamd_stat_rows(CLAMD_OP_CONV3X3, ...) (ignored when neither stats nor bn_sums is given).
+ *   relu: bit 0 = apply ReLU; bit 1 (CLAMD_BIAS_BORDER_CLASSES, forward launches behind a folded BatchNorm, see
+ *   clamd_bn_fold_bias below) = `bias` is a [9][Cout_p] table indexed by the border class of the output pixel.  Bit 1 is taken by
+ *   clamd_conv3x3 where clamd_conv3x3_border_bias_ok() says so (the persistent kernel), by clamd_conv3x3_winograd24 and by
+ *   clamd_conv3x3_winograd24_direct_filters; every other entry point rejects it. */
+enum { CLAMD_RELU = 1, CLAMD_BIAS_BORDER_CLASSES = 2 };
 int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
                   float* stats, const void* bn_y, float* bn_sums, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p,
                   int relu, int m_fastest, int dtype, const clamd_tuning* tune, void* stream);
+int clamd_conv3x3_border_bias_ok(int B, int H, int W, int Cin_p, int Cout_p, int dtype, const clamd_tuning* tune);
+/* ---- nn.BatchNorm2d folded into the nn.Conv2d(k3,p1) behind it (models/unet.py:15-16,30-31; bnfold.hip) ---------------------
+ * x = scale * r + shift with r the producer's saved conv+ReLU output and scale / shift from clamd_bn_finalize:
+ *   conv3x3(x, W) = conv3x3(r, W * scale[ci]) + the sum of T[co][tap] = sum_ci W[co][ci][tap] * shift[ci] over the taps that read
+ *   inside the image (nn.Conv2d pads x, not r, with zeros) -- nine border classes: 3 * (0 top row, 1 interior, 2 bottom row) +
+ *   (0 left column, 1 interior, 2 right column); H, W >= 2.
+ * The caller packs the filters with `kscale` = scale (PackJob / WinoPackJob, ops.PackTable / ops.WinoPackTable), fills the table
+ * with clamd_bn_fold_bias (table[class][co] = bias[co] + sum of T over the class's valid taps; padded channels 0) and launches
+ * the convolution on r with relu | CLAMD_BIAS_BORDER_CLASSES: the clamd_bn_apply pass over the producer's output is not needed.
+ * Weight gradient (trainer.py:175): run the weight-gradient entry point on r instead of x, then clamd_bn_fold_wgrad in place:
+ *   dW[co][ci][tap] = scale[ci] * dW[co][ci][tap] + shift[ci] * S[tap][co],  S = sum of gz over the pixels whose tap reads inside
+ *   the image = sum_gz (the convolution's bias gradient, as clamd_bn_bwd_finalize writes it) - border row - border column + corner,
+ *   the border sums taken here from gz in a fixed order.  dw = [Cout][Cin][3][3] fp32 (the parameter's own layout); workspace >=
+ *   clamd_bn_fold_wgrad_workspace_bytes(B, Cout_p).  The data gradient (w.r.t. x) is unchanged. */
+int clamd_bn_fold_bias(const float* w, const float* shift, const float* bias, float* table, int Cout, int Cin, int Cout_p, void* stream);
+/* the filter pack of that convolution and its bias table in ONE launch (both sit between the producer's clamd_bn_finalize and the
+ * convolution, on the critical path of the forward pass): form 0 = clamd_pack(jobs_dev, njobs, total_blocks, dtype), 16 =
+ * clamd_wino_pack, 24 = clamd_wino24_pack, with the blocks of clamd_bn_fold_bias appended to the grid. */
+int clamd_bn_fold_pack(int form, const void* jobs_dev, int njobs, int total_blocks, int dtype, const float* w, const float* shift,
+                       const float* bias, float* table, int Cout, int Cin, int Cout_p, void* stream);
+size_t clamd_bn_fold_wgrad_workspace_bytes(int B, int Cout_p);
+int clamd_bn_fold_wgrad(const void* gz, int gz_ldc, const float* sum_gz, const float* scale, const float* shift, float* dw,
+                        void* workspace, size_t ws_bytes, int B, int H, int W, int Cout_p, int Cout, int Cin, int dtype, void* stream);
 /* The same convolution (fp32 only; H, W even) by Winograd F(2x2,3x3): 2.25x fewer multiply-adds, fp32 transforms
  * (relative error vs fp64 3.5e-7 against 2.3e-7 for the direct sum).  w_wino = [Cin_p/8][16][Cout_p][8] written by
  * clamd_wino_pack (jobs: device table of WinoPackJob, see ops.WinoPackTable; the data gradient uses the tap-flipped,

@@ -33,7 +33,7 @@ def test_abi_library_exports_every_declared_symbol(C):
     assert sorted(C._lib.SIGNATURES) == names, 'ctypes signature table and header disagree'
     l = C._lib.load()
     assert l.clamd_version() >= 100
-    assert l.clamd_sizeof_pack_job() == 120 and l.clamd_sizeof_adam_tensor() == 48
+    assert l.clamd_sizeof_pack_job() == 128 and l.clamd_sizeof_adam_tensor() == 48
     assert l.clamd_bn_bwd_nsums() == 5
     assert l.clamd_sizeof_tuning() == ctypes.sizeof(C._lib.Tuning)
 
@@ -157,9 +157,14 @@ def test_engine_geometry_and_pack_table(C):
     w24 = [u for u in wino_units if u.w24]
     assert len(w24) == 15                                   # every width here (64 ... 8) is a multiple of 4: F(2x4,3x3)
     nw = sum(len(t.jobs) for t in e.wino_early + e.wino_late)          # two launches per form: enc1-enc3 first, the rest behind
-    assert sum(len(t.jobs) for t in e.wino_early) == 2 * sum(1 for u in wino_units if not u.pack_late)
-    assert nw == 2 * len(wino_units)
-    assert len(jobs) + nw == 18 * 3 - 1 + 5 * 3
+    # the second convolution of every block here (<= 128 channels) is a candidate for the algebraic BatchNorm fold (bnfold.hip): its
+    # forward filters are packed inside the step by a one-job table of its own (with the producer's scale, or plain)
+    fold = [u for u in e.convs if u.fold_a is not None]
+    assert len(fold) == 9 and all(u.fold_a.apply_in_filters and len(u.fold_table.jobs) == 1 and len(u.plain_table.jobs) == 1 for u in fold)
+    assert all(u.fold_table.jobs[0][-1] == u.fold_a.vec[0].data_ptr() and u.plain_table.jobs[0][-1] == 0 for u in fold)
+    assert sum(len(t.jobs) for t in e.wino_early) == sum(2 - (u.fold_a is not None) for u in wino_units if not u.pack_late)
+    assert nw == 2 * len(wino_units) - sum(1 for u in fold if u.wino)
+    assert len(jobs) + nw + len(fold) == 18 * 3 - 1 + 5 * 3
     assert e.pack_table.nblocks == sum(((j[3] + 31) // 32) * ((j[4] + 31) // 32) for j in jobs)
     assert C.cpad(3) == 32 and C.cpad(21) == 32 and C.cpad(1024) == 1024
 

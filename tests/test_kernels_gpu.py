@@ -538,6 +538,113 @@ def test_conv3x3_winograd24_fp32(C, shape):
             np.testing.assert_allclose(stats2.double().sum(0).cpu().numpy(), stats.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
 
 
+FOLD_SHAPES = [  # B, Cin, Cout, H, W
+    (2, 64, 64, 24, 40),       # 8x32 tiles ragged along x: every tile touches the border
+    (1, 128, 128, 16, 16),     # one 16x16 tile per image: all nine border classes inside one tile
+    (2, 64, 40, 32, 96),       # interior tiles exist (fast path) next to border tiles; padded output channels
+    (3, 40, 64, 64, 64),       # padded input channels (scale / shift of the padding never read as data)
+]
+
+
+@pytest.mark.parametrize('kernel,dcode', [('w24', 0), ('w24h', 0), ('pws', 0), ('pws', 1), ('pws', 2)])
+@pytest.mark.parametrize('shape', FOLD_SHAPES, ids=lambda sh: 'x'.join(str(a) for a in sh))
+def test_batchnorm_folded_into_conv3x3(C, kernel, dcode, shape):
+    """nn.BatchNorm2d folded algebraically into the nn.Conv2d behind it (bnfold.hip; models/unet.py:15-16): filters packed with the
+    per-input-channel scale, the shift as a border-class bias table in the epilogue, the weight gradient fixed up from the
+    gradient's border sums -- against the stock fp64 convolution ON THE NORMALISED TENSOR (zero padding after the affine), at the
+    bounds of the unfolded kernels; statistics rows included; negative and zero scales included."""
+    import torch.nn.functional as F
+    B, cin, cout, H, W = shape
+    rng = np.random.default_rng(321)
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    L = lib.load()
+    T = C.ops.TORCH_DT[dcode]
+    cin_p, cout_p = C.ops.cpad(cin), C.ops.cpad(cout)
+    r = rb(np.maximum(rnd(rng, B, cin, H, W) + 0.3, 0), dcode)                 # a post-ReLU activation as the kernels store it
+    scale = rnd(rng, cin) * 0.8
+    scale[0] = 0.0                                                             # gamma = 0 is legal
+    shift = rnd(rng, cin) * 0.5
+    w = rnd(rng, cout, cin, 3, 3) * (1.0 / np.sqrt(9 * cin))
+    b = rnd(rng, cout)
+    gz = rb(rnd(rng, B, cout, H, W), dcode)
+    x64 = torch.from_numpy(r).double() * torch.from_numpy(scale).double().view(1, -1, 1, 1) + torch.from_numpy(shift).double().view(1, -1, 1, 1)
+    # forward reference: what the compute dtype stores are the FOLDED filters w * scale (the shift term is an fp32 table of the fp32 master filters)
+    wfold = torch.from_numpy(rb(w * scale[None, :, None, None], dcode)).double()
+    shift_img = torch.from_numpy(shift).double().view(1, -1, 1, 1).expand(B, cin, H, W)
+    ref = torch.relu(F.conv2d(torch.from_numpy(r).double(), wfold, None, padding=1)
+                     + F.conv2d(shift_img, torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1)).numpy()
+    xg = x64.clone().requires_grad_(False)
+    wv = torch.from_numpy(w).double().requires_grad_(True)
+    F.conv2d(xg, wv, None, padding=1).backward(torch.from_numpy(gz).double())
+    rgw = wv.grad.numpy()
+
+    rt = nd(C, np.ascontiguousarray(np.pad(r, ((0, 0), (0, cin_p - cin), (0, 0), (0, 0))).transpose(0, 2, 3, 1)), dcode)
+    gzt = nd(C, np.ascontiguousarray(np.pad(gz, ((0, 0), (0, cout_p - cout), (0, 0), (0, 0))).transpose(0, 2, 3, 1)), dcode)
+    sc = torch.full((cin_p,), float('nan'), device='cuda'); sc[:cin] = dev(scale)       # padded entries must never matter
+    sh = torch.full((cin_p,), float('nan'), device='cuda'); sh[:cin] = dev(shift)
+    wt, bt = dev(w), dev(b)
+    table = torch.full((9, cout_p), float('nan'), device='cuda')
+    lib.call('clamd_bn_fold_bias', ptr(wt), ptr(sh), ptr(bt), ptr(table), cout, cin, cout_p, s)
+    y = torch.full((B, H, W, cout_p), 7.0, dtype=T, device='cuda')
+    flags = 1 | 2                                                              # ReLU | CLAMD_BIAS_BORDER_CLASSES
+    if kernel == 'pws':
+        tn = lib.Tuning(igemm_pws=2)
+        if not L.clamd_conv3x3_border_bias_ok(B, H, W, cin_p, cout_p, dcode, tn.ref()):
+            pytest.skip('the persistent kernel declines this shape')
+        wf = torch.zeros(9 * cout_p * cin_p, dtype=T, device='cuda')
+        tab = C.ops.PackTable(dcode); tab.conv3x3(wt, wf, None, [(cin, cin_p)], cout, kscale=sc); tab.finalize('cuda').run(dcode)
+        stats, rows = stat_buf(C, lib.OP_CONV3X3, B, H, W, cin_p, cout_p, dcode, tuning=tn)
+        lib.call('clamd_conv3x3', ptr(rt), cin_p, ptr(wf), ptr(table), ptr(y), cout_p, ptr(stats), None, None, rows, B, H, W, cin_p, cout_p,
+                 flags, 0, dcode, tn.ref(), s)
+        # the other structures refuse the flag instead of ignoring it
+        tn0 = lib.Tuning(igemm_pws=0)
+        with pytest.raises(RuntimeError, match='border-class'):
+            lib.call('clamd_conv3x3', ptr(rt), cin_p, ptr(wf), ptr(table), ptr(y), cout_p, None, None, None, 0, B, H, W, cin_p, cout_p,
+                     flags, 0, dcode, tn0.ref(), s)
+    else:
+        wf = torch.zeros(24 * cout_p * cin_p, device='cuda')
+        tab = C.ops.WinoPackTable(24); tab.conv3x3(wt, wf, None, [(cin, cin_p)], cout, kscale=sc); tab.finalize('cuda').run()
+        stats, rows = stat_buf(C, lib.OP_CONV3X3_WINOGRAD24, B, H, W, cin_p, cout_p, 0)
+        if kernel == 'w24':
+            lib.call('clamd_conv3x3_winograd24', ptr(rt), cin_p, ptr(wf), ptr(table), ptr(y), cout_p, ptr(stats), rows, B, H, W, cin_p, cout_p,
+                     flags, None, s)
+        else:
+            lib.call('clamd_conv3x3_winograd24_direct_filters', ptr(rt), cin_p, ptr(wf), ptr(table), ptr(y), cout_p, ptr(stats), rows, None, None,
+                     B, H, W, cin_p, cout_p, flags, None, s)
+    sync()
+    assert bool(torch.isfinite(table).all()) and float(table[:, cout:].abs().max() if cout < cout_p else 0.0) == 0.0
+    got = C.ops.from_nhwc(y, cout, dcode).cpu().numpy()
+    assert rel_l2(got, ref) < TOL[dcode], rel_l2(got, ref)
+    st = stats.double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=2e-3 if dcode == 1 else 1e-4, atol=2e-2 if dcode == 1 else 1e-3)
+    np.testing.assert_allclose(st[1, :cout], (ref ** 2).sum((0, 2, 3)), rtol=4e-3 if dcode == 1 else 1e-4, atol=2e-2 if dcode == 1 else 1e-3)
+    assert float(nf(C, y, dcode)[..., cout:].abs().max()) == 0.0 if cout < cout_p else True
+
+    # weight gradient on r, then the fix-up in place; twice: bit-identical (fixed-order border sums)
+    sum_gz = dev(gz.astype(np.float64).sum((0, 2, 3)).astype(np.float32))
+    fws = L.clamd_bn_fold_wgrad_workspace_bytes(B, cout_p)
+    fw = torch.empty(fws // 4 + 4, device='cuda')
+    outs = []
+    for _ in range(2):
+        gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
+        if kernel == 'pws':
+            wsb = L.clamd_wgrad_workspace_bytes(0, B, H, W, cout_p, cin_p, dcode)
+            ws = torch.empty(wsb // 4 + 4, device='cuda')
+            lib.call('clamd_wgrad', 0, ptr(gzt), cout_p, ptr(rt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, cin_p, cout, cin,
+                     cout, cout_p, cin, cin_p, dcode, None, s)
+        else:
+            wsb = L.clamd_wgrad_winograd24_workspace_bytes(cout_p, cin_p)
+            ws = torch.empty(wsb // 4 + 4, device='cuda')
+            lib.call('clamd_wgrad_winograd24', ptr(gzt), cout_p, ptr(rt), cin_p, ptr(ws), wsb, ptr(gw), B, H, W, cout_p, cin_p, cout, cin,
+                     cout, cout_p, cin, cin_p, None, s)
+        lib.call('clamd_bn_fold_wgrad', ptr(gzt), cout_p, ptr(sum_gz), ptr(sc), ptr(sh), ptr(gw), ptr(fw), fws, B, H, W, cout_p, cout, cin,
+                 dcode, s)
+        sync()
+        outs.append(gw)
+    assert torch.equal(outs[0], outs[1])
+    assert rel_l2(outs[0].cpu().numpy(), rgw) < (6e-5 if dcode == 2 else 2e-5), rel_l2(outs[0].cpu().numpy(), rgw)
+
+
 W24G_SHAPES = [  # B, Cin segs, Cout, H, W (Cin_p >= 64, Cout_p % 64 == 0)
     (1, [(64, 64)], 64, 16, 16),                 # 16x16-pixel workgroup tile, 8 chunks
     (2, [(128, 128)], 128, 8, 32),               # exactly one 8x32 tile per image, two output slabs

@@ -78,7 +78,12 @@ for label, wino in (('ours', True), ('ours-direct', False)):
         gz_ = C.ops.from_nhwc(u.gz, u.cout, eng.dcode).cpu().numpy()
         # BN output: first cout channels of u.out (a concat slice for encoder b-units)
         bo = u.out[..., :u.cout_p]
-        bo_ = C.ops.from_nhwc(bo.contiguous(), u.cout, eng.dcode).cpu().numpy()
+        if u.apply_folded or u.apply_in_filters:
+            # the normalised tensor is never written (folded into the consumer's transform / filters): apply scale and shift here
+            bo = (C.ops.split_decode(u.y) if eng.dcode == 2 else u.y.float()) * u.vec[0] + u.vec[1]
+            bo_ = bo[..., :u.cout].permute(0, 3, 1, 2).cpu().numpy()
+        else:
+            bo_ = C.ops.from_nhwc(bo.contiguous(), u.cout, eng.dcode).cpu().numpy()
         var64 = r64.var(axis=(0, 2, 3))
         istd64 = 1.0 / np.sqrt(var64 + 1e-5)
         istd_ = u.vec[3][:u.cout].cpu().numpy()
