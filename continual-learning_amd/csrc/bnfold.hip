@@ -92,6 +92,15 @@ __global__ void __launch_bounds__(256) bn_fold_wgrad_kernel(const T* __restrict_
     }
 }
 
+// pointwise consumer (the 1x1 head): dW[co][ci] = scale[ci] * dW[co][ci] + shift[ci] * (sum of the gradient over all pixels)[co]
+__global__ void __launch_bounds__(256) bn_fold_wgrad_pw_kernel(const float* __restrict__ total, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, float* __restrict__ dw, int Cout, int Cin) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cout * Cin) return;
+    const int co = i / Cin, ci = i - co * Cin;
+    dw[i] = fmaf(scale[ci], dw[i], shift[ci] * total[co]);
+}
+
 }  // namespace clamd
 
 using namespace clamd;
@@ -100,19 +109,26 @@ extern "C" {
 
 int clamd_bn_fold_bias(const float* w, const float* shift, const float* bias, float* table, int Cout, int Cin, int Cout_p, void* stream) {
     if (!w || !shift || !table || Cout <= 0 || Cin <= 0 || Cout_p < Cout) return clamd_fail("bn_fold_bias: bad arguments");
-    hipLaunchKernelGGL(bn_fold_bias_kernel, dim3(Cout_p), dim3(256), 0, (hipStream_t)stream, FoldBias{w, shift, bias, table, Cout, Cin, Cout_p});
+    hipLaunchKernelGGL(bn_fold_bias_kernel, dim3(Cout_p), dim3(256), 0, (hipStream_t)stream, FoldBias{w, shift, bias, table, Cout, Cin, Cout_p, 9});
     return clamd_check_launch("bn_fold_bias");
 }
 
-int clamd_bn_fold_pack(int form, const void* jobs_dev, int njobs, int total_blocks, int dtype, const float* w, const float* shift,
+int clamd_bn_fold_pack(int form, const void* jobs_dev, int njobs, int total_blocks, int dtype, const float* w, int taps, const float* shift,
                        const float* bias, float* table, int Cout, int Cin, int Cout_p, void* stream) {
     if (!w || !shift || !table || Cout <= 0 || Cin <= 0 || Cout_p < Cout) return clamd_fail("bn_fold_pack: bad arguments");
+    if (taps != 9 && !(taps == 1 && form == 0)) return clamd_fail("bn_fold_pack: taps must be 9 (3x3) or, with form 0, 1 (pointwise)");
     if (njobs <= 0 || total_blocks <= 0) return clamd_fail("bn_fold_pack: empty job table");
-    const FoldBias f{w, shift, bias, table, Cout, Cin, Cout_p};
+    const FoldBias f{w, shift, bias, table, Cout, Cin, Cout_p, taps};
     if (form == 0) return clamd_launch_pack(jobs_dev, njobs, total_blocks, dtype, &f, (hipStream_t)stream);
     if (form == 16) return clamd_launch_wino_pack(jobs_dev, njobs, total_blocks, &f, (hipStream_t)stream);
     if (form == 24) return clamd_launch_wino24_pack(jobs_dev, njobs, total_blocks, &f, (hipStream_t)stream);
     return clamd_fail("bn_fold_pack: form must be 0 (clamd_pack), 16 (clamd_wino_pack) or 24 (clamd_wino24_pack)");
+}
+
+int clamd_bn_fold_wgrad_pointwise(const float* sum_g, const float* scale, const float* shift, float* dw, int Cout, int Cin, void* stream) {
+    if (!sum_g || !scale || !shift || !dw || Cout <= 0 || Cin <= 0) return clamd_fail("bn_fold_wgrad_pointwise: bad arguments");
+    hipLaunchKernelGGL(bn_fold_wgrad_pw_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum_g, scale, shift, dw, Cout, Cin);
+    return clamd_check_launch("bn_fold_wgrad_pointwise");
 }
 
 size_t clamd_bn_fold_wgrad_workspace_bytes(int B, int Cout_p) { return (size_t)(B > 0 ? B : 0) * 4 * FOLD_NCH * (size_t)(Cout_p > 0 ? Cout_p : 0) * sizeof(float); }

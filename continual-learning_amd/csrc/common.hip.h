@@ -224,17 +224,22 @@ __device__ inline float wave_sum(float v) {
 // Border-class bias table of a BatchNorm folded into the convolution behind it (bnfold.hip): table[class][co] = bias[co] + the sum of
 // T[co][tap] = sum_ci w[co][ci][tap] * shift[ci] over the taps of that class which read inside the image.  Appended to the filter-pack launch
 // of the same convolution (blocks beyond the pack's own: one per physical output channel, 256 threads).
-struct FoldBias { const float* w; const float* shift; const float* bias; float* table; int Cout, Cin, Cout_p; };
+// taps = 9: w [Cout][Cin][3][3], nine classes; taps = 1: a pointwise convolution w [Cout][Cin] (the 1x1 head): no padding, one row.
+struct FoldBias { const float* w; const float* shift; const float* bias; float* table; int Cout, Cin, Cout_p, taps; };
 __device__ inline void fold_bias_block(const FoldBias& f, int co, float* T /* __shared__ [9] */) {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int tap = wv; tap < 9; tap += 4) {         // a wave per tap: lanes stride 64 over the input channels, then the xor butterfly
+    for (int tap = wv; tap < f.taps; tap += 4) {    // a wave per tap: lanes stride 64 over the input channels, then the xor butterfly
         float a = 0.f;
         if (co < f.Cout)
-            for (int ci = lane; ci < f.Cin; ci += 64) a = fmaf(f.w[((size_t)co * f.Cin + ci) * 9 + tap], f.shift[ci], a);
+            for (int ci = lane; ci < f.Cin; ci += 64) a = fmaf(f.w[((size_t)co * f.Cin + ci) * f.taps + tap], f.shift[ci], a);
         a = wave_sum(a);
         if (lane == 0) T[tap] = a;
     }
     __syncthreads();
+    if (f.taps == 1) {
+        if (threadIdx.x == 0) f.table[co] = co < f.Cout ? (f.bias ? f.bias[co] : 0.f) + T[0] : 0.f;
+        return;
+    }
     if (threadIdx.x < 9) {
         const int rc = threadIdx.x / 3, cc = threadIdx.x % 3;       // row class: 0 top (tap row 0 reads padding), 2 bottom (tap row 2 does)
         float s = (co < f.Cout && f.bias) ? f.bias[co] : 0.f;

@@ -475,7 +475,7 @@ using namespace clamd;
 
 int clamd_launch_pack(const void* jobs_dev, int njobs, int total_blocks, int dtype, const FoldBias* fold, hipStream_t stream) {
     if (njobs <= 0 || total_blocks <= 0) return clamd_fail("pack: empty job table");
-    const FoldBias f = fold ? *fold : FoldBias{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    const FoldBias f = fold ? *fold : FoldBias{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 9};
     const dim3 grid(total_blocks + (fold ? fold->Cout_p : 0));
     if (dtype == CLAMD_BF16)
         hipLaunchKernelGGL(pack_kernel<bf16_t>, grid, dim3(256), 0, stream, (const PackJob*)jobs_dev, njobs, total_blocks, f);

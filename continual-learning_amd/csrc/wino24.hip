@@ -466,7 +466,7 @@ using namespace clamd;
 
 int clamd_launch_wino24_pack(const void* jobs_dev, int njobs, int total_blocks, const clamd::FoldBias* fold, hipStream_t stream) {
     if (njobs <= 0 || total_blocks <= 0) return clamd_fail("wino24_pack: empty job table");
-    const clamd::FoldBias f = fold ? *fold : clamd::FoldBias{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+    const clamd::FoldBias f = fold ? *fold : clamd::FoldBias{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 9};
     hipLaunchKernelGGL(clamd::wino24_pack_kernel, dim3(total_blocks + (fold ? fold->Cout_p : 0)), dim3(256), 0, stream, (const clamd::WinoPackJob*)jobs_dev, njobs,
                        total_blocks, f);
     return clamd_check_launch("wino24_pack");

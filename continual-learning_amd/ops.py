@@ -63,10 +63,11 @@ class PackTable:
         if wd is not None:
             self.add(w, wd, 4, cin_p, cout_p, cin, cout, 1, cout * 4, 4, cout_p, 4 * cout_p, 1)
 
-    def head(self, w, wf, wd, cin, k):
-        """w [K][Cin][1][1] -> wf [K_p][Cin_p] and wd [Cin_p][K_p]."""
+    def head(self, w, wf, wd, cin, k, kscale=None):
+        """w [K][Cin][1][1] -> wf [K_p][Cin_p] and wd [Cin_p][K_p]; kscale as in conv3x3."""
         cin_p, kp = cpad(cin), cpad(k)
-        self.add(w, wf, 1, kp, cin_p, k, cin, 0, cin, 1, 0, cin_p, 1)
+        if wf is not None:
+            self.add(w, wf, 1, kp, cin_p, k, cin, 0, cin, 1, 0, cin_p, 1, kscale=kscale)
         if wd is not None:
             self.add(w, wd, 1, cin_p, kp, cin, k, 0, 1, cin, 0, kp, 1)
 

@@ -510,6 +510,18 @@ class _Engine:
                     and not a.split and not b.split and min(b.h, b.w_) >= 2 and b.cin_p <= FOLD_FILTERS_MAX_CHANNELS):
                 b.fold_a = a      # one direction only: a cycle between units would keep the engine's buffers alive until the garbage collector runs
                 b.cb = torch.zeros(9, b.cout_p, dtype=torch.float32, device=dev)
+        for st in self.stages:
+            t = st.get('tail')
+            if t is None:
+                continue
+            # ... and the 1x1 head behind the last BatchNorm: pointwise, no border classes -- in every compute dtype
+            t.fold_b = None
+            b = st['convs'][1]
+            if (FOLD_BN_INTO_FILTERS and t.kind == 'head' and not b.split and b.pooled is None and t.x is b.out
+                    and b.cout_p <= FOLD_FILTERS_MAX_CHANNELS):
+                t.fold_b = b
+                b.apply_in_filters = True
+                t.bias_fold = torch.zeros(t.cout_p, dtype=torch.float32, device=dev)
         nfw = max([lib.clamd_bn_fold_wgrad_workspace_bytes(B, u.cout_p) // 4 for u in convs if u.fold_a is not None] + [0])
         self.fold_ws = torch.empty(nfw, dtype=torch.float32, device=dev) if nfw else None
         for st in self.stages:      # half-batch pipeline: a's second-half apply may run under b's first-half convolution; across stages
@@ -646,6 +658,11 @@ class _Engine:
                 continue
             if t.kind == 'convT':
                 tab.convT(t.w, t.wf, t.wd, t.cin, t.cout)
+            elif t.fold_b is not None:      # forward filters inside the step, with the last BatchNorm's scale (see _fwd_fold)
+                tab.head(t.w, None, t.wd, t.cin, t.cout)
+                t.fold_table = PackTable(self.dcode)
+                t.fold_table.head(t.w, t.wf, None, t.cin, t.cout, kscale=t.fold_b.vec[0])
+                t.fold_table.finalize(self.dev)
             else:
                 tab.head(t.w, t.wf, t.wd, t.cin, t.cout)
             tab.vector(t.b, t.bias_p, t.cout)
@@ -741,6 +758,12 @@ class _Engine:
                 continue               # encoder: the pooled output feeds the next stage's first convolution (defer may be pending)
             assert defer is None
             h, w = H >> t.level, W >> t.level
+            tx, tx_ldc, tbias = t.x, t.x.shape[-1], t.bias_p
+            if t.fold_b is not None:       # the head reads the last unit's conv+ReLU output: its BatchNorm is in the filters and the bias
+                ft, fb = t.fold_table, t.fold_b
+                call('clamd_bn_fold_pack', 0, ptr(ft.dev_table), len(ft.jobs), ft.nblocks, dc, ptr(t.w), 1, ptr(fb.vec[1]), ptr(t.b),
+                     ptr(t.bias_fold), t.cout, t.cin, t.cout_p, s)
+                tx, tx_ldc, tbias = fb.y, fb.cout_p, t.bias_fold
             if t.kind == 'convT' and t.direct_f:
                 call('clamd_convT2x2_fwd_direct', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(t.y_slice), t.y_ldc,
                      B, h, w, t.cin_p, t.cout_p, s)
@@ -749,17 +772,17 @@ class _Engine:
                      B, h, w, t.cin_p, t.cout_p, dc, s)
             elif predict and t.cout_p <= 64:      # arg-max fused into the head's epilogue: the logits never reach HBM
                 logits = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
-                call('clamd_conv1x1_argmax', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(logits), None, B, h, w,
+                call('clamd_conv1x1_argmax', ptr(tx), tx_ldc, ptr(t.wf), ptr(tbias), ptr(logits), None, B, h, w,
                      t.cin_p, t.cout_p, self.K, dc, s)
             elif predict:      # more than 64 (padded) classes: the fused epilogue holds one 64-class slab; logits, then arg-max
                 lg = torch.empty(B, self.K, H, W, dtype=torch.float32, device=self.dev)
-                call('clamd_conv1x1_logits', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(lg), B, h, w,
+                call('clamd_conv1x1_logits', ptr(tx), tx_ldc, ptr(t.wf), ptr(tbias), ptr(lg), B, h, w,
                      t.cin_p, t.cout_p, self.K, dc, s)
                 logits = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
                 call('clamd_argmax_confusion', ptr(lg), None, ptr(logits), None, B, self.K, 1, H, W, s)
             else:
                 logits = torch.empty(B, self.K, H, W, dtype=torch.float32, device=self.dev)
-                call('clamd_conv1x1_logits', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(logits), B, h, w,
+                call('clamd_conv1x1_logits', ptr(tx), tx_ldc, ptr(t.wf), ptr(tbias), ptr(logits), B, h, w,
                      t.cin_p, t.cout_p, self.K, dc, s)
         if self._pack_pending == 2:     # no Winograd layer ran at all: the late part was never enqueued
             for t in self.wino_late:
@@ -825,7 +848,7 @@ class _Engine:
             return
         t = u.fold_table        # one launch: the filters times the producer's scale, and the bias table from its shift
         call('clamd_bn_fold_pack', (24 if u.w24 else 16) if u.wino else 0, ptr(t.dev_table), len(t.jobs), t.nblocks, self.dcode,
-             ptr(u.w), ptr(a.vec[1]), ptr(u.b), ptr(u.cb), u.cout, u.cin, u.cout_p, s)
+             ptr(u.w), 9, ptr(a.vec[1]), ptr(u.b), ptr(u.cb), u.cout, u.cin, u.cout_p, s)
 
     def _fwd_conv(self, u, training, s, hf):
         """conv3x3 + bias + ReLU (+ BatchNorm statistics rows) of unit u on the whole batch or one half of it."""
@@ -941,11 +964,15 @@ class _Engine:
                          ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
                          t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cout_p, t.cin_p, 0, dc, s)
                     sw = self._wg_stream_ptr()      # parameter gradients on the second stream, behind the data gradient (see _conv_bwd)
-                    call('clamd_wgrad', _lib.WGRAD_PW, ptr(self.dl), self.Kp, ptr(t.x), t.x.shape[-1], ptr(self.ws),
+                    fb = t.fold_b
+                    tx, tx_ldc = (fb.y, fb.cout_p) if fb is not None else (t.x, t.x.shape[-1])
+                    call('clamd_wgrad', _lib.WGRAD_PW, ptr(self.dl), self.Kp, ptr(tx), tx_ldc, ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cout_p, t.cin_p, t.cout, t.cin,
                          t.cout, t.cout_p, t.cin, t.cin_p, dc, tp, sw)
                     call('clamd_channel_sum', ptr(self.dl), self.Kp, g[t.keys[1]], B * h * w, self.Kp, t.cout, dc,
                          ptr(self.ws), self.ws_bytes, tp, sw)
+                    if fb is not None:      # the weight gradient ran on the un-normalised tensor: dW = scale * dW + shift * (bias gradient)
+                        call('clamd_bn_fold_wgrad_pointwise', g[t.keys[1]], ptr(fb.vec[0]), ptr(fb.vec[1]), g[t.keys[0]], t.cout, t.cin, sw)
                 else:
                     if t.direct:
                         call('clamd_convT2x2_dgrad_direct', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],

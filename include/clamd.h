@@ -116,9 +116,13 @@ int clamd_conv3x3_border_bias_ok(int B, int H, int W, int Cin_p, int Cout_p, int
 int clamd_bn_fold_bias(const float* w, const float* shift, const float* bias, float* table, int Cout, int Cin, int Cout_p, void* stream);
 /* the filter pack of that convolution and its bias table in ONE launch (both sit between the producer's clamd_bn_finalize and the
  * convolution, on the critical path of the forward pass): form 0 = clamd_pack(jobs_dev, njobs, total_blocks, dtype), 16 =
- * clamd_wino_pack, 24 = clamd_wino24_pack, with the blocks of clamd_bn_fold_bias appended to the grid. */
-int clamd_bn_fold_pack(int form, const void* jobs_dev, int njobs, int total_blocks, int dtype, const float* w, const float* shift,
+ * clamd_wino_pack, 24 = clamd_wino24_pack, with the blocks of clamd_bn_fold_bias appended to the grid (taps = 9).
+ * The 1x1 head behind the last BatchNorm (models/unet.py:70-72) folds the same way without border classes: taps = 1 (form 0), w
+ * [Cout][Cin], table = one row [Cout_p] = bias + W . shift; its weight gradient on the un-normalised tensor is fixed up by
+ * clamd_bn_fold_wgrad_pointwise: dW[co][ci] = scale[ci] * dW[co][ci] + shift[ci] * sum_g[co] (sum_g = the head's bias gradient). */
+int clamd_bn_fold_pack(int form, const void* jobs_dev, int njobs, int total_blocks, int dtype, const float* w, int taps, const float* shift,
                        const float* bias, float* table, int Cout, int Cin, int Cout_p, void* stream);
+int clamd_bn_fold_wgrad_pointwise(const float* sum_g, const float* scale, const float* shift, float* dw, int Cout, int Cin, void* stream);
 size_t clamd_bn_fold_wgrad_workspace_bytes(int B, int Cout_p);
 int clamd_bn_fold_wgrad(const void* gz, int gz_ldc, const float* sum_gz, const float* scale, const float* shift, float* dw,
                         void* workspace, size_t ws_bytes, int B, int H, int W, int Cout_p, int Cout, int Cin, int dtype, void* stream);

@@ -164,7 +164,9 @@ def test_engine_geometry_and_pack_table(C):
     assert all(u.fold_table.jobs[0][-1] == u.fold_a.vec[0].data_ptr() and u.plain_table.jobs[0][-1] == 0 for u in fold)
     assert sum(len(t.jobs) for t in e.wino_early) == sum(2 - (u.fold_a is not None) for u in wino_units if not u.pack_late)
     assert nw == 2 * len(wino_units) - sum(1 for u in fold if u.wino)
-    assert len(jobs) + nw + len(fold) == 18 * 3 - 1 + 5 * 3
+    head = e.stages[-1]['tail']
+    assert head.kind == 'head' and head.fold_b is e.convs[-1] and len(head.fold_table.jobs) == 1      # the 1x1 head folds the last BatchNorm
+    assert len(jobs) + nw + len(fold) + 1 == 18 * 3 - 1 + 5 * 3
     assert e.pack_table.nblocks == sum(((j[3] + 31) // 32) * ((j[4] + 31) // 32) for j in jobs)
     assert C.cpad(3) == 32 and C.cpad(21) == 32 and C.cpad(1024) == 1024
 
