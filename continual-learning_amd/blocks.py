@@ -1,0 +1,209 @@
+"""The reference's building blocks as stand-alone custom ops (models/unet.py:8-38: DownBlock = MaxPool, Conv-ReLU-BN x 2; UpBlock =
+Conv-ReLU-BN x 2, ConvTranspose; :50-55 / :66-72 the plain first and last sequences).
+
+``UNet.forward`` runs the whole network as ONE autograd Function over a planned engine (unet.py) -- that is the measured path.  A child
+called on its own (``model.enc2(x)``, ``model.dec1.block(x)``: feature probes, unit tests of one block) runs here: one
+``torch.autograd.Function`` per block over the same libclamd kernels (generic direct convolutions, BatchNorm statistics rows, fused
+BatchNorm passes, stand-alone max-pool), NCHW fp32 in and out like every visible tensor of this package, buffers allocated per call.
+No stock-torch operator is involved and there is no CPU path.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr
+from .ops import PackTable, TORCH_DT, cpad, from_nhwc, to_nhwc
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def _stream():
+    return _lib.stream_ptr()
+
+
+class _BlockFn(torch.autograd.Function):
+    """forward(x, plan, *params): plan = (ops, dcode, training, buffers); ops = [('pool',), ('crb', k), ..., ('convT',) | ('head',)];
+    params = (conv.weight, conv.bias, bn.weight, bn.bias) per 'crb' in order, then (weight, bias) of the tail."""
+
+    @staticmethod
+    def forward(ctx, x, plan, *params):
+        ops, dcode, training, buffers = plan
+        lib = _lib.load()
+        T = TORCH_DT[dcode]
+        dev = x.device
+        s = _stream()
+        B, C, H, W = x.shape
+        cur = to_nhwc(x.contiguous().float(), dcode)          # [B,H,W,cpad(C)]
+        saved, pi = [], 0
+        for op in ops:
+            if op[0] == 'pool':
+                if (H | W) & 1:
+                    raise ValueError('MaxPool2d(2,2) block: H and W must be even')
+                out = torch.empty(B, H // 2, W // 2, cur.shape[-1], dtype=T, device=dev)
+                call('clamd_maxpool2x2', ptr(cur), cur.shape[-1], ptr(out), out.shape[-1], B, H, W, cur.shape[-1], dcode, s)
+                saved.append(('pool', cur, H, W))
+                cur, H, W = out, H // 2, W // 2
+            elif op[0] == 'crb':
+                w, b, gamma, beta = params[pi:pi + 4]
+                rm, rv, nbt = buffers[op[1]]
+                pi += 4
+                cout, cin = w.shape[0], w.shape[1]
+                cin_p, cout_p = cur.shape[-1], cpad(cout)
+                wf = torch.zeros(9 * cout_p * cin_p, dtype=T, device=dev)
+                wd = torch.zeros(9 * cin_p * cout_p, dtype=T, device=dev)
+                bias_p = torch.zeros(cout_p, dtype=torch.float32, device=dev)
+                tab = PackTable(dcode)
+                tab.conv3x3(w.detach(), wf, wd, [(cin, cin_p)], cout)
+                tab.vector(b.detach(), bias_p, cout)
+                tab.finalize(dev).run(dcode, s)
+                rows = _lib.stat_rows(_lib.OP_CONV3X3, B, H, W, cin_p, cout_p, dcode)
+                y = torch.empty(B, H, W, cout_p, dtype=T, device=dev)
+                stats = torch.empty(rows, 2, cout_p, dtype=torch.float32, device=dev) if training else None
+                call('clamd_conv3x3', ptr(cur), cin_p, ptr(wf), ptr(bias_p), ptr(y), cout_p, ptr(stats), None, None, rows, B, H, W,
+                     cin_p, cout_p, 1, 1 if 9 * cout_p > B * H * W else 0, dcode, None, s)
+                vec = torch.zeros(7, cout_p, dtype=torch.float32, device=dev)       # scale, shift, mean, istd, k0, k1, k2
+                call('clamd_bn_finalize', ptr(stats), rows, ptr(gamma.detach()), ptr(beta.detach()), ptr(rm), ptr(rv), ptr(vec[0]), ptr(vec[1]),
+                     ptr(vec[2]), ptr(vec[3]), cout_p, cout, float(B * H * W), BN_MOMENTUM, BN_EPS, s)
+                out = torch.empty_like(y)
+                call('clamd_bn_apply', ptr(y), cout_p, ptr(vec[0]), ptr(vec[1]), ptr(out), cout_p, None, 0, B, H, W, cout_p, dcode, s)
+                if training:
+                    nbt += 1
+                saved.append(('crb', cur, y, vec, wd, gamma.detach(), (cin, cin_p, cout, cout_p, H, W)))
+                cur = out
+            elif op[0] == 'convT':
+                w, b = params[pi:pi + 2]
+                pi += 2
+                cin, cout = w.shape[0], w.shape[1]
+                cin_p, cout_p = cur.shape[-1], cpad(cout)
+                wf = torch.zeros(4 * cout_p * cin_p, dtype=T, device=dev)
+                wd = torch.zeros(cin_p * 4 * cout_p, dtype=T, device=dev)
+                bias_p = torch.zeros(cout_p, dtype=torch.float32, device=dev)
+                tab = PackTable(dcode)
+                tab.convT(w.detach(), wf, wd, cin, cout)
+                tab.vector(b.detach(), bias_p, cout)
+                tab.finalize(dev).run(dcode, s)
+                out = torch.empty(B, 2 * H, 2 * W, cout_p, dtype=T, device=dev)
+                call('clamd_convT2x2_fwd', ptr(cur), cin_p, ptr(wf), ptr(bias_p), ptr(out), cout_p, B, H, W, cin_p, cout_p, dcode, s)
+                saved.append(('convT', cur, wd, (cin, cin_p, cout, cout_p, H, W)))
+                cur, H, W = out, 2 * H, 2 * W
+            else:                                       # 'head': 1x1 convolution, fp32 NCHW logits straight from the epilogue
+                w, b = params[pi:pi + 2]
+                pi += 2
+                k, cin = w.shape[0], w.shape[1]
+                cin_p, kp = cur.shape[-1], cpad(k)
+                wf = torch.zeros(kp * cin_p, dtype=T, device=dev)
+                wd = torch.zeros(cin_p * kp, dtype=T, device=dev)
+                bias_p = torch.zeros(kp, dtype=torch.float32, device=dev)
+                tab = PackTable(dcode)
+                tab.head(w.detach(), wf, wd, cin, k)
+                tab.vector(b.detach(), bias_p, k)
+                tab.finalize(dev).run(dcode, s)
+                logits = torch.empty(B, k, H, W, dtype=torch.float32, device=dev)
+                call('clamd_conv1x1_logits', ptr(cur), cin_p, ptr(wf), ptr(bias_p), ptr(logits), B, H, W, cin_p, kp, k, dcode, s)
+                saved.append(('head', cur, wd, (cin, cin_p, k, kp, H, W)))
+                cur = None
+        ctx.saved_ops, ctx.dcode, ctx.B, ctx.cin0, ctx.training = saved, dcode, B, C, training
+        ctx.shapes = [tuple(p.shape) for p in params]
+        if cur is None:
+            return logits
+        last = ops[-1]
+        cout = params[-2].shape[1] if last[0] == 'convT' else params[-4].shape[0]
+        return from_nhwc(cur, cout, dcode)
+
+    @staticmethod
+    def backward(ctx, gout):
+        if not ctx.training:
+            raise RuntimeError('block backward after an eval-mode forward is not supported (BatchNorm backward uses batch statistics)')
+        dcode, B = ctx.dcode, ctx.B
+        lib = _lib.load()
+        T = TORCH_DT[dcode]
+        dev = gout.device
+        s = _stream()
+        grads = []
+        g = None                                                        # NHWC gradient w.r.t. the current op's output
+        gout = gout.contiguous().float()
+        for rec in reversed(ctx.saved_ops):
+            kind = rec[0]
+            if kind == 'head':
+                _, x, wd, (cin, cin_p, k, kp, H, W) = rec
+                dl = to_nhwc(gout, dcode, cp=kp)
+                gx = torch.empty(B, H, W, cin_p, dtype=T, device=dev)
+                call('clamd_conv1x1', ptr(dl), kp, ptr(wd), None, ptr(gx), cin_p, None, None, None, 0, B, H, W, kp, cin_p, 0, dcode, s)
+                wsb = max(lib.clamd_wgrad_workspace_bytes(_lib.WGRAD_PW, B, H, W, kp, cin_p, dcode), lib.clamd_channel_sum_workspace_bytes(kp))
+                ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev)
+                dw = torch.empty(k, cin, 1, 1, dtype=torch.float32, device=dev)
+                db = torch.empty(k, dtype=torch.float32, device=dev)
+                call('clamd_wgrad', _lib.WGRAD_PW, ptr(dl), kp, ptr(x), cin_p, ptr(ws), wsb, ptr(dw), B, H, W, kp, cin_p, k, cin,
+                     k, kp, cin, cin_p, dcode, None, s)
+                call('clamd_channel_sum', ptr(dl), kp, ptr(db), B * H * W, kp, k, dcode, ptr(ws), wsb, None, s)
+                grads = [dw, db] + grads
+                g = gx
+            elif kind == 'convT':
+                _, x, wd, (cin, cin_p, cout, cout_p, H, W) = rec
+                gy = to_nhwc(gout, dcode, cp=cout_p) if g is None else g
+                gx = torch.empty(B, H, W, cin_p, dtype=T, device=dev)
+                call('clamd_convT2x2_dgrad', ptr(gy), cout_p, ptr(wd), ptr(gx), cin_p, None, None, 0, B, H, W, cin_p, cout_p, dcode, s)
+                wsb = max(lib.clamd_wgrad_workspace_bytes(_lib.WGRAD_UP2, B, H, W, cin_p, cout_p, dcode), lib.clamd_channel_sum_workspace_bytes(cout_p))
+                ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev)
+                dw = torch.empty(cin, cout, 2, 2, dtype=torch.float32, device=dev)
+                db = torch.empty(cout, dtype=torch.float32, device=dev)
+                call('clamd_wgrad', _lib.WGRAD_UP2, ptr(x), cin_p, ptr(gy), cout_p, ptr(ws), wsb, ptr(dw), B, H, W, cin_p, cout_p, cin, cout,
+                     cin, cin_p, cout, cout_p, dcode, None, s)
+                call('clamd_channel_sum', ptr(gy), cout_p, ptr(db), B * 4 * H * W, cout_p, cout, dcode, ptr(ws), wsb, None, s)
+                grads = [dw, db] + grads
+                g = gx
+            elif kind == 'crb':
+                _, x, y, vec, wd, gamma, (cin, cin_p, cout, cout_p, H, W) = rec
+                ga = to_nhwc(gout, dcode, cp=cout_p) if g is None else g
+                rows = _lib.stat_rows(_lib.OP_BN_BWD_REDUCE, B, H, W, 0, cout_p, dcode)
+                sums = torch.empty(rows, lib.clamd_bn_bwd_nsums(), cout_p, dtype=torch.float32, device=dev)
+                call('clamd_bn_bwd_reduce', ptr(ga), cout_p, None, 0, ptr(y), cout_p, ptr(vec[0]), ptr(vec[1]), ptr(sums), rows,
+                     B, H, W, cout_p, dcode, None, s)
+                dgamma, dbeta, dbias = (torch.empty(cout, dtype=torch.float32, device=dev) for _ in range(3))
+                call('clamd_bn_bwd_finalize', ptr(sums), rows, ptr(gamma), ptr(vec[2]), ptr(vec[3]), ptr(vec[4]), ptr(dgamma), ptr(dbeta),
+                     ptr(dbias), cout_p, cout, float(B * H * W), s)
+                gz = torch.empty(B, H, W, cout_p, dtype=T, device=dev)
+                call('clamd_bn_bwd_apply', ptr(ga), cout_p, None, 0, ptr(y), cout_p, ptr(vec[0]), ptr(vec[1]), ptr(vec[4]), ptr(gz), cout_p,
+                     B, H, W, cout_p, dcode, s)
+                gx = torch.empty(B, H, W, cin_p, dtype=T, device=dev)
+                call('clamd_conv3x3', ptr(gz), cout_p, ptr(wd), None, ptr(gx), cin_p, None, None, None, 0, B, H, W, cout_p, cin_p, 0,
+                     1 if 9 * cin_p > B * H * W else 0, dcode, None, s)
+                wsb = lib.clamd_wgrad_workspace_bytes(_lib.WGRAD_CONV3, B, H, W, cout_p, cin_p, dcode)
+                ws = torch.empty(wsb // 4 + 16, dtype=torch.float32, device=dev)
+                dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=dev)
+                call('clamd_wgrad', _lib.WGRAD_CONV3, ptr(gz), cout_p, ptr(x), cin_p, ptr(ws), wsb, ptr(dw), B, H, W, cout_p, cin_p, cout, cin,
+                     cout, cout_p, cin, cin_p, dcode, None, s)
+                grads = [dw, dbias, dgamma, dbeta] + grads
+                g = gx
+            else:                                                       # 'pool'
+                _, x, H, W = rec
+                cp = x.shape[-1]
+                gp = to_nhwc(gout, dcode, cp=cp) if g is None else g
+                gx = torch.empty(B, H, W, cp, dtype=T, device=dev)
+                call('clamd_maxpool2x2_bwd', ptr(x), cp, ptr(gp), cp, ptr(gx), cp, B, H, W, cp, dcode, s)
+                g = gx
+        gin = from_nhwc(g, ctx.cin0, dcode) if ctx.needs_input_grad[0] else None
+        return (gin, None) + tuple(grads)
+
+
+def run_block(seq, st, dcode, x):
+    """Runs the layers of one stage of the UNet table (unet.stage_table) on x [B,C,H,W] (fp32, GPU)."""
+    if not x.is_cuda:
+        raise RuntimeError('continual-learning_amd blocks run only on GPU tensors: there is no CPU fallback')
+    if x.dim() != 4:
+        raise ValueError(f'expected [B,C,H,W], got {tuple(x.shape)}')
+    ops, params, buffers = [], [], []
+    if st['pool']:
+        ops.append(('pool',))
+    for ci, bi, cin, cout in st['convs']:
+        conv, bn = seq[ci], seq[bi]
+        ops.append(('crb', len(buffers)))
+        params += [conv.weight, conv.bias, bn.weight, bn.bias]
+        buffers.append((bn.running_mean, bn.running_var, bn.num_batches_tracked))
+    if st['tail'] is not None:
+        kind, ti, _, _ = st['tail']
+        ops.append((kind,))
+        params += [seq[ti].weight, seq[ti].bias]
+    if x.shape[1] != st['convs'][0][2]:
+        raise ValueError(f'expected {st["convs"][0][2]} input channels, got {x.shape[1]}')
+    training = seq.training
+    return _BlockFn.apply(x, (ops, dcode, training, buffers), *params)

@@ -159,17 +159,24 @@ def stage_table(num_classes, in_dim=3, conv_dim=64):
 
 
 class _NoForward:
-    """The children of UNet are PARAMETER CONTAINERS (torch's default init, the reference's state_dict names).  Their own
-    ``forward`` would run stock torch operators (MIOpen) -- a silent fallback this package does not have: it raises."""
+    """The LAYERS inside UNet's blocks are parameter containers (torch's default init, the reference's state_dict names).  Their own
+    ``forward`` would run stock torch operators (MIOpen) -- a silent fallback this package does not have: it raises.  The BLOCKS
+    (models/unet.py:8-38: enc1 ... last, and their ``.block`` sequences) can be called on their own: blocks.py runs them as one
+    autograd Function over libclamd kernels."""
 
     def forward(self, *args, **kwargs):
-        raise RuntimeError(f'{type(self).__name__}.forward: the children of continual-learning_amd.UNet only hold parameters; '
-                           'run UNet.forward / UNet.predict (one autograd Function over libclamd kernels) -- there is no '
-                           'stock-torch path for a single block')
+        raise RuntimeError(f'{type(self).__name__}.forward: the layers of continual-learning_amd.UNet only hold parameters; '
+                           'run UNet.forward / UNet.predict, or a whole block (model.enc2(x), model.dec1(x): blocks.py) -- there is no '
+                           'stock-torch path for a single layer')
 
 
 class _Seq(_NoForward, nn.Sequential):
-    pass
+    def forward(self, x):
+        spec = getattr(self, '_block_spec', None)
+        if spec is None:
+            return _NoForward.forward(self, x)
+        from . import blocks
+        return blocks.run_block(self, spec[0], spec[1], x)
 
 
 class _Conv2d(_NoForward, nn.Conv2d):
@@ -198,6 +205,9 @@ class _Stage(_NoForward, nn.Module):
     def __init__(self, layers):
         super().__init__()
         self.block = _Seq(*layers)
+
+    def forward(self, x):
+        return self.block(x)
 
 
 def _stage_modules(st):
@@ -229,7 +239,9 @@ class UNet(nn.Module):
         self._table = stage_table(num_classes, in_dim, conv_dim)
         for st in self._table:
             layers = _stage_modules(st)
-            self.add_module(st['name'], _Stage(layers) if st['wrapped'] else _Seq(*layers))
+            mod = _Stage(layers) if st['wrapped'] else _Seq(*layers)
+            (mod.block if st['wrapped'] else mod)._block_spec = (st, _DTYPES[compute_dtype][0])      # stand-alone call of the block: blocks.py
+            self.add_module(st['name'], mod)
         self._engines = {}
         self.grad_sync = None          # set by ddp.GradSync to overlap RCCL all-reduce with backward
         self._tuning = None

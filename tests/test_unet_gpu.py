@@ -399,6 +399,57 @@ def test_predict_fuses_argmax_into_the_head(C, dtype):
     assert acc == pytest.approx(ref, abs=1e-9) and tr.model.training is False
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16x3', 'bf16'])
+def test_blocks_run_on_their_own(C, dtype):
+    """The reference's blocks (models/unet.py:8-38, :50-55, :66-72) as stand-alone custom ops (blocks.py): every child of UNet called on
+    its own -- enc1 (plain), enc2 (DownBlock: pool first), dec1 (UpBlock: ConvTranspose last), last (1x1 head last), and the inner
+    ``.block`` sequence -- against the stock torch modules with the same parameters: output, input gradient, every parameter gradient,
+    running statistics; train and eval mode.  One autograd Function over libclamd kernels per block, no torch operator."""
+    import torch.nn as nn
+    from oracle import torch_cpu as TC
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(11)
+    m = C.UNet(5, 3, 8, compute_dtype=dtype).to(dev).train()
+    ref = TC.build_unet(5, 3, 8).to(dev).train()
+    ref.load_state_dict(m.state_dict())
+    tol = {'fp32': 2e-5, 'bf16x3': 2e-4, 'bf16': 3e-2}[dtype]
+    # gradients: a random 8 / 16-channel block sits on its ReLU ties -- a rounding-level change of a pre-activation flips one and moves the
+    # gradient by a visible amount (DESIGN.md section 2); fp32 is held per tensor, the rounded dtypes on the block's whole gradient
+    gtol = {'fp32': 2e-3, 'bf16x3': 3e-2, 'bf16': 0.3}[dtype]
+    cases = [('enc1', (2, 3, 32, 48)), ('enc2', (2, 8, 32, 48)), ('dec1', (2, 64, 4, 6)), ('dec4', (2, 32, 16, 24)), ('last', (2, 16, 32, 48))]
+    for name, shape in cases:
+        ours, theirs = getattr(m, name), getattr(ref, name)
+        x = torch.randn(*shape, device=dev)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        oa, ob = ours(xa), theirs(xb)
+        assert oa.shape == ob.shape and oa.dtype == torch.float32
+        assert rel_l2(oa.detach().cpu().numpy(), ob.detach().cpu().numpy()) < tol, name
+        g = torch.randn_like(ob)
+        oa.backward(g); ob.backward(g)
+        assert rel_l2(xa.grad.cpu().numpy(), xb.grad.cpu().numpy()) < gtol, name
+        pa, pb = dict(ours.named_parameters()), dict(theirs.named_parameters())
+        assert list(pa) == list(pb)
+        if dtype == 'fp32':
+            for k in pa:
+                r = pb[k].grad
+                assert float((pa[k].grad - r).norm()) <= gtol * float(r.norm()) + 1e-6 * r.numel() ** 0.5, (name, k)
+        ga, gb = (torch.cat([d[k].grad.reshape(-1) for k in pa]) for d in (pa, pb))
+        assert float((ga - gb).norm() / gb.norm()) < gtol, name
+        ba, bb = dict(ours.named_buffers()), dict(theirs.named_buffers())
+        for k in ba:
+            assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-4 if dtype != 'bf16' else 2e-2, atol=1e-5 if dtype != 'bf16' else 1e-3), (name, k)
+        m.zero_grad(); ref.zero_grad()
+    # the inner sequence is the same op; eval mode normalises with the running statistics
+    x = torch.randn(2, 8, 32, 48, device=dev)
+    assert m.enc2.block(x).shape == (2, 16, 16, 24)
+    m.eval(); ref.eval()
+    ref.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        assert rel_l2(m.enc2(x).cpu().numpy(), ref.enc2(x).cpu().numpy()) < tol
+        assert rel_l2(m.enc2.block(x).cpu().numpy(), ref.enc2(x).cpu().numpy()) < tol
+    assert isinstance(m.enc2.block[1], nn.Conv2d)
+
+
 def test_misuse_errors(C):
     model = C.UNet(3, 3, 4)
     with pytest.raises(RuntimeError):
@@ -613,7 +664,8 @@ def test_fused_bn_backward_sums_match_the_separate_reduction(C, dtype, monkeypat
 
 
 def test_misuse_errors(C):
-    """There is no silent stock-torch path: (1) a child module called on its own raises (the children only hold parameters);
+    """There is no silent stock-torch path: (1) a LAYER called on its own raises (the layers only hold parameters; a whole block runs
+    through blocks.py, test_blocks_run_on_their_own);
     (2) nn.DataParallel (trainer.py:120-122) on ONE device calls the module itself and works, across devices the replication is
     refused with a pointer to ddp.GradSync; (3) torch's DistributedDataParallel wrapper works (world 1: bit-identical to the
     plain step) -- its reducer hooks see the gradients this path's autograd Function returns."""
@@ -623,11 +675,12 @@ def test_misuse_errors(C):
     m = C.UNet(5, 3, 8).to(dev).train()
     x = torch.from_numpy(C.synth.images(3, 2, 3, 32, 32)).to(dev)
     y = torch.from_numpy(C.synth.labels(3, 2, 32, 32, 5)).to(dev)
-    for child, arg in ((m.enc1, x), (m.enc2, torch.zeros(2, 8, 32, 32, device=dev)), (m.enc2.block, torch.zeros(2, 8, 32, 32, device=dev)),
-                       (m.enc1[0], x), (m.enc1[2], torch.zeros(2, 8, 32, 32, device=dev)), (m.dec1.block[6], torch.zeros(2, 128, 2, 2, device=dev)),
-                       (m.last[6], torch.zeros(2, 8, 32, 32, device=dev))):
+    for child, arg in ((m.enc1[0], x), (m.enc1[2], torch.zeros(2, 8, 32, 32, device=dev)), (m.dec1.block[6], torch.zeros(2, 128, 2, 2, device=dev)),
+                       (m.enc2.block[0], torch.zeros(2, 8, 32, 32, device=dev)), (m.last[6], torch.zeros(2, 8, 32, 32, device=dev))):
         with pytest.raises(RuntimeError, match='no stock-torch path'):
             child(arg)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.enc2(torch.zeros(2, 8, 32, 32))
     assert isinstance(m.enc1[0], nn.Conv2d) and isinstance(m.enc1[2], nn.BatchNorm2d) and isinstance(m.dec1.block[6], nn.ConvTranspose2d)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         m(x.cpu())
