@@ -49,6 +49,9 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
     constexpr int EPI_SLOTS = (4 * 32 * EPW + 8 * 64) / 4;       // 4 waves x [32][EPW] fp32 + statistics hand-over
     static_assert((2 * STAGE + EPI_SLOTS) * 16 <= 160 * 1024, "two LDS stages + the epilogue region must fit one CU");
     __shared__ uint4 smem[2 * STAGE + EPI_SLOTS];
+    // CLS: this workgroup's 64 columns of the [9][Np] border-class bias table (a folded BatchNorm, bnfold.hip), filled by the consumers while
+    // they wait for the first stage: a border tile then takes its biases from LDS, not through two dependent global round trips per row tile
+    __shared__ float cls_tab[CLS ? 9 * 64 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= 4;
@@ -223,6 +226,12 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             const int n = n0 + 32 * nt + r;
             bcol[nt] = (p.bias && n < p.Np) ? p.bias[(CLS ? 4 * p.Np : 0) + n] : 0.f;      // class 4: interior pixels
         }
+        if constexpr (CLS) {
+            for (int i = ltid; i < 9 * 64; i += 256) {
+                const int n = n0 + (i & 63);
+                cls_tab[i] = n < p.Np ? p.bias[(i >> 6) * p.Np + n] : 0.f;
+            }
+        }
         float* const wbuf = reinterpret_cast<float*>(smem + 2 * STAGE) + cw * 32 * EPW;   // this wave's transposition block
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();
         const bool plain = !p.relu && !p.bias && !p.stats;         // wave-uniform
@@ -361,8 +370,6 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             const __amdgpu_buffer_rsrc_t yrs = make_rsrc((const char*)p.y + (size_t)b * y_img, y_img);
             const unsigned y_so = (unsigned)((y0 * p.W + x0) * p.y_ldc) * (unsigned)sizeof(T);
             const bool full = !RAGGED || (y0 + TH <= p.H && x0 + TW <= p.W);           // wave-uniform
-            // a folded BatchNorm's shift term depends on which taps read padding: tiles on the image border take the bias per pixel
-            const bool edge_tile = CLS && (y0 == 0 || x0 == 0 || y0 + TH >= p.H || x0 + TW >= p.W);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const unsigned long long e0 = PWD_T(); (void)e0;
@@ -374,47 +381,52 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) wbuf[acc_row(e, h) * EPW + 32 * nt + r] = acc[mt][nt][e];
-                } else if (edge_tile) {
-                    // an MFMA row tile is 32 / TW image rows of the tile: the row class is wave-uniform, the column class differs from
-                    // "interior" in at most the first / last pixel of a row -- three table entries per row and channel.  Where the tile is
-                    // whole along x, WHICH accumulator registers hold those two pixels is known at compile time (acc_row): the other
-                    // registers cost what they cost in an interior tile.
+                } else if (CLS) {
+                    // Border-class bias (a folded BatchNorm): an MFMA row tile is 32 / TW image rows of the tile, so the row class is
+                    // wave-uniform and the column class differs from "interior" in at most the first / last pixel of a row -- three table
+                    // entries (LDS) per row and channel.  ONE code path for every tile of the launch (a separate path for the 30-56 % border
+                    // tiles was cold in the instruction cache every time it ran: +44 % per launch); where the tile is whole along x, WHICH
+                    // accumulator registers hold those two pixels is known at compile time (acc_row), the others pay nothing.
                     constexpr int RPM = 32 / TW;
                     const bool whole_x = x0 + TW <= p.W;
                     const bool first_col = x0 == 0 && h == 0, last_col = x0 + TW == p.W && h == 1;
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
-                        const int n = n0 + 32 * nt + r;
-                        const float* const bt = p.bias + (n < p.Np ? n : 0);
                         float bl[RPM], bm[RPM], br[RPM];
 #pragma unroll
                         for (int rr = 0; rr < RPM; ++rr) {
                             const int yy = y0 + (MT * cw + mt) * RPM + rr;
                             const int rc = yy == 0 ? 0 : (yy == p.H - 1 ? 6 : 3);
-                            bl[rr] = n < p.Np ? bt[(rc + 0) * p.Np] : 0.f;
-                            bm[rr] = n < p.Np ? bt[(rc + 1) * p.Np] : 0.f;
-                            br[rr] = n < p.Np ? bt[(rc + 2) * p.Np] : 0.f;
+                            bl[rr] = cls_tab[(rc + 0) * 64 + 32 * nt + r];
+                            bm[rr] = cls_tab[(rc + 1) * 64 + 32 * nt + r];
+                            br[rr] = cls_tab[(rc + 2) * 64 + 32 * nt + r];
                         }
+                        if (whole_x) {      // wave-uniform
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int rr = TW == 32 ? 0 : (e >> 3);                 // acc_row(e, h) / TW
-                            const int yy = y0 + (MT * cw + mt) * RPM + rr;
-                            float bv = bm[rr];
-                            bool in = yy < p.H;
-                            if (whole_x) {      // wave-uniform
-                                const int ec = TW == 32 ? (e >> 2) : ((e >> 2) & 1);            // acc_row = (e & 3) + 8 * (e >> 2) + 4 * h
+                            for (int e = 0; e < 16; ++e) {
+                                const int rr = TW == 32 ? 0 : (e >> 3);                 // acc_row(e, h) / TW
+                                const int ec = TW == 32 ? (e >> 2) : ((e >> 2) & 1);    // acc_row = (e & 3) + 8 * (e >> 2) + 4 * h
+                                float bv = bm[rr];
                                 if ((e & 3) == 0 && ec == 0) bv = first_col ? bl[rr] : bv;         // column 0 of the tile: h == 0 lanes
                                 if ((e & 3) == 3 && ec == TW / 8 - 1) bv = last_col ? br[rr] : bv;  // column TW - 1: h == 1 lanes
-                            } else {
-                                const int xx = x0 + acc_row(e, h) - rr * TW;
-                                bv = xx == 0 ? bl[rr] : (xx == p.W - 1 ? br[rr] : bv);
-                                in = in && xx < p.W;
+                                const float v = fmaxf(acc[mt][nt][e] + bv, relu_lo);
+                                const float vs = (full || y0 + (MT * cw + mt) * RPM + rr < p.H) ? v : 0.f;
+                                st1[nt] += vs;
+                                st2[nt] = fmaf(vs, vs, st2[nt]);
+                                wbuf[acc_row(e, h) * EPW + 32 * nt + r] = v;
                             }
-                            const float v = fmaxf(acc[mt][nt][e] + bv, relu_lo);
-                            const float vs = (full || in) ? v : 0.f;
-                            st1[nt] += vs;
-                            st2[nt] = fmaf(vs, vs, st2[nt]);
-                            wbuf[acc_row(e, h) * EPW + 32 * nt + r] = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int rr = TW == 32 ? 0 : (e >> 3);
+                                const int xx = x0 + acc_row(e, h) - rr * TW, yy = y0 + (MT * cw + mt) * RPM + rr;
+                                const float bv = xx == 0 ? bl[rr] : (xx == p.W - 1 ? br[rr] : bm[rr]);
+                                const float v = fmaxf(acc[mt][nt][e] + bv, relu_lo);
+                                const float vs = (yy < p.H && xx < p.W) ? v : 0.f;
+                                st1[nt] += vs;
+                                st2[nt] = fmaf(vs, vs, st2[nt]);
+                                wbuf[acc_row(e, h) * EPW + 32 * nt + r] = v;
+                            }
                         }
                     }
                 } else if (full) {

@@ -53,9 +53,9 @@ NARROW_DIRECT = os.environ.get('CLAMD_NARROW_DIRECT', '1') != '0'
 # epilogue, the weight gradient fixed up from the gradient's border sums.  The normalised tensor is never written: the bn_apply pass
 # of the first unit of enc1 / enc2 / dec4 / last (268 + 268 MB at level 0 in fp32) leaves the forward pass.  Up to
 # FOLD_FILTERS_MAX_CHANNELS input channels: the per-step filter pack is on the critical path, the apply pass shrinks with depth.
-# Interleaved A/B against the previous build (bench.py, ms per step): fp32 21.30 -> 21.08, bf16x3 15.39 -> 15.19, bf16 6.73 -> 6.79: in bf16 the
-# apply passes are half the bytes while the pack launch (12 us), the table lookups of the border tiles and the two fix-up launches cost the
-# same, so 'auto' folds on the fp32-storage paths only; True = every compute dtype; False = never.
+# Interleaved A/B (bench.py, ms per step): fp32 21.30 -> 21.08, bf16x3 15.17 -> 14.84, bf16 6.81 = 6.81: in bf16 the apply passes are half
+# the bytes while the pack launch (12 us) on the critical chain and the fix-up launches cost the same, so 'auto' folds the 3x3 pairs on the
+# fp32-storage paths only (the 1x1 head folds everywhere); True = every compute dtype; False = never.
 FOLD_BN_INTO_FILTERS = {'0': False, 'false': False, 'all': True, 'true': True}.get(os.environ.get('CLAMD_FOLD_FILTERS', 'auto').lower(), 'auto')
 FOLD_FILTERS_MAX_CHANNELS = int(os.environ.get('CLAMD_FOLD_FILTERS_MAX_CHANNELS', '128'))
 # fp32 path: ConvTranspose2d forward / data gradient as register-blocked GEMMs with operands loaded straight into the MFMA operand
