@@ -475,6 +475,46 @@ __global__ void nchw_im2col3_kernel(const float* __restrict__ src, T* dst, int l
     }
 }
 
+// The same for the network's own first layer (C <= 3, Cp = 32, W a multiple of 4): a thread takes FOUR pixels of a row -- per channel and
+// tap row one 16-byte load plus the two neighbours instead of twelve scalar gathers, 4 x 128 bytes (fp32) of output back to back.
+template <typename T>
+__global__ void __launch_bounds__(256) nchw_im2col3x4_kernel(const float* __restrict__ src, T* dst, int ldc, int B, int C, int H, int W) {
+    const long long hw = (long long)H * W, nq = (long long)B * hw / 4;
+    const int wq = W / 4;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(q % wq) * 4;
+        const long long row = q / wq;
+        const int y = (int)(row % H);
+        const long long b = row / H;
+        float a[3][3][6];                                   // [channel][tap row][x - 1 .. x + 4]
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = y + ky - 1;
+                const bool ok = c < C && yy >= 0 && yy < H;
+                const float* r = src + (b * C + (ok ? c : 0)) * hw + (long long)(ok ? yy : 0) * W + x;
+                const float4 m = ok ? *reinterpret_cast<const float4*>(r) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a[c][ky][0] = (ok && x > 0) ? r[-1] : 0.f;
+                a[c][ky][1] = m.x; a[c][ky][2] = m.y; a[c][ky][3] = m.z; a[c][ky][4] = m.w;
+                a[c][ky][5] = (ok && x + 4 < W) ? r[4] : 0.f;
+            }
+        const long long pix = (b * H + y) * W + x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) {
+                float o[8];
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) {
+                    const int k = cg * 8 + k8, c = k / 9, t = k - c * 9;        // compile-time after unrolling
+                    o[k8] = k < 27 ? a[c < 3 ? c : 0][t / 3][j + t % 3] : 0.f;
+                }
+                Vec8<T>::store(dst + (pix + j) * ldc + cg * 8, o);
+            }
+    }
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int ldc, float* dst, int B, int C, int H, int W) {
     const long long hw = (long long)H * W, n = (long long)B * C * hw;
@@ -695,6 +735,16 @@ int clamd_nchw_im2col3(const float* src, void* dst, int ldc, int B, int C, int H
     const long long nitem = (long long)B * H * W;
     dim3 g(ew_grid(nitem, 8192)), b(256);
     hipStream_t s = (hipStream_t)stream;
+    if (C <= 3 && Cp == 32 && W % 4 == 0 && ((size_t)src % 16) == 0) {
+        const dim3 g4(ew_grid(nitem / 4, 8192));
+#define LAUNCH4(T) hipLaunchKernelGGL(nchw_im2col3x4_kernel<T>, g4, b, 0, s, src, (T*)dst, ldc, B, C, H, W)
+        if (dtype == CLAMD_BF16) LAUNCH4(bf16_t);
+        else if (dtype == CLAMD_F32) LAUNCH4(float);
+        else if (dtype == CLAMD_SPLIT) LAUNCH4(split_t);
+        else return clamd_fail("nchw_im2col3: bad dtype");
+#undef LAUNCH4
+        return clamd_check_launch("nchw_im2col3");
+    }
 #define LAUNCH(T) hipLaunchKernelGGL(nchw_im2col3_kernel<T>, g, b, 0, s, src, (T*)dst, ldc, B, C, H, W, Cp)
     if (dtype == CLAMD_BF16) LAUNCH(bf16_t);
     else if (dtype == CLAMD_F32) LAUNCH(float);
