@@ -27,7 +27,6 @@ class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, plan, *params):
         ops, dcode, training, buffers = plan
-        lib = _lib.load()
         T = TORCH_DT[dcode]
         dev = x.device
         s = _stream()
@@ -102,7 +101,6 @@ class _BlockFn(torch.autograd.Function):
                 saved.append(('head', cur, wd, (cin, cin_p, k, kp, H, W)))
                 cur = None
         ctx.saved_ops, ctx.dcode, ctx.B, ctx.cin0, ctx.training = saved, dcode, B, C, training
-        ctx.shapes = [tuple(p.shape) for p in params]
         if cur is None:
             return logits
         last = ops[-1]
