@@ -59,8 +59,8 @@ SIGNATURES = {
     'clamd_conv3x3': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_conv3x3_border_bias_ok': (_I, [_I, _I, _I, _I, _I, _I, _P]),
     'clamd_bn_fold_bias': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
-    'clamd_maxpool2x2': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
-    'clamd_maxpool2x2_bwd': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_maxpool2x2': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_maxpool2x2_bwd': (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_bn_fold_pack': (_I, [_I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     'clamd_bn_fold_wgrad_pointwise': (_I, [_P, _P, _P, _P, _I, _I, _P]),
     'clamd_bn_fold_wgrad_workspace_bytes': (_SZ, [_I, _I]),

@@ -38,7 +38,7 @@ class _BlockFn(torch.autograd.Function):
                 if (H | W) & 1:
                     raise ValueError('MaxPool2d(2,2) block: H and W must be even')
                 out = torch.empty(B, H // 2, W // 2, cur.shape[-1], dtype=T, device=dev)
-                call('clamd_maxpool2x2', ptr(cur), cur.shape[-1], ptr(out), out.shape[-1], B, H, W, cur.shape[-1], dcode, s)
+                call('clamd_maxpool2x2', ptr(cur), cur.shape[-1], None, ptr(out), out.shape[-1], B, H, W, cur.shape[-1], dcode, s)
                 saved.append(('pool', cur, H, W))
                 cur, H, W = out, H // 2, W // 2
             elif op[0] == 'crb':
@@ -177,7 +177,7 @@ class _BlockFn(torch.autograd.Function):
                 cp = x.shape[-1]
                 gp = to_nhwc(gout, dcode, cp=cp) if g is None else g
                 gx = torch.empty(B, H, W, cp, dtype=T, device=dev)
-                call('clamd_maxpool2x2_bwd', ptr(x), cp, ptr(gp), cp, ptr(gx), cp, B, H, W, cp, dcode, s)
+                call('clamd_maxpool2x2_bwd', ptr(x), cp, None, ptr(gp), cp, ptr(gx), cp, B, H, W, cp, dcode, s)
                 g = gx
         gin = from_nhwc(g, ctx.cin0, dcode) if ctx.needs_input_grad[0] else None
         return (gin, None) + tuple(grads)

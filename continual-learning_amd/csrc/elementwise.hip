@@ -124,9 +124,12 @@ __global__ void bn_apply_kernel(const T* __restrict__ y, int y_ldc, const float*
 // nn.MaxPool2d(2,2) on its own (models/unet.py:12: the first layer of a DownBlock run as a stand-alone block, blocks.py; inside the
 // UNet step the pool is part of bn_apply / bn_bwd_*).  Forward: window maximum; backward: the gradient goes to the FIRST maximum of
 // the window (the tie rule of bn_apply_kernel / load_gu and of torch's CPU kernel), zeros elsewhere.
+// sign (optional, [Cp]): channels with sign[c] < 0 take the window MINIMUM -- the max-pool of a tensor s * x + t that is never written
+// (a BatchNorm folded into its consumers, bnfold.hip) taken on x itself: max(s x + t) = s min(x) + t for s < 0.
 template <typename T, bool BWD>
 __global__ void __launch_bounds__(256) maxpool2x2_kernel(const T* __restrict__ x, int x_ldc, T* __restrict__ out, int o_ldc,
-                                                        const T* __restrict__ gp, int gp_ldc, int B, int H, int W, int Cp) {
+                                                        const T* __restrict__ gp, int gp_ldc, const float* __restrict__ sign,
+                                                        int B, int H, int W, int Cp) {
     const int G = Cp >> 3, w2 = W / 2, h2 = H / 2;
     const long long nitem = (long long)B * h2 * w2 * G;
     for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < nitem; it += (long long)gridDim.x * blockDim.x) {
@@ -135,13 +138,16 @@ __global__ void __launch_bounds__(256) maxpool2x2_kernel(const T* __restrict__ x
         const int px = (int)(pix % w2), py = (int)((pix / w2) % h2), b = (int)(pix / ((long long)w2 * h2));
         float m[8], v[4][8];
         int arg[8];
+        bool neg[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) neg[j] = sign != nullptr && sign[cg * 8 + j] < 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long long p = ((long long)b * H + 2 * py + (q >> 1)) * W + 2 * px + (q & 1);
             Vec8<T>::load(x + p * x_ldc + cg * 8, v[q]);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (q == 0 || v[q][j] > m[j]) { m[j] = v[q][j]; arg[j] = q; }
+                if (q == 0 || (neg[j] ? v[q][j] < m[j] : v[q][j] > m[j])) { m[j] = v[q][j]; arg[j] = q; }
         }
         if constexpr (!BWD) Vec8<T>::store(out + pix * o_ldc + cg * 8, m);
         else {
@@ -587,8 +593,8 @@ int clamd_bn_apply(const void* y, int y_ldc, const float* scale, const float* sh
     return clamd_check_launch("bn_apply");
 }
 
-static int launch_maxpool(bool bwd, const void* x, int x_ldc, void* out, int o_ldc, const void* gp, int gp_ldc, int B, int H, int W, int Cp,
-                          int dtype, void* stream) {
+static int launch_maxpool(bool bwd, const void* x, int x_ldc, void* out, int o_ldc, const void* gp, int gp_ldc, const float* sign, int B, int H,
+                          int W, int Cp, int dtype, void* stream) {
     if (!x || !out || (bwd && !gp)) return clamd_fail("maxpool2x2: null argument");
     if (B <= 0 || H <= 0 || W <= 0 || ((H | W) & 1)) return clamd_fail("maxpool2x2: needs even H, W");
     if (Cp % 8 || x_ldc < Cp || o_ldc < Cp || (bwd && gp_ldc < Cp)) return clamd_fail("maxpool2x2: bad channel counts / pitches");
@@ -600,8 +606,8 @@ static int launch_maxpool(bool bwd, const void* x, int x_ldc, void* out, int o_l
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(T)                                                                                                                   \
     do {                                                                                                                            \
-        if (bwd) hipLaunchKernelGGL((maxpool2x2_kernel<T, true>), g, b, 0, s, (const T*)x, x_ldc, (T*)out, o_ldc, (const T*)gp, gp_ldc, B, H, W, Cp); \
-        else hipLaunchKernelGGL((maxpool2x2_kernel<T, false>), g, b, 0, s, (const T*)x, x_ldc, (T*)out, o_ldc, (const T*)nullptr, 0, B, H, W, Cp);   \
+        if (bwd) hipLaunchKernelGGL((maxpool2x2_kernel<T, true>), g, b, 0, s, (const T*)x, x_ldc, (T*)out, o_ldc, (const T*)gp, gp_ldc, sign, B, H, W, Cp); \
+        else hipLaunchKernelGGL((maxpool2x2_kernel<T, false>), g, b, 0, s, (const T*)x, x_ldc, (T*)out, o_ldc, (const T*)nullptr, 0, sign, B, H, W, Cp);   \
     } while (0)
     if (dtype == CLAMD_BF16) LAUNCH(bf16_t);
     else if (dtype == CLAMD_F32) LAUNCH(float);
@@ -611,13 +617,13 @@ static int launch_maxpool(bool bwd, const void* x, int x_ldc, void* out, int o_l
     return clamd_check_launch("maxpool2x2");
 }
 
-int clamd_maxpool2x2(const void* x, int x_ldc, void* pooled, int p_ldc, int B, int H, int W, int Cp, int dtype, void* stream) {
-    return launch_maxpool(false, x, x_ldc, pooled, p_ldc, nullptr, 0, B, H, W, Cp, dtype, stream);
+int clamd_maxpool2x2(const void* x, int x_ldc, const float* sign, void* pooled, int p_ldc, int B, int H, int W, int Cp, int dtype, void* stream) {
+    return launch_maxpool(false, x, x_ldc, pooled, p_ldc, nullptr, 0, sign, B, H, W, Cp, dtype, stream);
 }
 
-int clamd_maxpool2x2_bwd(const void* x, int x_ldc, const void* gp, int gp_ldc, void* gx, int gx_ldc, int B, int H, int W, int Cp,
+int clamd_maxpool2x2_bwd(const void* x, int x_ldc, const float* sign, const void* gp, int gp_ldc, void* gx, int gx_ldc, int B, int H, int W, int Cp,
                          int dtype, void* stream) {
-    return launch_maxpool(true, x, x_ldc, gx, gx_ldc, gp, gp_ldc, B, H, W, Cp, dtype, stream);
+    return launch_maxpool(true, x, x_ldc, gx, gx_ldc, gp, gp_ldc, sign, B, H, W, Cp, dtype, stream);
 }
 
 int clamd_bn_bwd_reduce(const void* ga, int ga_ldc, const void* gp, int gp_ldc, const void* y, int y_ldc,

@@ -58,6 +58,12 @@ NARROW_DIRECT = os.environ.get('CLAMD_NARROW_DIRECT', '1') != '0'
 # fp32-storage paths only (the 1x1 head folds everywhere); True = every compute dtype; False = never.
 FOLD_BN_INTO_FILTERS = {'0': False, 'false': False, 'all': True, 'true': True}.get(os.environ.get('CLAMD_FOLD_FILTERS', 'auto').lower(), 'auto')
 FOLD_FILTERS_MAX_CHANNELS = int(os.environ.get('CLAMD_FOLD_FILTERS_MAX_CHANNELS', '128'))
+# fp32 path: the same fold for the OUTPUT of an encoder block -- pooled into the next block, concatenated into the decoder (models/unet.py:80-87)
+# -- where both readers are narrow F(2x4) convolutions (enc1 -> enc2's first conv and last's first conv at config 2): the block's second conv
+# writes its conv+ReLU output straight into the concat slice, one pass pools it (window minimum where the BatchNorm scale is negative:
+# max(s x + t) = s min(x) + t), and the two readers take scale / shift in their filters and bias tables.  The pooled bn_apply pass of enc1
+# (603 MB, the largest elementwise pass of the step) becomes a 335 MB pooling pass.
+FOLD_POOLED = os.environ.get('CLAMD_FOLD_POOLED', '1') != '0'
 # fp32 path: ConvTranspose2d forward / data gradient as register-blocked GEMMs with operands loaded straight into the MFMA operand
 # registers (csrc/pw_direct.hip) instead of the LDS-staged 256-pixel x 64-channel tiles of igemm_kernel.
 # BUILT, MEASURED, OFF BY DEFAULT.  Alone the kernels are faster (tools/convt_direct_ab.py: forward 0.67 -> 0.64 ms, data gradient
@@ -320,6 +326,14 @@ class _UNetFn(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+class _FoldSource:
+    """What a folded convolution reads instead of a normalised tensor: the raw tensor (`y`, pitch `cout_p`) and the per-input-channel
+    scale / shift (`vec[0]`, `vec[1]`) that live in its filters and bias table -- the interface of the producing _Conv the pair fold uses."""
+
+    def __init__(self, y, pitch, scale, shift):
+        self.y, self.cout_p, self.vec, self.apply_in_filters = y, pitch, [scale, shift], False
+
+
 class _Conv:
     """One Conv3x3 -> ReLU -> BatchNorm unit and everything it needs in both directions."""
     pass
@@ -522,6 +536,30 @@ class _Engine:
                     and not a.split and not b.split and min(b.h, b.w_) >= 2 and b.cin_p <= FOLD_FILTERS_MAX_CHANNELS):
                 b.fold_a = a      # one direction only: a cycle between units would keep the engine's buffers alive until the garbage collector runs
                 b.cb = torch.zeros(9, b.cout_p, dtype=torch.float32, device=dev)
+        for u in convs:
+            u.pool_fold, u.y_ldc = False, u.cout_p
+        for k in range(3):
+            # ... and the output of an encoder block with two narrow F(2x4) readers (FOLD_POOLED): static (fp32 Winograd kernels take the
+            # border-class table under every tuning), because the raw tensor then lives where the normalised one would
+            b, nxt = self.stages[k]['convs'][1], self.stages[k + 1]['convs'][0]
+            dec = next((st_['convs'][0] for st_ in self.stages if st_['kind'] == 'dec' and st_['convs'][0].xin is self.cat[k]), None)
+            ok = (FOLD_POOLED and FOLD_BN_INTO_FILTERS and self.dcode == _lib.F32 and dec is not None and nxt.xin is self.pool[k]
+                  and all(c.w24 and not c.pre_f and c.fold_a is None and not c.split and c.cin_p <= FOLD_FILTERS_MAX_CHANNELS and min(c.h, c.w_) >= 2
+                          and all(lg == ph for lg, ph in c.cin_segs) for c in (nxt, dec))
+                  and b.w24 and not b.pre_f and not b.split and b.cout == b.cout_p and len(dec.cin_segs) == 2
+                  and dec.cin_segs[0] == (b.cout, b.cout_p))
+            if not ok:
+                continue
+            b.pool_fold, b.apply_in_filters = True, True
+            b.y, b.y_ldc = self.cat[k], self.cat[k].shape[-1]               # conv+ReLU output straight into the skip half of the concat buffer
+            comp = torch.zeros(2, dec.cin_p, dtype=torch.float32, device=dev)  # scale / shift over the decoder conv's input: [block | up-conv]
+            comp[0, b.cout_p:] = 1.0
+            vec = b.vec
+            b.vec = [comp[0, :b.cout_p], comp[1, :b.cout_p]] + [vec[i] for i in range(2, 7)]     # rows 4-6 (k0, k1, k2) stay contiguous
+            nxt.fold_a = _FoldSource(self.pool[k], self.pool[k].shape[-1], b.vec[0], b.vec[1])
+            dec.fold_a = _FoldSource(self.cat[k], self.cat[k].shape[-1], comp[0], comp[1])
+            for c in (nxt, dec):
+                c.cb = torch.zeros(9, c.cout_p, dtype=torch.float32, device=dev)
         for st in self.stages:
             t = st.get('tail')
             if t is None:
@@ -901,7 +939,7 @@ class _Engine:
             else:
                 name = ('clamd_conv3x3_winograd24_direct_filters' if u.direct_f else 'clamd_conv3x3_winograd24') if u.w24 else 'clamd_conv3x3_winograd'
                 extra = (None, None) if u.direct_f else ()           # bn_y, bn_sums: data-gradient launches only
-                _timed('igemm_conv3x3', flops, nbytes, name, ptr(xin), xin_ldc, ptr(u.wf), ptr(bias), ptr(y), u.cout_p, ptr(st), rows,
+                _timed('igemm_conv3x3', flops, nbytes, name, ptr(xin), xin_ldc, ptr(u.wf), ptr(bias), ptr(y), u.y_ldc, ptr(st), rows,
                        *extra, Bl, u.h, u.w_, u.cin_p, u.cout_p, relu, tp, s)
         else:
             _timed('igemm_conv3x3', flops, nbytes, 'clamd_conv3x3', ptr(xin), xin_ldc, ptr(u.wf), ptr(bias), ptr(y), u.cout_p,
@@ -915,6 +953,9 @@ class _Engine:
     def _fwd_post(self, u, s, hf):
         """BatchNorm apply (+ max-pool, concat placement) of unit u on the whole batch or one half of it."""
         if u.apply_folded:          # the only reader of the BatchNorm output is the next convolution's input transform
+            return
+        if u.pool_fold:             # ... or the filters and bias tables of both readers of an encoder block's output: only the pooling is left
+            call('clamd_maxpool2x2', ptr(u.y), u.y_ldc, ptr(u.vec[0]), ptr(u.pooled), u.pooled.shape[-1], self.B, u.h, u.w_, u.cout_p, self.dcode, s)
             return
         if u.apply_in_filters:      # ... or its filters and bias table (bnfold.hip)
             return
@@ -1041,11 +1082,11 @@ class _Engine:
         count = float(B * u.h * u.w_)
         g = self._gp
         if not u.fused_reduce:     # otherwise the five sums were accumulated by the epilogue of the kernel that wrote `ga`
-            call('clamd_bn_bwd_reduce', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.cout_p,
+            call('clamd_bn_bwd_reduce', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.y_ldc,
                  ptr(v[0]), ptr(v[1]), ptr(u.sums), u.sum_rows, B, u.h, u.w_, u.cout_p, dc, tp, s)
         call('clamd_bn_bwd_finalize', ptr(u.sums), u.sum_rows, ptr(u.gamma), ptr(v[2]), ptr(v[3]), ptr(v[4]), g[u.keys[2]],
              g[u.keys[3]], g[u.keys[1]], u.cout_p, u.cout, count, s)
-        call('clamd_bn_bwd_apply', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.cout_p,
+        call('clamd_bn_bwd_apply', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.y_ldc,
              ptr(v[0]), ptr(v[1]), ptr(v[4]), ptr(u.gz), u.cout_p, B, u.h, u.w_, u.cout_p, dc, s)
         if len(u.cin_segs) == 2:
             c_seg0, c_seg0p = u.cin_segs[0]

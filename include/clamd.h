@@ -265,9 +265,11 @@ int clamd_bn_bwd_apply(const void* ga, int ga_ldc, const void* gp, int gp_ldc, c
                        int H, int W, int Cp, int dtype, void* stream);
 /* nn.MaxPool2d(2,2) alone (models/unet.py:12: the first layer of a DownBlock run as a stand-alone block, blocks.py; inside the UNet step
  * the pool is part of clamd_bn_apply / clamd_bn_bwd_*): x [B,H,W,ldc] -> pooled [B,H/2,W/2,ldc]; backward: gx [B,H,W,ldc] = gp at the first
- * maximum of each window (the tie rule of clamd_bn_apply and of torch's CPU kernel), 0 elsewhere. */
-int clamd_maxpool2x2(const void* x, int x_ldc, void* pooled, int p_ldc, int B, int H, int W, int Cp, int dtype, void* stream);
-int clamd_maxpool2x2_bwd(const void* x, int x_ldc, const void* gp, int gp_ldc, void* gx, int gx_ldc, int B, int H, int W, int Cp,
+ * maximum of each window (the tie rule of clamd_bn_apply and of torch's CPU kernel), 0 elsewhere.
+ * sign (optional, [Cp]): channels with sign[c] < 0 take the window MINIMUM instead -- the pool of a tensor scale * x + shift that is never
+ * written (a BatchNorm folded into the consumers of the pooled tensor, see clamd_bn_fold_bias) taken on x: max(s x + t) = s min(x) + t. */
+int clamd_maxpool2x2(const void* x, int x_ldc, const float* sign, void* pooled, int p_ldc, int B, int H, int W, int Cp, int dtype, void* stream);
+int clamd_maxpool2x2_bwd(const void* x, int x_ldc, const float* sign, const void* gp, int gp_ldc, void* gx, int gx_ldc, int B, int H, int W, int Cp,
                          int dtype, void* stream);
 /* out[c] = sum_pixels g[p,c]  (bias gradients of convT / head): per-block partial rows in `workspace`
  * (>= clamd_channel_sum_workspace_bytes(Cp)), then a fixed-order fp64 sum -- no float atomics, out is overwritten. */

@@ -160,7 +160,12 @@ def test_engine_geometry_and_pack_table(C):
     # the second convolution of every block here (<= 128 channels) is a candidate for the algebraic BatchNorm fold (bnfold.hip): its
     # forward filters are packed inside the step by a one-job table of its own (with the producer's scale, or plain)
     fold = [u for u in e.convs if u.fold_a is not None]
-    assert len(fold) == 9 and all(u.fold_a.apply_in_filters and len(u.fold_table.jobs) == 1 and len(u.plain_table.jobs) == 1 for u in fold)
+    # ... plus the two readers of enc3's output (32 channels = its padded count; 64 x 64 input: 16 x 16 there), whose BatchNorm is folded
+    # into both: the block's second conv writes its conv+ReLU output into the concat buffer and only a pooling pass is left
+    pooled = [u for u in e.convs if u.pool_fold]
+    assert [u.name for u in pooled] == ['enc3.block.4'] and pooled[0].y is e.cat[2] and pooled[0].y_ldc == 64
+    assert sorted(u.name for u in fold if not hasattr(u.fold_a, 'name')) == ['dec3.block.0', 'enc4.block.1']
+    assert len(fold) == 11 and all(u.fold_a.apply_in_filters and len(u.fold_table.jobs) == 1 and len(u.plain_table.jobs) == 1 for u in fold)
     assert all(u.fold_table.jobs[0][-1] == u.fold_a.vec[0].data_ptr() and u.plain_table.jobs[0][-1] == 0 for u in fold)
     assert sum(len(t.jobs) for t in e.wino_early) == sum(2 - (u.fold_a is not None) for u in wino_units if not u.pack_late)
     assert nw == 2 * len(wino_units) - sum(1 for u in fold if u.wino)

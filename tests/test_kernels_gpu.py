@@ -1104,6 +1104,34 @@ def test_bn_fwd_bwd_pool(C, name, dcode, shape, pool):
                                atol=(1e-3 if dcode != 1 else 3e-2) * (np.abs(gz_ref.sum((0, 2, 3))).max() + 1e-6))
 
 
+@pytest.mark.parametrize('name,dcode', DT)
+def test_maxpool2x2_alone_and_signed(C, name, dcode):
+    """nn.MaxPool2d(2,2) on its own (models/unet.py:12; blocks.py) and its signed form (window minimum where sign < 0: the pool of a
+    BatchNorm output scale * x + shift taken on x, bnfold.hip): bit-exact against torch on the stored values, gradient to the first
+    extremum of the window; pitched input and output (a channel slice of a concat buffer)."""
+    import torch.nn.functional as F
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    rng = np.random.default_rng(5)
+    B, Cc, H, W = 2, 64, 12, 20
+    x = rb(rnd(rng, B, H, W, 2 * Cc), dcode)                                   # [B,H,W,128]: the op works on the first 64 channels
+    xt = nd(C, x, dcode)
+    sign = dev(np.where(rng.random(Cc) < 0.5, -1.0, 1.0).astype(np.float32))
+    T = C.ops.TORCH_DT[dcode]
+    for sg in (None, sign):
+        out = torch.zeros(B, H // 2, W // 2, Cc, dtype=T, device='cuda')
+        lib.call('clamd_maxpool2x2', ptr(xt), 2 * Cc, ptr(sg), ptr(out), Cc, B, H, W, Cc, dcode, s)
+        xs = torch.from_numpy(x[..., :Cc]).cuda().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+        sv = (sg if sg is not None else torch.ones(Cc, device='cuda')).view(1, -1, 1, 1)
+        ref = F.max_pool2d(xs * sv, 2, 2) * sv                                 # max for +1, min for -1 (exact: multiplication by +-1)
+        assert torch.equal(nf(C, out, dcode).permute(0, 3, 1, 2), ref.detach())
+        gp = rb(rnd(rng, B, H // 2, W // 2, Cc), dcode)
+        gx = torch.zeros(B, H, W, Cc, dtype=T, device='cuda')
+        lib.call('clamd_maxpool2x2_bwd', ptr(xt), 2 * Cc, ptr(sg), ptr(nd(C, gp, dcode)), Cc, ptr(gx), Cc, B, H, W, Cc, dcode, s)
+        ref.backward(torch.from_numpy(gp).cuda().permute(0, 3, 1, 2))         # d(pool)/dx = s * s = 1 at the selected element of each window
+        sync()
+        assert torch.equal(nf(C, gx, dcode).permute(0, 3, 1, 2), xs.grad)
+
+
 def test_bn_eval_mode(C):
     rng = np.random.default_rng(15)
     lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()

@@ -789,6 +789,43 @@ def test_batchnorm_folded_into_the_next_convolutions_filters(C, dtype, cd, size,
         assert torch.equal(m_on.predict(x), torch.max(lo_on, 1)[1])
 
 
+def test_batchnorm_of_an_encoder_block_folded_into_both_readers(C, monkeypatch):
+    """unet.FOLD_POOLED (fp32): the BatchNorm at the END of an encoder block folded into both readers of the block's output -- the next
+    block's first convolution (through the 2x2 max-pool) and the decoder convolution that takes it through the concat buffer
+    (models/unet.py:80-87).  The block's second convolution writes its conv+ReLU output into the concat slice, a pooling pass takes the
+    window maximum -- the MINIMUM where the BatchNorm scale is negative: half of the scales are made negative here -- and the readers carry
+    scale / shift in their filters and border-class bias tables ([scale | 1], [shift | 0] over the concatenated input).  One step against the
+    run without it (loss to rounding, gradients to the conditioning floor), bit-reproducible, eval mode and predict()."""
+    from continual_learning_amd import unet as U
+    nc, cd, B, size = 6, 64, 2, 64
+
+    def hook(m, opt):
+        with torch.no_grad():
+            m.enc1[5].weight[::2] *= -1.0           # negative BatchNorm scales: the pooling pass must take the window minimum there
+
+    monkeypatch.setattr(U, 'FOLD_POOLED', False)
+    ref = _one_step(C, 'fp32', nc, cd, B, size, hook=hook)
+    assert not any(u.pool_fold for u in next(iter(ref[3]._engines.values())).convs)
+    monkeypatch.setattr(U, 'FOLD_POOLED', True)
+    one = _one_step(C, 'fp32', nc, cd, B, size, hook=hook)
+    eng = next(iter(one[3]._engines.values()))
+    pf = [u for u in eng.convs if u.pool_fold]
+    assert [u.name for u in pf] == ['enc1.3'] and pf[0].y is eng.cat[0] and pf[0].y_ldc == 2 * pf[0].cout_p
+    readers = [u.name for u in eng.convs if u.fold_on and isinstance(u.fold_a, U._FoldSource)]
+    assert sorted(readers) == ['enc2.block.1', 'last.0'], readers
+    assert abs(float(one[0]) - float(ref[0])) < 2e-6 * abs(float(ref[0])), (float(one[0]), float(ref[0]))
+    assert float((one[1] - ref[1]).norm() / ref[1].norm()) < 1e-2
+    a, a2 = _one_step(C, 'fp32', nc, cd, B, size, hook=hook, steps=2), _one_step(C, 'fp32', nc, cd, B, size, hook=hook, steps=2)
+    assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1]) and torch.equal(a[2], a2[2])
+    x = torch.from_numpy(C.synth.images(5, B, 3, size, size)).cuda()
+    m_on, m_off = a[3].eval(), ref[3].eval()
+    m_off.load_state_dict(m_on.state_dict())
+    with torch.no_grad():
+        lo_on, lo_off = m_on(x), m_off(x)
+        assert rel_l2(lo_on.cpu().numpy(), lo_off.cpu().numpy()) < 2e-5
+        assert torch.equal(m_on.predict(x), torch.max(lo_on, 1)[1])
+
+
 def test_winograd_dgrad_with_fused_bn_backward_sums(C, monkeypatch):
     """unet.FUSE_WINO_SUMS (opt-in): the five BatchNorm-backward sums of a stage's first unit taken in the epilogue of the Winograd
     data-gradient launch (pre-transformed and direct-filter kernels of wino24g.hip) instead of the separate bn_bwd_reduce pass: the

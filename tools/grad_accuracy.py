@@ -80,7 +80,8 @@ for label, wino in (('ours', True), ('ours-direct', False)):
         bo = u.out[..., :u.cout_p]
         if u.apply_folded or u.apply_in_filters:
             # the normalised tensor is never written (folded into the consumer's transform / filters): apply scale and shift here
-            bo = (C.ops.split_decode(u.y) if eng.dcode == 2 else u.y.float()) * u.vec[0] + u.vec[1]
+            yv = u.y[..., :u.cout_p]          # (a pooled-fold unit keeps its conv+ReLU output in the concat buffer)
+            bo = (C.ops.split_decode(yv.contiguous()) if eng.dcode == 2 else yv.float()) * u.vec[0] + u.vec[1]
             bo_ = bo[..., :u.cout].permute(0, 3, 1, 2).cpu().numpy()
         else:
             bo_ = C.ops.from_nhwc(bo.contiguous(), u.cout, eng.dcode).cpu().numpy()
