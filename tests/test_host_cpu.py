@@ -176,6 +176,29 @@ def test_engine_geometry_and_pack_table(C):
     assert C.cpad(3) == 32 and C.cpad(21) == 32 and C.cpad(1024) == 1024
 
 
+def test_fold_plan_at_the_reference_width(C):
+    """Planning only (no kernel runs without a GPU): at conv_dim 64 the algebraic BatchNorm folds of bnfold.hip cover the second convolution of
+    enc1 / enc2 / dec4 / last, the 1x1 head, and both readers of enc1's output (its conv+ReLU output lives in the concat buffer); the wide
+    layers fold through their transform kernels instead; bf16 keeps the 3x3 pairs unfolded."""
+    from continual_learning_amd.unet import _Engine, _FoldSource
+    e = _Engine(C.UNet(21, 3, 64), 2, 64, 64, torch.device('cpu'))
+    pair = sorted(u.name for u in e.convs if u.fold_a is not None and not isinstance(u.fold_a, _FoldSource))
+    assert pair == ['dec4.block.3', 'enc1.3', 'enc2.block.4', 'last.3']
+    assert [u.name for u in e.convs if u.pool_fold] == ['enc1.3']
+    readers = {u.name: u.fold_a for u in e.convs if isinstance(u.fold_a, _FoldSource)}
+    assert sorted(readers) == ['enc2.block.1', 'last.0']
+    enc1b = next(u for u in e.convs if u.name == 'enc1.3')
+    assert readers['last.0'].y is e.cat[0] and readers['enc2.block.1'].y is e.pool[0] and enc1b.y is e.cat[0] and enc1b.y_ldc == 128
+    # the block's scale / shift vectors are the first halves of the decoder convolution's [scale | 1], [shift | 0]
+    assert enc1b.vec[0].data_ptr() == readers['last.0'].vec[0].data_ptr() and enc1b.vec[1].data_ptr() == readers['last.0'].vec[1].data_ptr()
+    assert torch.equal(readers['last.0'].vec[0][64:], torch.ones(64)) and torch.equal(readers['last.0'].vec[1], torch.zeros(128))
+    # (64 x 64 input: 4 x 4 images at the bottom, where the Winograd kernels do not apply)
+    assert sorted(u.name for u in e.convs if u.apply_folded) == ['dec2.block.0', 'dec3.block.0', 'enc3.block.1', 'enc4.block.1']
+    assert e.stages[-1]['tail'].fold_b.name == 'last.3'
+    eb = _Engine(C.UNet(21, 3, 64, compute_dtype='bf16'), 2, 64, 64, torch.device('cpu'))
+    assert not any(u.fold_a is not None or u.pool_fold for u in eb.convs) and eb.stages[-1]['tail'].fold_b is not None
+
+
 def test_fused_adam_state_dict_layout_without_gpu(C):
     p = torch.nn.Parameter(torch.zeros(3))
     opt = C.FusedAdam([p], lr=1e-4, betas=[0.5, 0.99])
