@@ -1,10 +1,10 @@
 """Two train steps (Adam, lr 1e-3: sign-like first update) on a small random configuration: gradient of the SECOND step of this path with
 the algebraic BatchNorm fold on / off and of stock torch fp32 on the GPU, each against stock torch fp64 on the CPU.  Tells a wrong gradient
-from the amplification of rounding-level differences by the first update.    python tools/fold_two_step.py [nc cd size B] [dtype]"""
+from the amplification of rounding-level differences by the first update.    python tests/diag/fold_two_step.py [nc cd size B] [dtype]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import continual_learning_amd as C  # noqa: E402

@@ -2,11 +2,11 @@
 Conv-ReLU-BN unit compared with the stock torch counterpart run in float64 on the CPU (oracle/torch_cpu.py): post-ReLU
 activation, BatchNorm output, saved inverse std, gradient w.r.t. the conv output, weight gradient -- for this path (Winograd
 and direct fp32 kernels) and for stock torch fp32 on the same GPU.
-    python tools/grad_accuracy.py [nc cd H W B] [dtype]"""
+    python tests/diag/grad_accuracy.py [nc cd H W B] [dtype]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import continual_learning_amd as C  # noqa: E402

@@ -150,6 +150,6 @@ def test_ddp_bf16_gradient_exchange_tracks_the_fp32_exchange():
     rel_u = float((upd - upd_ref).norm() / upd_ref.norm())
     print(f'bf16 exchange: update after {CFG["steps"]} steps rel {rel_u:.2e}')
     # Adam's sign-like first steps amplify rounding-level gradient differences into different trajectories: after ONE update the
-    # second-step gradients of stock torch fp32 and stock torch fp64 are already 10-33 % apart on this network (tools/fold_two_step.py);
+    # second-step gradients of stock torch fp32 and stock torch fp64 are already 10-33 % apart on this network (tests/diag/fold_two_step.py);
     # 0.24-0.27 measured here.  The bound only says the bf16 exchange is not a different optimisation (a sign error would give ~1.4).
     assert rel_u < 0.5, rel_u

@@ -756,7 +756,7 @@ def test_batchnorm_folded_into_the_next_convolutions_filters(C, dtype, cd, size,
     default on the fp32-storage paths, forced here for bf16 too): filters packed with the producer's scale, shift as a border-class bias
     table, weight gradient fixed up from the gradient's border sums -- the normalised tensor is never written.  Same mathematics: ONE train
     step agrees with the unfolded run to rounding (loss) and to the conditioning floor of this network's gradients (ReLU / max-pool tie
-    flips; a second step would compare two chaotic trajectories: tools/fold_two_step.py -- stock torch fp32 is
+    flips; a second step would compare two chaotic trajectories: tests/diag/fold_two_step.py -- stock torch fp32 is
     10-33 % from stock torch fp64 there, and so are both variants); bit-identical run after run over two steps, on one stream or three;
     eval mode and predict() agree with the unfolded model."""
     from continual_learning_amd import unet as U
