@@ -8,7 +8,8 @@ import os
 from ctypes import c_char_p, c_double, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libclamd.so')
+# CLAMD_LIB: an experiment build of the same sources (build.py --variant), for the A/B and diagnostic tools only
+LIB_PATH = os.environ.get('CLAMD_LIB') or os.path.join(_HERE, 'libclamd.so')
 
 F32, BF16, SPLIT = 0, 1, 2      # SPLIT = 'bf16x3': fp32 storage, 3-term split-bf16 MFMA
 WGRAD_CONV3, WGRAD_PW, WGRAD_UP2 = 0, 1, 2
@@ -22,7 +23,7 @@ class Tuning(ctypes.Structure):
     state; an engine owns one of these and passes it to every launch (None = library defaults)."""
     _fields_ = [(n, c_int) for n in ('igemm_pws', 'igemm_ws', 'igemm_variant', 'pws_wres', 'wgrad_ws', 'wgrad_dma',
                                      'wgrad_xcd', 'wgrad_blocks', 'wgrad_tw16', 'wino_band', 'wino_persist', 'wino_mt',
-                                     'bn_reduce_blocks', 'chsum_blocks', 'cu_reserve')] + [('reserved', c_int * 9)]
+                                     'bn_reduce_blocks', 'chsum_blocks', 'cu_reserve', 'pws_cl')] + [('reserved', c_int * 8)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -58,6 +59,7 @@ SIGNATURES = {
     'clamd_stat_rows': (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_conv3x3': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_conv3x3_border_bias_ok': (_I, [_I, _I, _I, _I, _I, _I, _P]),
+    'clamd_conv3x3_bn_sums': (_I, [_I, _I, _I, _I, _I, _I, _P]),
     'clamd_bn_fold_bias': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     'clamd_maxpool2x2': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_maxpool2x2_bwd': (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -79,6 +81,9 @@ SIGNATURES = {
     'clamd_bn_bwd_reduce': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_bn_bwd_finalize': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _P]),
     'clamd_bn_bwd_apply': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_bn_bwd_apply_sums_rows': (_I, [_I, _I, _I, _I]),
+    'clamd_bn_bwd_apply_sums': (_I, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'clamd_rows_sum': (_I, [_P, _I, _P, _I, _I, _P]),
     'clamd_channel_sum_workspace_bytes': (_SZ, [_I]),
     'clamd_channel_sum': (_I, [_P, _I, _P, _LL, _I, _I, _I, _P, _SZ, _P, _P]),
     'clamd_nchw_to_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _D, _I, _P]),
@@ -105,6 +110,8 @@ SIGNATURES = {
     'clamd_ce_workspace_bytes': (_SZ, []),
     'clamd_ce_bad_label_count_offset': (_SZ, []),
     'clamd_ce_fwd_bwd': (_I, [_P, _P, _P, _I, _I, _D, _D, _P, _P, _P, _SZ, _I, _I, _I, _I, _LL, _D, _P]),
+    'clamd_ce_count': (_I, [_P, _I, _I, _I, _I, _LL, _P, _SZ, _P]),
+    'clamd_ce_fwd_bwd_counted': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _SZ, _I, _I, _I, _I, _LL, _D, _P]),
     'clamd_adam_step': (_I, [_P, _P, _I, _P, _P, _P, _P, _P]),
     'clamd_argmax_confusion': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'clamd_voc_prepare': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
@@ -113,6 +120,7 @@ SIGNATURES = {
     'clamd_f32_to_bf16': (_I, [_P, _P, _LL, _P]),
     'clamd_bf16_to_f32': (_I, [_P, _P, _LL, _P]),
     'clamd_scale_by_device_scalar': (_I, [_P, _LL, _P, _P]),
+    'clamd_scale_by_device_scalar_nhwc': (_I, [_P, _LL, _I, _P, _P]),
 }
 
 # include/clamd_debug.h: measurement scaffolding (tools/cu_steal.py), bound when present, never part of the product header

@@ -1,6 +1,7 @@
 """Builds libclamd.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
 
     python continual-learning_amd/build.py [--force]
+    python continual-learning_amd/build.py --variant NAME [-DFLAG ...] [--diag]     # experiment build -> build/NAME/libclamd.so (CLAMD_LIB)
 
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the snapshot.
 """
@@ -29,22 +30,33 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=True, diag=False):
+def build(force=False, verbose=True, diag=False, variant=None, extra_flags=()):
+    """variant: name of an EXPERIMENT build (A/B and diagnostic tools): written to build/<variant>/libclamd.so with its own objects,
+    loaded by a process that sets CLAMD_LIB to that path; the product library (variant None) is never touched by it."""
     global FLAGS
+    flags = list(FLAGS)
     if os.environ.get('CLAMD_EXTRA_FLAGS'):     # experiments (ablation builds): never for measurements that are reported
-        FLAGS = FLAGS + os.environ['CLAMD_EXTRA_FLAGS'].split()
+        flags += os.environ['CLAMD_EXTRA_FLAGS'].split()
+    flags += list(extra_flags)
     if diag:
-        FLAGS = FLAGS + ['-DCLAMD_DIAG']      # diagnostic build: in-kernel cycle stamps (never for measurements)
-    stamp = os.path.join(HERE, 'csrc', '.build_stamp')
+        flags += ['-DCLAMD_DIAG']             # diagnostic build: in-kernel cycle stamps (never for measurements)
+    out, objdir = OUT, CSRC
+    if variant:
+        objdir = os.path.join(HERE, '..', 'build', variant)
+        os.makedirs(objdir, exist_ok=True)
+        out = os.path.join(objdir, 'libclamd.so')
+    stamp = os.path.join(objdir, '.build_stamp')
+    saved, FLAGS = FLAGS, flags
     dig = _digest()
-    if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == dig:
-        return OUT
+    FLAGS = saved
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return out
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
 
     def cc(src):
-        obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        obj = os.path.join(objdir, src.replace('.hip', '.o'))
+        cmd = [hipcc] + flags + ['-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr[-6000:]}')
@@ -54,14 +66,17 @@ def build(force=False, verbose=True, diag=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(cc, SOURCES))
-    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs,
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs,
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stderr[-4000:])
     with open(stamp, 'w') as f:
         f.write(dig)
-    return OUT
+    return out
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv or '--diag' in sys.argv, diag='--diag' in sys.argv))
+    # python build.py [--force] [--diag] [--variant NAME [-Dflag ...]]
+    var = sys.argv[sys.argv.index('--variant') + 1] if '--variant' in sys.argv else None
+    print(build(force='--force' in sys.argv or ('--diag' in sys.argv and not var), diag='--diag' in sys.argv, variant=var,
+                extra_flags=[a for a in sys.argv[1:] if a.startswith('-D')]))

@@ -199,6 +199,13 @@ template <typename T> __device__ inline void buf_st8(__amdgpu_buffer_rsrc_t rs, 
     }
 }
 
+// max without the canonicalising v_max hipcc puts in front of fmaxf on an MFMA result (a NaN operand yields the other one, as fmaxf)
+__device__ inline float vmax_f32(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Row of accumulator register `reg` (0..15) for lane half h in a 32x32 MFMA tile; column = lane & 31.
 __device__ inline int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 

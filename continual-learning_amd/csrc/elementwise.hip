@@ -297,9 +297,13 @@ __global__ void __launch_bounds__(FIN_THREADS) bn_bwd_finalize_kernel(const floa
     if (c < C) {
         dgamma[c] = (float)(istd * (s[1] - mu * s[0]));
         dbeta[c] = (float)s[0];
-        dbias[c] = (float)(k0 * s[2] + k1 * s[4] + k2 * s[3]);
+        if (dbias) dbias[c] = (float)(k0 * s[2] + k1 * s[4] + k2 * s[3]);
     }
 }
+
+// g_z = k0 g + k1 y + k2 where the ReLU was active: ONE expression (two fused multiply-adds) for every apply kernel, so the variants
+// write the same bits
+__device__ inline float bn_bwd_gz(float k0, float k1, float k2, float g, float y) { return fmaf(k0, g, fmaf(k1, y, k2)); }
 
 template <typename T, bool POOL>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ ga, int ga_ldc, const T* __restrict__ gp, int gp_ldc,
@@ -325,7 +329,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ ga, int ga_ldc, const 
             Vec8<T>::load(ga + pix * ga_ldc + cg * 8, g);
             Vec8<T>::load(y + pix * y_ldc + cg * 8, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = v[j] > 0.f ? (k0[j] * g[j] + k1[j] * v[j] + k2[j]) : 0.f;
+            for (int j = 0; j < 8; ++j) g[j] = v[j] > 0.f ? bn_bwd_gz(k0[j], k1[j], k2[j], g[j], v[j]) : 0.f;
             Vec8<T>::store(gz + pix * gz_ldc + cg * 8, g);
         }
         return;
@@ -344,7 +348,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ ga, int ga_ldc, const 
             Vec8<T>::load(ga + pix * ga_ldc + cg * 8, g);
             Vec8<T>::load(y + pix * y_ldc + cg * 8, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = v[j] > 0.f ? (k0[j] * g[j] + k1[j] * v[j] + k2[j]) : 0.f;
+            for (int j = 0; j < 8; ++j) g[j] = v[j] > 0.f ? bn_bwd_gz(k0[j], k1[j], k2[j], g[j], v[j]) : 0.f;
             Vec8<T>::store(gz + pix * gz_ldc + cg * 8, g);
         } else {
             float sc[8], sh[8];
@@ -359,12 +363,57 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ ga, int ga_ldc, const 
                 const long long p = ((long long)b * H + 2 * py + (q >> 1)) * W + 2 * px + (q & 1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    g[q][j] = v[q][j] > 0.f ? (k0[j] * g[q][j] + k1[j] * v[q][j] + k2[j]) : 0.f;
+                    g[q][j] = v[q][j] > 0.f ? bn_bwd_gz(k0[j], k1[j], k2[j], g[q][j], v[q][j]) : 0.f;
                 Vec8<T>::store(gz + p * gz_ldc + cg * 8, g[q]);
             }
         }
     }
 }
+
+// bn_bwd_apply without the pooling branch, plus the per-channel sum of the g_z it writes (= the gradient of the convolution's bias) as one
+// partial row per workgroup: the launches whose producing data-gradient kernel takes only sum g and sum g y (igemm_pws.hip, CLM = 3) get
+// the bias gradient here, where g_z exists anyway, instead of from three more running sums in the MFMA kernel's epilogue.
+// A thread's channel group is fixed (grid stride % G == 0: G is a power of two <= 256); the 256 / G threads of a group are added in
+// thread order through LDS: deterministic.
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_apply_sums_kernel(const T* __restrict__ ga, int ga_ldc, const T* __restrict__ y, int y_ldc,
+                                                                const float* __restrict__ k012, T* gz, int gz_ldc, float* rows,
+                                                                long long npix, int Cp) {
+    __shared__ float red[256 * 8];
+    const int G = Cp >> 3, tid = threadIdx.x;
+    const long long nitem = npix * G;
+    const long long it0 = (long long)blockIdx.x * 256 + tid;
+    const int cg = (int)(it0 % G);
+    float k0[8], k1[8], k2[8], acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        k0[j] = k012[cg * 8 + j]; k1[j] = k012[Cp + cg * 8 + j]; k2[j] = k012[2 * Cp + cg * 8 + j];
+        acc[j] = 0.f;
+    }
+    for (long long it = it0; it < nitem; it += (long long)gridDim.x * 256) {
+        const long long pix = it / G;
+        float g[8], v[8];
+        Vec8<T>::load(ga + pix * ga_ldc + cg * 8, g);
+        Vec8<T>::load(y + pix * y_ldc + cg * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            g[j] = v[j] > 0.f ? bn_bwd_gz(k0[j], k1[j], k2[j], g[j], v[j]) : 0.f;
+            acc[j] += g[j];
+        }
+        Vec8<T>::store(gz + pix * gz_ldc + cg * 8, g);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = acc[j];
+    __syncthreads();
+    const int per = 256 / G;                       // threads per channel group: tid = q * G + cg
+    for (int c = tid; c < Cp; c += 256) {
+        const int g8 = c >> 3, j = c & 7;
+        float t = 0.f;
+        for (int q = 0; q < per; ++q) t += red[(q * G + g8) * 8 + j];
+        rows[(size_t)blockIdx.x * Cp + c] = t;
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Per-channel sum of an NHWC tensor (bias gradients of convT / head): every block writes its partial row [Cp] into the
@@ -678,6 +727,42 @@ int clamd_bn_bwd_apply(const void* ga, int ga_ldc, const void* gp, int gp_ldc, c
     else return clamd_fail("bn_bwd_apply: bad dtype");
 #undef LAUNCH
     return clamd_check_launch("bn_bwd_apply");
+}
+
+static long long apply_sums_rows(long long npix, int Cp) {
+    const long long g = (npix * (Cp / 8) + 255) / 256;
+    return g < 1 ? 1 : (g > 2048 ? 2048 : g);
+}
+
+int clamd_bn_bwd_apply_sums_rows(int B, int H, int W, int Cp) {
+    if (B <= 0 || H <= 0 || W <= 0 || !pow2_channels(Cp)) return clamd_fail("bn_bwd_apply_sums_rows: bad sizes");
+    return (int)apply_sums_rows((long long)B * H * W, Cp);
+}
+
+int clamd_bn_bwd_apply_sums(const void* ga, int ga_ldc, const void* y, int y_ldc, const float* k012, void* gz, int gz_ldc,
+                            float* gz_rows, int nrows, int B, int H, int W, int Cp, int dtype, void* stream) {
+    if (!pow2_channels(Cp)) return clamd_fail("bn_bwd_apply_sums: physical channels must be a power of two in [32,2048]");
+    if (!ga || !y || !k012 || !gz || !gz_rows) return clamd_fail("bn_bwd_apply_sums: null argument");
+    if (int e = clamd_check_split(dtype, ga, ga_ldc)) return e;
+    if (int e = clamd_check_split(dtype, y, y_ldc)) return e;
+    if (int e = clamd_check_split(dtype, gz, gz_ldc)) return e;
+    const long long npix = (long long)B * H * W;
+    if (nrows != apply_sums_rows(npix, Cp)) return clamd_fail("bn_bwd_apply_sums: nrows must be clamd_bn_bwd_apply_sums_rows(B, H, W, Cp)");
+    dim3 g((unsigned)nrows), b(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(T) hipLaunchKernelGGL((bn_bwd_apply_sums_kernel<T>), g, b, 0, s, (const T*)ga, ga_ldc, (const T*)y, y_ldc, k012, (T*)gz, gz_ldc, gz_rows, npix, Cp)
+    if (dtype == CLAMD_BF16) LAUNCH(bf16_t);
+    else if (dtype == CLAMD_F32) LAUNCH(float);
+    else if (dtype == CLAMD_SPLIT) LAUNCH(split_t);
+    else return clamd_fail("bn_bwd_apply_sums: bad dtype");
+#undef LAUNCH
+    return clamd_check_launch("bn_bwd_apply_sums");
+}
+
+int clamd_rows_sum(const float* rows, int nrows, float* out, int Cp, int C, void* stream) {
+    if (!rows || !out || nrows <= 0 || Cp <= 0 || Cp % 8 || C > Cp) return clamd_fail("rows_sum: bad arguments");
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(Cp / 8), dim3(FIN_THREADS), 0, (hipStream_t)stream, rows, nrows, out, Cp, C);
+    return clamd_check_launch("rows_sum");
 }
 
 size_t clamd_channel_sum_workspace_bytes(int Cp) { return (size_t)CHSUM_MAX_BLOCKS * (Cp > 0 ? Cp : 0) * sizeof(float); }

@@ -34,7 +34,19 @@ __device__ unsigned long long g_pws_diag[8];
 // RAGGED = false (image height and width are multiples of the tile): no edge masks anywhere.  With one kernel for both
 // cases hipcc merged the `full` and the ragged branch of the epilogue into one select-per-element version (16 compares,
 // 30 v_cndmask, 18 s_and per 32x64 block: 283 instead of ~215 instructions for EVERY tile).
-template <typename T, int TW, bool RAGGED, bool CLS = false>      // CLS: bias from a border-class table (IgemmParams::bias_classes)
+//
+// CLM (bf16): "channels in the lane" epilogues.  The MFMA takes the FILTER fragment as its row operand and the pixel fragment as its
+// column operand, so lane (r, h) ends up with one PIXEL (column r) and 16 output channels per 32-channel block; the filter rows are
+// read through a lane permutation (bits 2 and 3 of r exchanged) that makes those 16 channels two runs of 8 CONSECUTIVE ones:
+//   accumulator e of lane (r, h), block nt  ->  channel 32 nt + 16 (e >> 3) + 8 h + (e & 7)
+// i.e. a lane's registers 8q .. 8q+7 are one 16-byte piece of the NHWC output and go to memory with one buffer store -- no LDS
+// transposition (32 ds_write_b32 + 8 ds_read_b128 per 32 x 64 block in the CLM = 0 epilogue), the bias is the accumulator's initial
+// value, and the per-channel statistics are running sums per accumulator register (64 registers, reduced over the 32 pixel lanes once
+// per workgroup).  Per 256-pixel tile and wave ~170 instead of ~430 non-MFMA instructions on a forward launch.
+//   CLM 0: the wave-private transposition epilogue (fp32 / bf16x3 storage)          1: plain (data gradient: no bias, ReLU, statistics)
+//   CLM 2: bias (+ border-class table, CLS) + ReLU + statistics                      3: plain + the two running sums of the consumer's
+//                                                                                       BatchNorm backward (sum g, sum g y: rows k = 0, 1)
+template <typename T, int TW, bool RAGGED, bool CLS = false, int CLM = 0>      // CLS: bias from a border-class table (IgemmParams::bias_classes)
 __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, const int gm, const int w_resident) {
     constexpr int MT = 2;
     using G = WsGeo<TW, MT>;
@@ -46,9 +58,13 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
     // 16 banks when they write; 72 (conflict-free writes) was measured no faster in the write phase (it is VALU-issue
     // bound: 34.7k cycles either way) and slower in the read-back (6.0k -> 8.9k cycles), -DPWS_EPW=72 to reproduce.
     constexpr int EPW = PWS_EPW;
-    constexpr int EPI_SLOTS = (4 * 32 * EPW + 8 * 64) / 4;       // 4 waves x [32][EPW] fp32 + statistics hand-over
+    constexpr bool CL = CLM != 0;
+    static_assert(!CL || sizeof(T) == 2, "channels-in-the-lane epilogues: bf16 storage");
+    static_assert(!CLS || CLM == 0 || CLM == 2, "the border-class table belongs to the bias epilogue");
+    constexpr int EPI_SLOTS = CL ? 0 : (4 * 32 * EPW + 8 * 64) / 4;       // 4 waves x [32][EPW] fp32 + statistics hand-over
     static_assert((2 * STAGE + EPI_SLOTS) * 16 <= 160 * 1024, "two LDS stages + the epilogue region must fit one CU");
     __shared__ uint4 smem[2 * STAGE + EPI_SLOTS];
+    static_assert(!CL || 2 * STAGE * 16 >= 2 * 64 * 4 * 33 * 4, "the final hand-over of the running sums reuses the two stages");
     // CLS: this workgroup's 64 columns of the [9][Np] border-class bias table (a folded BatchNorm, bnfold.hip), filled by the consumers while
     // they wait for the first stage: a border tile then takes its biases from LDS, not through two dependent global round trips per row tile
     __shared__ float cls_tab[CLS ? 9 * 64 : 1];
@@ -72,7 +88,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
     // bf16 data-gradient launches may also accumulate the five per-channel sums of the consumer's fused ReLU/BatchNorm
     // backward (IgemmParams::bn_y / bn_sums): registers across tiles, one flush per workgroup; the saved activation
     // pieces are fetched while the last K-step of the tile is still multiplying.
-    constexpr bool BN = sizeof(T) == 2;
+    constexpr bool BN = sizeof(T) == 2 && CLM == 0;
     const bool do_bn = BN && p.bn_y != nullptr;
     float bs[BN ? 5 : 1][8];
 #pragma unroll
@@ -212,6 +228,194 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
 #undef PWS_STORE_IN
 #undef PWS_STORE_W
 #undef PWS_PROTO_AFFINE
+    } else if constexpr (CL) {
+        // ------------------------------------------------------------------ consumers, channels in the lane (see the head of the kernel)
+        int apix[MT];
+        unsigned st_vo[MT], bn_vo[CLM == 3 ? MT : 1];      // tile-relative byte offsets: pixel of MFMA column r, channel piece 8 h
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = 32 * MT * cw + 32 * mt + r;
+            apix[mt] = (m / TW) * HW_ + (m % TW);
+            st_vo[mt] = (unsigned)(((m / TW) * p.W + m % TW) * p.y_ldc + n0 + 8 * h) * 2u;
+            if constexpr (CLM == 3) bn_vo[mt] = (unsigned)(((m / TW) * p.W + m % TW) * p.Np + n0 + 8 * h) * 2u;
+        }
+        const int rperm = (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1);      // filter row behind MFMA row r: bits 2 and 3 exchanged
+        const bool nt1 = n0 + 32 < p.Np;                                      // the slab's second 32-channel block exists (wave-uniform)
+        float bcl[CLM == 2 ? 2 : 1][16];                                      // bias (class 4 of a border-class table) per accumulator register
+        float cs1[CLM >= 2 ? 2 : 1][16], cs2[CLM >= 2 ? 2 : 1][16];           // running sums per accumulator register, across tiles
+        if constexpr (CLM == 2) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int n = n0 + 32 * nt + 16 * (e >> 3) + 8 * h + (e & 7);
+                    bcl[nt][e] = (p.bias && n < p.Np) ? p.bias[(CLS ? 4 * p.Np : 0) + n] : 0.f;
+                }
+        }
+        if constexpr (CLM >= 2) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { cs1[nt][e] = 0.f; cs2[nt][e] = 0.f; }
+        }
+        if constexpr (CLS) {      // what a border pixel's bias differs by from the interior's (class 4), natural channel order
+            for (int i = ltid; i < 9 * 64; i += 256) {
+                const int n = n0 + (i & 63);
+                cls_tab[i] = n < p.Np ? p.bias[(i >> 6) * p.Np + n] - p.bias[4 * p.Np + n] : 0.f;
+            }
+        }
+        const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+        const unsigned y_img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.y_ldc * 2u;
+        const unsigned bn_img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.Np * 2u;      // bn_y: dense pitch Np
+        uint4 ypc[CLM == 3 ? MT : 1][4];             // saved-activation pieces [nt * 2 + q] of the tile being finished
+        unsigned long long d0 = PWD_T(), d1, d2, dk = 0, db = 0, de = 0;
+        (void)d1; (void)d2; (void)dk; (void)db; (void)de;
+        __syncthreads();                                   // step 0 is staged
+        PWD_ADD(0, PWD_T() - d0);
+        for (int ti = 0; ti < T_; ++ti) {
+            const int tm = mg + ti * gm;
+            const int x0 = (tm % tiles_x) * TW, y0 = ((tm / tiles_x) % tiles_y) * TH, b = tm / (tiles_x * tiles_y);
+            const bool full = !RAGGED || (y0 + TH <= p.H && x0 + TW <= p.W);           // wave-uniform
+            f32x16 acc[MT][2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = CLM == 2 ? bcl[j][e] : 0.f;      // the bias is where the sum starts
+
+            for (int ks = 0; ks < nk; ++ks) {
+                d0 = PWD_T();
+                const uint4* sm = smem + (ks & 1) * STAGE;
+                if constexpr (CLM == 3) {
+                    if (ks == nk - 1) {                            // wave-uniform: fetch the saved activation under the last K-step
+                        const __amdgpu_buffer_rsrc_t brs = make_rsrc((const char*)p.bn_y + (size_t)b * bn_img, bn_img);
+                        const unsigned bso = (unsigned)((y0 * p.W + x0) * p.Np) * 2u;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            unsigned vo = bn_vo[mt];
+                            if (!full) {
+                                const int m = 32 * MT * cw + 32 * mt + r;
+                                if (!(y0 + m / TW < p.H && x0 + m % TW < p.W)) vo = BUF_OOB;
+                            }
+#pragma unroll
+                            for (int pc = 0; pc < 4; ++pc)
+                                ypc[mt][pc] = buf_ld16(brs, (pc < 2 || nt1) ? vo + 32u * pc : BUF_OOB, bso);
+                        }
+                    }
+                }
+                constexpr int NSTEP = 2 * NT;
+                uint4 f[2][MT + 2];      // [buffer][pixel fragments a[mt] ..., filter fragments b0, b1]
+#define PCL_FRAG(s_, d_)                                                                                          \
+    do {                                                                                                          \
+        const int t_ = (s_) >> 1, g_ = ((s_) & 1) * 2 + h;                                                        \
+        const int ib_ = (t_ / 3) * HW_ + (t_ % 3);                                                                \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < MT; ++mt_) d_[mt_] = sm[ib_ + g_ * NPIXP + apix[mt_]];          \
+        d_[MT] = sm[G::IN_SLOTS + (t_ * 4 + g_) * G::WG + rperm];                                                 \
+        d_[MT + 1] = sm[G::IN_SLOTS + (t_ * 4 + g_) * G::WG + 32 + rperm];                                        \
+    } while (0)
+                PCL_FRAG(0, f[0]);
+                __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);
+#pragma unroll
+                for (int st = 0; st < NSTEP; ++st) {
+                    if (st + 1 < NSTEP) PCL_FRAG(st + 1, f[(st + 1) & 1]);
+                    const uint4* c = f[st & 1];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        mma16<T>(c[MT], c[mt], acc[mt][0]);            // rows = filter rows (channels), columns = pixels
+                        mma16<T>(c[MT + 1], c[mt], acc[mt][1]);
+                    }
+                    if (st + 1 < NSTEP) sched_mfma_reads<2 * MT, MT + 2>();
+                    else __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT, 0);
+                }
+#undef PCL_FRAG
+                d1 = PWD_T();
+                __syncthreads();                           // hand the stage back to the producers
+                dk += d1 - d0; db += PWD_T() - d1;
+            }
+            d2 = PWD_T();
+
+            // ---- epilogue: a lane owns the pixel of its column; registers 8q .. 8q+7 of block nt are 16 bytes of the output
+            const __amdgpu_buffer_rsrc_t yrs = make_rsrc((const char*)p.y + (size_t)b * y_img, y_img);
+            const unsigned y_so = (unsigned)((y0 * p.W + x0) * p.y_ldc) * 2u;
+            bool border = false;
+            if constexpr (CLS) border = x0 == 0 || y0 == 0 || x0 + TW >= p.W || y0 + TH >= p.H;      // wave-uniform
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = 32 * MT * cw + 32 * mt + r;
+                bool pok = true;
+                if (!full) pok = y0 + m / TW < p.H && x0 + m % TW < p.W;
+                const unsigned vo = pok ? st_vo[mt] : BUF_OOB;
+                if constexpr (CLS) {
+                    if (border) {      // lanes on the image border add what their class's bias differs by (interior lanes read the zero row)
+                        const int cls = border_class(y0 + m / TW, x0 + m % TW, p.H, p.W);
+                        const float* row = cls_tab + (pok ? cls : 4) * 64 + 8 * h;
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                const float4 d0_ = *reinterpret_cast<const float4*>(row + 32 * nt + 16 * q);
+                                const float4 d1_ = *reinterpret_cast<const float4*>(row + 32 * nt + 16 * q + 4);
+                                acc[mt][nt][8 * q + 0] += d0_.x; acc[mt][nt][8 * q + 1] += d0_.y; acc[mt][nt][8 * q + 2] += d0_.z; acc[mt][nt][8 * q + 3] += d0_.w;
+                                acc[mt][nt][8 * q + 4] += d1_.x; acc[mt][nt][8 * q + 5] += d1_.y; acc[mt][nt][8 * q + 6] += d1_.z; acc[mt][nt][8 * q + 7] += d1_.w;
+                            }
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    if (nt == 1 && !nt1) break;            // wave-uniform
+                    float v[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = CLM == 2 ? vmax_f32(acc[mt][nt][e], relu_lo) : acc[mt][nt][e];
+                    if constexpr (CLM == 2) {
+                        if (p.stats) {                     // wave-uniform
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const float vs = full ? v[e] : (pok ? v[e] : 0.f);
+                                cs1[nt][e] += vs;
+                                cs2[nt][e] = fmaf(vs, vs, cs2[nt][e]);
+                            }
+                        }
+                    }
+                    if constexpr (CLM == 3) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const uint4 u = ypc[mt][nt * 2 + q];
+                            const float yv[8] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u),
+                                                 __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float g = full ? v[8 * q + j] : (pok ? v[8 * q + j] : 0.f);
+                                cs1[nt][8 * q + j] += g;
+                                cs2[nt][8 * q + j] = fmaf(g, yv[j], cs2[nt][8 * q + j]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        buf_st16(yrs, vo + (unsigned)(64 * nt + 32 * q), y_so,
+                                 make_uint4(pack2bf(v[8 * q + 0], v[8 * q + 1]), pack2bf(v[8 * q + 2], v[8 * q + 3]),
+                                            pack2bf(v[8 * q + 4], v[8 * q + 5]), pack2bf(v[8 * q + 6], v[8 * q + 7])));
+                }
+            }
+            de += PWD_T() - d2;
+        }
+        PWD_ADD(1, dk); PWD_ADD(2, db); PWD_ADD(3, de);
+        if (wave == 0) PWD_ADD(7, 1);
+        // running sums -> LDS (the stages are free: every wave is past the last K-step's barrier): [kind][channel][wave][pixel lane], pitch 33
+        if constexpr (CLM >= 2) {
+            if (CLM == 3 || p.stats) {
+                float* fb = reinterpret_cast<float*>(smem);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int c = 32 * nt + 16 * (e >> 3) + 8 * h + (e & 7);
+                        fb[((0 * 64 + c) * 4 + cw) * 33 + r] = cs1[nt][e];
+                        fb[((1 * 64 + c) * 4 + cw) * 33 + r] = cs2[nt][e];
+                    }
+            }
+        }
     } else {
         // ------------------------------------------------------------------ consumers: LDS fragments -> MFMA -> epilogue
         int apix[MT];
@@ -506,6 +710,30 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
     }
 
     // ---------------------------------------------------------------------- statistics: one flush per workgroup
+    if constexpr (CLM >= 2) {
+        // channels-in-the-lane epilogues: 128 (kind, channel) sums of 4 waves x 32 pixel lanes each, added in a fixed order -- thread
+        // (kind, channel, wave) adds its 32 lanes' values, two xor shuffles add the four waves -- and written as this workgroup's row
+        if (CLM == 3 || p.stats) {
+            __syncthreads();
+            const float* fb = reinterpret_cast<const float*>(smem);
+            const int kc = tid >> 2;
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) t += fb[tid * 33 + i];
+            t += __shfl_xor(t, 1);
+            t += __shfl_xor(t, 2);
+            const int k = kc >> 6, c = kc & 63;
+            if ((tid & 3) == 0 && n0 + c < p.Np) {
+                if constexpr (CLM == 2) p.stats[((size_t)mg * 2 + k) * p.Np + n0 + c] = t;
+                else p.bn_sums[((size_t)mg * 5 + k) * p.Np + n0 + c] = t;
+            }
+            if constexpr (CLM == 3) {      // rows 2-4 of the five-sum layout: not taken here (the conv-bias gradient comes from clamd_bn_bwd_apply)
+                if (tid < 192 && n0 + (tid & 63) < p.Np) p.bn_sums[((size_t)mg * 5 + 2 + (tid >> 6)) * p.Np + n0 + (tid & 63)] = 0.f;
+            }
+        }
+        return;
+    }
+    if constexpr (CLM == 1) return;
     if (p.stats) {
         float* sbuf = reinterpret_cast<float*>(smem + 2 * STAGE) + 4 * 32 * EPW;
         if (!producer) {
@@ -589,14 +817,27 @@ static int launch_pws_t(const IgemmParams& p, hipStream_t s, int dtype, const cl
     const long long nblk = gm * ntn;
     if (ntm > 0x7fffffff) return clamd_fail("igemm_pws: grid out of range");
     const bool ragged = (p.H % TH) != 0 || (p.W % TW) != 0;
+#define PWS_LAUNCH_K(TW_, RG_, CLS_, CLM_) hipLaunchKernelGGL((igemm_pws_kernel<T, TW_, RG_, CLS_, CLM_>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm, tn.pws_wres)
 #define PWS_LAUNCH(TW_, RG_)                                                                                                      \
     do {                                                                                                                           \
-        if (p.bias_classes) hipLaunchKernelGGL((igemm_pws_kernel<T, TW_, RG_, true>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm, tn.pws_wres); \
-        else hipLaunchKernelGGL((igemm_pws_kernel<T, TW_, RG_, false>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm, tn.pws_wres);              \
+        if constexpr (sizeof(T) == 2) {                                                                                            \
+            /* bf16: the channels-in-the-lane epilogues (tuning pws_cl = 0: the transposition epilogue, for A/B tools) */            \
+            const bool plain_ = !p.bias && !p.relu && !p.stats && !p.bias_classes;                                                 \
+            if (tn.pws_cl && p.bn_y && plain_) { PWS_LAUNCH_K(TW_, RG_, false, 3); break; }                                        \
+            if (tn.pws_cl && !p.bn_y) {                                                                                            \
+                if (plain_) PWS_LAUNCH_K(TW_, RG_, false, 1);                                                                      \
+                else if (p.bias_classes) PWS_LAUNCH_K(TW_, RG_, true, 2);                                                          \
+                else PWS_LAUNCH_K(TW_, RG_, false, 2);                                                                             \
+                break;                                                                                                             \
+            }                                                                                                                      \
+        }                                                                                                                          \
+        if (p.bias_classes) PWS_LAUNCH_K(TW_, RG_, true, 0);                                                                       \
+        else PWS_LAUNCH_K(TW_, RG_, false, 0);                                                                                     \
     } while (0)
     if (wide) { if (ragged) PWS_LAUNCH(32, true); else PWS_LAUNCH(32, false); }
     else { if (ragged) PWS_LAUNCH(16, true); else PWS_LAUNCH(16, false); }
 #undef PWS_LAUNCH
+#undef PWS_LAUNCH_K
     return clamd_check_launch("igemm_pws");
 }
 

@@ -35,6 +35,7 @@ int clamd_check_tuning(const clamd_tuning* t) {
     if (t->bn_reduce_blocks < 0 || t->bn_reduce_blocks > 65535) return clamd_fail("tuning: bn_reduce_blocks 0..65535");
     if (t->chsum_blocks < 0 || t->chsum_blocks > 1024) return clamd_fail("tuning: chsum_blocks 0..1024");
     if (t->cu_reserve < 0 || t->cu_reserve > 128) return clamd_fail("tuning: cu_reserve 0..128");
+    if (t->pws_cl < 0 || t->pws_cl > 1) return clamd_fail("tuning: pws_cl 0..1");
     return 0;
 }
 
@@ -156,6 +157,38 @@ __global__ void count_valid_kernel(const long long* __restrict__ labels, long lo
     }
 }
 
+// The same count as one partial pair per workgroup (plain stores: no memset in front, no serialised atomics behind); the consumers add the
+// CE_COUNT_BLOCKS pairs themselves (integers: any order gives the same sum).
+constexpr int CE_COUNT_BLOCKS = 256;
+__global__ void __launch_bounds__(256) count_valid_rows_kernel(const long long* __restrict__ labels, long long n, long long ignore_index,
+                                                               int K, unsigned int* rows /* [CE_COUNT_BLOCKS][2] */) {
+    unsigned int c = 0, bad = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long l = labels[i];
+        const bool in = l >= 0 && l < K;
+        c += (l != ignore_index && in) ? 1u : 0u;
+        bad += (l != ignore_index && !in) ? 1u : 0u;
+    }
+    __shared__ unsigned int wsum[2][4];
+    c = (unsigned int)wave_sum((float)c);   // <= 64 * iterations: exact in fp32 for the sizes used here
+    bad = (unsigned int)wave_sum((float)bad);
+    if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = c; wsum[1][threadIdx.x >> 6] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        rows[2 * blockIdx.x + 0] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+        rows[2 * blockIdx.x + 1] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+    }
+}
+// total of column `col` of those rows, by every thread of a 256-thread workgroup (through `tmp`, 4 words of LDS)
+__device__ inline unsigned int ce_count_total(const unsigned int* __restrict__ rows, int col, unsigned int* tmp) {
+    static_assert(CE_COUNT_BLOCKS == 256, "one row per thread");
+    unsigned int v = rows[2 * threadIdx.x + col];
+    v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return tmp[0] + tmp[1] + tmp[2] + tmp[3];
+}
+
 template <int KMAX>
 __global__ void __launch_bounds__(256) ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                  const float* __restrict__ old_logits, int K_old_total, int c_old,
@@ -240,14 +273,21 @@ __global__ void __launch_bounds__(256) ce_kernel(const float* __restrict__ logit
 // The training-step case (no distillation term, H * W a multiple of 4): four consecutive pixels per thread -- 16-byte loads and stores, K * 16
 // bytes in flight per lane instead of K * 4 -- and ONE exponential per logit (e = exp(z - max) is kept; softmax = e / sum).  176 MB at
 // config 2: 71 -> 4x us per launch (the scalar kernel above stays for the distillation term and for odd sizes).
-template <int KMAX>
+// NT != void: d logits is ALSO written as an NHWC tensor [pixel][ldc] of compute dtype NT (channels K .. 31 zero) -- the layout the 1x1
+// head's data gradient reads, so the backward pass needs no NCHW -> NHWC conversion (88 + 67 MB at config 2 in bf16): a thread's four
+// pixels are consecutive there too (4 x 64 bytes in bf16).
+struct ce_no_nhwc {};
+template <int KMAX, typename NT = ce_no_nhwc>
 __global__ void __launch_bounds__(256) ce4_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                   float* __restrict__ dlogits, float* __restrict__ partial,
                                                   const unsigned int* __restrict__ nvalid, int B, int K, long long HW,
-                                                  long long ignore_index, float grad_scale) {
+                                                  long long ignore_index, float grad_scale, NT* dl_nhwc = nullptr, int dl_ldc = 0,
+                                                  const unsigned int* __restrict__ count_rows = nullptr) {
     __shared__ float red[4];
+    __shared__ unsigned int cnt_tmp[4];
     const long long nq = (long long)B * HW / 4;
-    const float gs = grad_scale / (float)max(*nvalid, 1u);
+    const unsigned int nv = count_rows ? ce_count_total(count_rows, 0, cnt_tmp) : *nvalid;
+    const float gs = grad_scale / (float)max(nv, 1u);
     float ce_sum = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (long long)gridDim.x * blockDim.x) {
         const long long pix = 4 * i, b = pix / HW, p = pix - b * HW;
@@ -287,7 +327,25 @@ __global__ void __launch_bounds__(256) ce4_kernel(const float* __restrict__ logi
                 g.x = v[k].x * r.x - (lab[0] == k ? h.x : 0.f); g.y = v[k].y * r.y - (lab[1] == k ? h.y : 0.f);
                 g.z = v[k].z * r.z - (lab[2] == k ? h.z : 0.f); g.w = v[k].w * r.w - (lab[3] == k ? h.w : 0.f);
                 *reinterpret_cast<float4*>(d + k * HW) = g;
+                if constexpr (!__is_same(NT, ce_no_nhwc)) v[k] = g;
             }
+        if constexpr (!__is_same(NT, ce_no_nhwc)) {
+            NT* o = dl_nhwc + pix * dl_ldc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) {          // 32 physical channels: four groups of eight
+                    float t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = cg * 8 + j;
+                        float e = 0.f;
+                        if (k < KMAX) { if (k < K) e = q == 0 ? v[k < KMAX ? k : 0].x : q == 1 ? v[k < KMAX ? k : 0].y : q == 2 ? v[k < KMAX ? k : 0].z : v[k < KMAX ? k : 0].w; }
+                        t[j] = e;
+                    }
+                    Vec8<NT>::store(o + (long long)q * dl_ldc + cg * 8, t);
+                }
+        }
     }
     ce_sum = wave_sum(ce_sum);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ce_sum;
@@ -298,9 +356,15 @@ __global__ void __launch_bounds__(256) ce4_kernel(const float* __restrict__ logi
     }
 }
 
-__global__ void ce_finalize_kernel(const float* __restrict__ partial, int nblocks, const unsigned int* nvalid,
-                                   float inv_npix, float lam, float* out3) {
+__global__ void ce_finalize_kernel(const float* __restrict__ partial, int nblocks, unsigned int* nvalid,
+                                   float inv_npix, float lam, float* out3, const unsigned int* __restrict__ count_rows = nullptr) {
     __shared__ double red[2][256];
+    __shared__ unsigned int cnt_tmp[2][4];
+    if (count_rows) {      // the totals of the per-workgroup counts, left where the single-counter form keeps them
+        const unsigned int c = ce_count_total(count_rows, 0, cnt_tmp[0]), b = ce_count_total(count_rows, 1, cnt_tmp[1]);
+        if (threadIdx.x == 0) { nvalid[0] = c; nvalid[1] = b; }
+        __syncthreads();
+    }
     double a = 0, b = 0;
     for (int i = threadIdx.x; i < nblocks; i += 256) { a += partial[2 * i]; b += partial[2 * i + 1]; }
     red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
@@ -480,6 +544,20 @@ __global__ void scale_by_dev_kernel(float* p, long long n, const float* __restri
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] *= v;
 }
 
+// ... the same for an NHWC tensor of a compute dtype (the second copy of d logits the fused loss writes), 8-channel groups
+template <typename T>
+__global__ void scale_by_dev_t_kernel(T* p, long long ngroups, const float* __restrict__ scale) {
+    const float v = *scale;
+    if (v == 1.f) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < ngroups; i += (long long)gridDim.x * blockDim.x) {
+        float t[8];
+        Vec8<T>::load(p + i * 8, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] *= v;
+        Vec8<T>::store(p + i * 8, t);
+    }
+}
+
 // Rehearsal aid (tools/cu_steal.py, tests): `gridDim.x` workgroups that each keep one CU to themselves for `ticks`
 // 100-MHz ticks -- 96 KB of LDS per workgroup means at most one per CU and no room beside it for the 120-160-KB MFMA
 // workgroups of this library -- the way an RCCL channel workgroup holds a CU during a collective.  Every wave exits at the
@@ -562,7 +640,7 @@ int clamd_pack(const void* jobs_dev, int njobs, int total_blocks, int dtype, voi
     return clamd_launch_pack(jobs_dev, njobs, total_blocks, dtype, nullptr, (hipStream_t)stream);
 }
 
-size_t clamd_ce_workspace_bytes(void) { return (size_t)(2 * 2048 + 4) * sizeof(float); }
+size_t clamd_ce_workspace_bytes(void) { return (size_t)(2 * 2048 + 4 + 2 * CE_COUNT_BLOCKS) * sizeof(float); }
 size_t clamd_ce_bad_label_count_offset(void) { return (size_t)(2 * 2048 + 1) * sizeof(float); }
 
 int clamd_ce_fwd_bwd(const float* logits, const long long* labels, const float* old_logits, int K_old_total, int c_old,
@@ -592,6 +670,60 @@ int clamd_ce_fwd_bwd(const float* logits, const long long* labels, const float* 
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, partial, g, nvalid, (float)(1.0 / (double)npix),
                        (float)lam, loss3);
     return clamd_check_launch("ce_fwd_bwd");
+}
+
+int clamd_ce_count(const long long* labels, int B, int K, int H, int W, long long ignore_index, void* workspace, size_t ws_bytes, void* stream) {
+    if (K < 1 || K > 32 || !labels || B <= 0 || H <= 0 || W <= 0) return clamd_fail("ce_count: bad arguments");
+    if (ws_bytes < clamd_ce_workspace_bytes()) return clamd_fail("ce: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int* rows = (unsigned int*)((float*)workspace + 2 * 2048 + 4);
+    const long long npix = (long long)B * H * W;
+    hipLaunchKernelGGL(count_valid_rows_kernel, dim3(CE_COUNT_BLOCKS), dim3(256), 0, s, labels, npix, ignore_index, K, rows);
+    return clamd_check_launch("ce_count");
+}
+
+int clamd_ce_fwd_bwd_counted(const float* logits, const long long* labels, float* dlogits, void* dl_nhwc, int dl_ldc, int dl_dtype,
+                             float* loss3, void* workspace, size_t ws_bytes, int B, int K, int H, int W, long long ignore_index,
+                             double grad_scale, void* stream) {
+    if (K < 1 || K > 32) return clamd_fail("ce: number of classes must be in [1, 32]");
+    if (ws_bytes < clamd_ce_workspace_bytes()) return clamd_fail("ce: workspace too small");
+    const long long HW = (long long)H * W, npix = (long long)B * HW;
+    if (HW % 4 || ((size_t)logits % 16) || ((size_t)dlogits % 16) || ((size_t)labels % 32))
+        return clamd_fail("ce_fwd_bwd_counted: needs H * W % 4 == 0 and 16-byte aligned logits / 32-byte aligned labels (use clamd_ce_fwd_bwd)");
+    if (dl_nhwc) {
+        if (dl_ldc < 32 || dl_ldc % 8 || ((size_t)dl_nhwc % 16)) return clamd_fail("ce_fwd_bwd_counted: the NHWC copy needs a pitch >= 32 channels, a multiple of 8, and a 16-byte aligned base");
+        if (int e = clamd_check_split(dl_dtype, dl_nhwc, dl_ldc)) return e;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    unsigned int* nvalid = (unsigned int*)(partial + 2 * 2048);
+    int g = (int)((npix / 4 + 255) / 256);
+    if (g > 2048) g = 2048;
+    const unsigned int* rows = (const unsigned int*)(partial + 2 * 2048 + 4);
+#define CE4T(KM_, T_) hipLaunchKernelGGL((ce4_kernel<KM_, T_>), dim3(g), dim3(256), 0, s, logits, labels, dlogits, partial, nvalid, B, K, HW, ignore_index, (float)grad_scale, (T_*)dl_nhwc, dl_ldc, rows)
+#define CE4K(T_) do { if (K <= 8) CE4T(8, T_); else if (K <= 16) CE4T(16, T_); else if (K <= 24) CE4T(24, T_); else CE4T(32, T_); } while (0)
+    if (!dl_nhwc) CE4K(ce_no_nhwc);
+    else if (dl_dtype == CLAMD_BF16) CE4K(bf16_t);
+    else if (dl_dtype == CLAMD_F32) CE4K(float);
+    else if (dl_dtype == CLAMD_SPLIT) CE4K(split_t);
+    else return clamd_fail("ce_fwd_bwd_counted: bad dtype");
+#undef CE4K
+#undef CE4T
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, partial, g, nvalid, (float)(1.0 / (double)npix), 0.f, loss3, rows);
+    return clamd_check_launch("ce_fwd_bwd_counted");
+}
+
+int clamd_scale_by_device_scalar_nhwc(void* p, long long n, int dtype, const float* scale_dev, void* stream) {
+    if (n <= 0 || n % 8 || !scale_dev || !p) return clamd_fail("scale_by_device_scalar_nhwc: bad arguments (n must be a multiple of 8 channels)");
+    if (int e = clamd_check_split(dtype, p, 16)) return e;
+    long long g = (n / 8 + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CLAMD_BF16) hipLaunchKernelGGL(scale_by_dev_t_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, s, (bf16_t*)p, n / 8, scale_dev);
+    else if (dtype == CLAMD_F32) hipLaunchKernelGGL(scale_by_dev_t_kernel<float>, dim3((unsigned)g), dim3(256), 0, s, (float*)p, n / 8, scale_dev);
+    else if (dtype == CLAMD_SPLIT) hipLaunchKernelGGL(scale_by_dev_t_kernel<split_t>, dim3((unsigned)g), dim3(256), 0, s, (split_t*)p, n / 8, scale_dev);
+    else return clamd_fail("scale_by_device_scalar_nhwc: bad dtype");
+    return clamd_check_launch("scale_by_device_scalar_nhwc");
 }
 
 int clamd_adam_step(const void* tensors_dev, const void* chunks_dev, int nchunks, const float* hyper_dev, int* step_dev,

@@ -8,11 +8,18 @@ pass: the forward computes the loss and d loss / d logits; backward only scales 
 SURVEY.md §8a row A12).  The reference has NO such code: this term is build-defined and its parity is
 pinned only by tests against this repo's own CPU restatement.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import _lib
 from ._lib import call, ptr
+
+
+# d logits handed to the UNet's backward pass in the head data gradient's own layout (see _CEFn.forward); =0: the engine converts the NCHW
+# gradient as it does for any other loss (A/B measurements)
+HANDOVER = os.environ.get('CLAMD_LOSS_HANDOVER', '1') != '0'
 
 
 class _CEFn(torch.autograd.Function):
@@ -21,6 +28,7 @@ class _CEFn(torch.autograd.Function):
         if not logits.is_cuda:
             raise RuntimeError('continual-learning_amd loss runs only on GPU tensors: there is no CPU fallback')
         lib = _lib.load()
+        logits_in = logits
         logits = logits.contiguous().float()
         labels = labels.contiguous()
         if labels.dtype != torch.int64:
@@ -38,22 +46,41 @@ class _CEFn(torch.autograd.Function):
             kold = old_logits.shape[1]
             if old_logits.shape[0] != B or tuple(old_logits.shape[2:]) != (H, W):
                 raise ValueError('old_logits must be [B, K_old, H, W]')
-        call('clamd_ce_fwd_bwd', ptr(logits), ptr(labels), ptr(old_logits), kold, int(c_old), float(temperature),
-             float(lam), ptr(dl), ptr(out3), ptr(ws), wsb, B, K, H, W, int(ignore_index), 1.0, _lib.stream_ptr())
+        ctx.sink = None
+        if old_logits is None and (H * W) % 4 == 0:
+            # the training-step form: the count of valid pixels as partial rows (no memset, no atomics), and, when the logits come from this
+            # package's UNet, d logits written a second time in the layout (and dtype) its 1x1 head's data gradient reads -- the backward
+            # pass then starts without a conversion pass (unet._Engine.backward)
+            from . import unet as U
+            call('clamd_ce_count', ptr(labels), B, K, H, W, int(ignore_index), ptr(ws), wsb, _lib.stream_ptr())
+            eng = U.dlogits_sink(logits_in, B, K, H, W) if HANDOVER else None
+            nh, ldc, dcode = (eng.dl, eng.Kp, eng.dcode) if eng is not None else (None, 0, 0)
+            call('clamd_ce_fwd_bwd_counted', ptr(logits), ptr(labels), ptr(dl), ptr(nh), ldc, dcode, ptr(out3), ptr(ws), wsb, B, K, H, W,
+                 int(ignore_index), 1.0, _lib.stream_ptr())
+            if eng is not None:
+                ctx.sink = eng
+                eng.dl_src = (dl.data_ptr(), dl._version, eng.generation)
+        else:
+            call('clamd_ce_fwd_bwd', ptr(logits), ptr(labels), ptr(old_logits), kold, int(c_old), float(temperature),
+                 float(lam), ptr(dl), ptr(out3), ptr(ws), wsb, B, K, H, W, int(ignore_index), 1.0, _lib.stream_ptr())
         ctx.save_for_backward(dl)
         ctx.parts = out3
         # labels outside [0, K) that are not ignore_index: a device counter on the criterion (int(...) synchronises);
         # torch's CrossEntropyLoss asserts on such labels, here they are left out of the mean and counted
         off = lib.clamd_ce_bad_label_count_offset() // 4
         holder.bad_labels = ws[off:off + 1].view(torch.int32)
-        return out3[0].clone()
+        return out3[0]
 
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
         # g is the scalar upstream gradient on the DEVICE (exactly 1 for loss.backward()): the kernel tests it there and
         # touches d logits only when it is not 1 -- no host sync, no 176-MB multiply-by-one pass per step
-        call('clamd_scale_by_device_scalar', ptr(dl), dl.numel(), ptr(g.contiguous().float()), _lib.stream_ptr())
+        g = g.contiguous().float()
+        call('clamd_scale_by_device_scalar', ptr(dl), dl.numel(), ptr(g), _lib.stream_ptr())
+        eng = ctx.sink
+        if eng is not None and eng.dl_src is not None and eng.dl_src[0] == dl.data_ptr():      # the NHWC copy follows
+            call('clamd_scale_by_device_scalar_nhwc', ptr(eng.dl), eng.dl.numel(), eng.dcode, ptr(g), _lib.stream_ptr())
         return dl, None, None, None, None, None, None, None
 
 

@@ -99,6 +99,9 @@ HALF_BATCH_MIN_PIXELS = int(os.environ.get('CLAMD_HALF_BATCH_MIN_PIXELS', '32768
 # SIMD, <= 64 registers, <= 8 KB LDS), so they run under the MFMA-bound kernel instead of after it.  Results are unchanged
 # (same kernels, same arguments); joined back before backward() returns.  Off while bench.py times single launches.
 WGRAD_STREAM = os.environ.get('CLAMD_WGRAD_STREAM', '1') != '0'      # =0: everything on one stream (kernel-trace profiles)
+# The plain filter pack of everything behind enc3 (96 % of the parameters; HBM-bound) on the second stream under enc1-enc3 instead of in
+# front of the forward pass (=0: one launch chain on the main stream, as before round 4)
+PACK_LATE_STREAM = os.environ.get('CLAMD_PACK_LATE_STREAM', '1') != '0'
 
 # bench.py sets this to a list to get per-launch HIP-event timings of the MFMA kernels:
 # entries (tag, algorithmic_flops, start_event, end_event, algorithmic_bytes), recorded on the stream the kernel is
@@ -285,7 +288,9 @@ class UNet(nn.Module):
             eng = _Engine(self, B, H, W, x.device)
             self._engines = {key: eng}     # one shape at a time: activations are sized for it
         params = [p for p in self.parameters()]
-        return _UNetFn.apply(x.contiguous().float(), eng, *params)
+        out = _UNetFn.apply(x.contiguous().float(), eng, *params)
+        out._clamd_engine = (weakref.ref(eng), eng.generation)      # lets this package's loss write d logits where the backward pass reads it
+        return out
 
     @torch.no_grad()
     def predict(self, x):
@@ -306,6 +311,19 @@ class UNet(nn.Module):
 
     def extra_repr(self):
         return f'num_classes={self.num_classes}, in_dim={self.in_dim}, conv_dim={self.conv_dim}, compute={self.compute_dtype}'
+
+
+def dlogits_sink(logits, B, K, H, W):
+    """For loss.CrossEntropyLoss: the engine whose forward produced `logits` (and nothing since), or None.  Its `dl` buffer [B,H,W,Kp] takes a
+    second copy of d logits in the head data gradient's own layout; the engine uses it when the gradient autograd hands back is the very
+    tensor the loss wrote (same storage, untouched: `dl_src`) and converts that tensor as before otherwise."""
+    tag = getattr(logits, '_clamd_engine', None)
+    if tag is None:
+        return None
+    eng, gen = tag[0](), tag[1]
+    if eng is None or eng.generation != gen or (eng.B, eng.K, eng.H, eng.W) != (B, K, H, W) or not eng.fwd_training or eng.dl.device != logits.device:
+        return None
+    return eng
 
 
 class _UNetFn(torch.autograd.Function):
@@ -351,9 +369,12 @@ class _Engine:
         self.B, self.H, self.W, self.dev = B, H, W, device
         self.dcode, self.tdtype = _DTYPES[model.compute_dtype]
         self.wino = bool(WINOGRAD) and self.dcode == _lib.F32
+        self.pack_late_stream = bool(PACK_LATE_STREAM)
         self.tuning = model.tuning
         self.NS = lib.clamd_bn_bwd_nsums()
         self.generation = 0
+        self.dl_src = None
+        self.fwd_training = False
         self.esize = 2 if self.dcode == _lib.BF16 else 4      # activation element size in HBM (bf16x3 stores fp32)
         K, d = model.num_classes, model.conv_dim
         self.K, self.Kp = K, cpad(K)
@@ -643,6 +664,7 @@ class _Engine:
             if u.fold_a is not None:
                 u.fold_a.apply_in_filters = u.fold_on      # the producer's bn_apply pass is skipped
         for u in self.convs:
+            u.gz_nrows = 0
             Bl = B // 2 if u.split else B          # images per forward launch (half-batch pipeline: two launches, rows concatenated)
             if u.im2col:
                 r = rows(_lib.OP_CONV1X1, Bl, u.h, u.w_, u.cin_p, u.cout_p, dc)
@@ -660,24 +682,32 @@ class _Engine:
                         u.sum_rows = rows(_lib.OP_CONV3X3_WINOGRAD24, B, b.h, b.w_, b.cout_p, b.cin_p, dc, tuning=tn)
                     else:
                         u.sum_rows = rows(_lib.OP_CONV3X3, B, b.h, b.w_, b.cout_p, b.cin_p, dc, fused_bn=True, tuning=tn)
+                        # the persistent bf16 kernel takes sum g and sum g y only: the conv-bias gradient then comes from the apply pass
+                        if _lib.load().clamd_conv3x3_bn_sums(B, b.h, b.w_, b.cout_p, b.cin_p, dc, tune_ptr(tn)) == 2:
+                            u.gz_nrows = _lib.load().clamd_bn_bwd_apply_sums_rows(B, u.h, u.w_, u.cout_p)
                 elif src.kind == 'head':
                     u.sum_rows = rows(_lib.OP_CONV1X1, B, u.h, u.w_, src.cout_p, src.cin_p, dc, fused_bn=True)
                 else:                 # ConvTranspose2d data gradient: the launch runs on the convT INPUT grid (= this unit's)
                     u.sum_rows = rows(_lib.OP_CONVT2X2_DGRAD, B, u.h, u.w_, src.cin_p, src.cout_p, dc, fused_bn=True)
             else:
                 u.sum_rows = rows(_lib.OP_BN_BWD_REDUCE, B, u.h, u.w_, 1 if u.g_src[2] is not None else 0, u.cout_p, dc, tuning=tn)
-            sizes.append((u.stat_rows * 2 + u.sum_rows * self.NS) * u.cout_p)
+            sizes.append((u.stat_rows * 2 + u.sum_rows * self.NS + u.gz_nrows) * u.cout_p)
         self.stat_arena = torch.empty(sum(sizes), dtype=torch.float32, device=self.dev)
         off = 0
         for u, n in zip(self.convs, sizes):
-            k = u.stat_rows * 2 * u.cout_p
+            k, k2 = u.stat_rows * 2 * u.cout_p, u.gz_nrows * u.cout_p
             u.stats = self.stat_arena[off:off + k]
-            u.sums = self.stat_arena[off + k:off + n]
+            u.sums = self.stat_arena[off + k:off + n - k2]
+            u.gz_rows = self.stat_arena[off + n - k2:off + n] if k2 else None
             off += n
 
     # ------------------------------------------------------------------------------------------ pack table
     def _build_pack_table(self):
         tab = PackTable(self.dcode)
+        # ... and the plain pack in two launches too: `tab` = what the first three encoder stages need (and every bias vector), in front of
+        # the forward pass; `late` = the 3x3 filters from enc4 on and the ConvTranspose / head filters (96 % of the parameters: 118 MB read,
+        # 62 MB written in bf16, 130 us -- HBM-bound) on the second stream under enc1-enc3, waited for in front of enc4's first convolution
+        late = PackTable(self.dcode)
         # Winograd filter transforms in two launches per form: "early" = the first three encoder stages (4 % of the parameters,
         # needed 0.3 ms into the forward pass), "late" = everything else (first needed by enc4, 2 ms in): the forward pass waits for
         # a few microseconds of packing instead of for all of it (see forward())
@@ -692,7 +722,7 @@ class _Engine:
                 if u.wd is not None:
                     wtab[(24 if u.w24d else 16, u.pack_late)].conv3x3(u.w, None, u.wd, u.cin_segs, u.cout)
             else:
-                tab.conv3x3(u.w, None if u.fold_a is not None else u.wf, u.wd, u.cin_segs, u.cout)
+                (late if u.pack_late else tab).conv3x3(u.w, None if u.fold_a is not None else u.wf, u.wd, u.cin_segs, u.cout)
             tab.vector(u.b, u.bias_p, u.cout)
             if u.fold_a is not None:
                 # the forward filters of a fold candidate are packed inside the step, behind the producer's bn_finalize: with its scale
@@ -707,16 +737,18 @@ class _Engine:
             if t is None:
                 continue
             if t.kind == 'convT':
-                tab.convT(t.w, t.wf, t.wd, t.cin, t.cout)
+                late.convT(t.w, t.wf, t.wd, t.cin, t.cout)
             elif t.fold_b is not None:      # forward filters inside the step, with the last BatchNorm's scale (see _fwd_fold)
-                tab.head(t.w, None, t.wd, t.cin, t.cout)
+                late.head(t.w, None, t.wd, t.cin, t.cout)
                 t.fold_table = PackTable(self.dcode)
                 t.fold_table.head(t.w, t.wf, None, t.cin, t.cout, kscale=t.fold_b.vec[0])
                 t.fold_table.finalize(self.dev)
             else:
-                tab.head(t.w, t.wf, t.wd, t.cin, t.cout)
+                late.head(t.w, t.wf, t.wd, t.cin, t.cout)
             tab.vector(t.b, t.bias_p, t.cout)
         self.pack_table = tab.finalize(self.dev)
+        self.pack_late = late.finalize(self.dev) if late.jobs else None
+        self._ev_pack_late = None
         self.wino_early = [t.finalize(self.dev) for (pl, late), t in wtab.items() if t.jobs and not late]
         self.wino_late = [t.finalize(self.dev) for (pl, late), t in wtab.items() if t.jobs and late]
         self._ev_early = torch.cuda.Event() if self.dev.type == 'cuda' else None
@@ -741,6 +773,7 @@ class _Engine:
         training = m.training
         self.fwd_training = training
         self.generation += 1
+        self.dl_src = None
         self._check_ptrs(params)
         s = _lib.stream_ptr()
         B, H, W, dc = self.B, self.H, self.W, self.dcode
@@ -760,6 +793,15 @@ class _Engine:
         else:
             for t in self.wino_late:
                 t.run(sp)
+        self._ev_pack_late = None
+        if self.pack_late is not None:      # behind the early Winograd transforms (fp32), which the second convolution is waiting for
+            if self.wg_stream is not None and KERNEL_TIMING is None and self.pack_late_stream:
+                self.wg_stream.wait_stream(torch.cuda.current_stream())      # the parameters are final on the current stream (Adam)
+                self.pack_late.run(dc, self.wg_stream.cuda_stream)
+                self._ev_pack_late = torch.cuda.Event()
+                self._ev_pack_late.record(self.wg_stream)
+            else:
+                self.pack_late.run(dc, s)
         if self.convs[0].im2col:
             call('clamd_nchw_im2col3', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
                  self.x_in.shape[-1], dc, s)
@@ -807,6 +849,7 @@ class _Engine:
             if t is None:
                 continue               # encoder: the pooled output feeds the next stage's first convolution (defer may be pending)
             assert defer is None
+            self._join_pack_late()
             h, w = H >> t.level, W >> t.level
             tx, tx_ldc, tbias = t.x, t.x.shape[-1], t.bias_p
             if t.fold_b is not None:       # the head reads the last unit's conv+ReLU output: its BatchNorm is in the filters and the bias
@@ -840,6 +883,7 @@ class _Engine:
         if self._pack_pending:          # some part was never waited for (no late Winograd layer in this net): join before returning
             torch.cuda.current_stream().wait_stream(self.wg_stream)
             self._pack_pending = 0
+        self._join_pack_late()
         if training:
             torch._foreach_add_(self.nbts, 1)
         return logits
@@ -900,9 +944,17 @@ class _Engine:
         call('clamd_bn_fold_pack', (24 if u.w24 else 16) if u.wino else 0, ptr(t.dev_table), len(t.jobs), t.nblocks, self.dcode,
              ptr(u.w), 9, ptr(a.vec[1]), ptr(u.b), ptr(u.cb), u.cout, u.cin, u.cout_p, s)
 
+    def _join_pack_late(self):
+        """The late part of the plain filter pack (second stream) is needed from here on."""
+        if self._ev_pack_late is not None:
+            torch.cuda.current_stream().wait_event(self._ev_pack_late)
+            self._ev_pack_late = None
+
     def _fwd_conv(self, u, training, s, hf):
         """conv3x3 + bias + ReLU (+ BatchNorm statistics rows) of unit u on the whole batch or one half of it."""
         dc, tp = self.dcode, tune_ptr(self.tuning)
+        if u.pack_late:
+            self._join_pack_late()
         Bl = self.B if hf is None else self.B // 2
         _TIMED_UNIT[:] = [u.name + ' fwd', self.executed_fraction(u, 'fwd')]
         rows = u.stat_rows_launch
@@ -1012,7 +1064,11 @@ class _Engine:
             if t is not None:
                 h, w = H >> t.level, W >> t.level
                 if t.kind == 'head':
-                    call('clamd_nchw_to_nhwc', ptr(gout), ptr(self.dl), self.Kp, B, self.K, H, W, self.Kp, 1.0, dc, s)
+                    src = self.dl_src
+                    if not (src is not None and src == (gout.data_ptr(), gout._version, self.generation)):
+                        # not the tensor this package's loss wrote beside its NHWC copy (another loss, a hook, a sum of gradients): convert
+                        call('clamd_nchw_to_nhwc', ptr(gout), ptr(self.dl), self.Kp, B, self.K, H, W, self.Kp, 1.0, dc, s)
+                    self.dl_src = None
                     call('clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], None,
                          ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
                          t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cout_p, t.cin_p, 0, dc, s)
@@ -1084,10 +1140,16 @@ class _Engine:
         if not u.fused_reduce:     # otherwise the five sums were accumulated by the epilogue of the kernel that wrote `ga`
             call('clamd_bn_bwd_reduce', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.y_ldc,
                  ptr(v[0]), ptr(v[1]), ptr(u.sums), u.sum_rows, B, u.h, u.w_, u.cout_p, dc, tp, s)
+        two = u.fused_reduce and u.gz_nrows > 0      # the producing launch took sum g and sum g y only: d conv-bias = sum g_z, from the apply pass
         call('clamd_bn_bwd_finalize', ptr(u.sums), u.sum_rows, ptr(u.gamma), ptr(v[2]), ptr(v[3]), ptr(v[4]), g[u.keys[2]],
-             g[u.keys[3]], g[u.keys[1]], u.cout_p, u.cout, count, s)
-        call('clamd_bn_bwd_apply', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.y_ldc,
-             ptr(v[0]), ptr(v[1]), ptr(v[4]), ptr(u.gz), u.cout_p, B, u.h, u.w_, u.cout_p, dc, s)
+             g[u.keys[3]], None if two else g[u.keys[1]], u.cout_p, u.cout, count, s)
+        if two:
+            assert gp is None
+            call('clamd_bn_bwd_apply_sums', ptr(ga), ga_ldc, ptr(u.y), u.y_ldc, ptr(v[4]), ptr(u.gz), u.cout_p, ptr(u.gz_rows), u.gz_nrows,
+                 B, u.h, u.w_, u.cout_p, dc, s)
+        else:
+            call('clamd_bn_bwd_apply', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.y_ldc,
+                 ptr(v[0]), ptr(v[1]), ptr(v[4]), ptr(u.gz), u.cout_p, B, u.h, u.w_, u.cout_p, dc, s)
         if len(u.cin_segs) == 2:
             c_seg0, c_seg0p = u.cin_segs[0]
         else:
@@ -1142,6 +1204,8 @@ class _Engine:
         # The issue ORDER of the two launches alone makes no difference.
         dgrad()
         sw = self._wg_stream_ptr()
+        if two:      # off the critical chain: the fixed-order sum of the apply pass's rows, in front of this unit's weight gradient
+            call('clamd_rows_sum', ptr(u.gz_rows), u.gz_nrows, g[u.keys[1]], u.cout_p, u.cout, sw)
         if u.im2col:
             call('clamd_wgrad', _lib.WGRAD_PW, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
                  g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, 9 * u.cin, u.cout, u.cout_p, 9 * u.cin, u.cin_p, dc, tp, sw)

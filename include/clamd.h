@@ -57,14 +57,17 @@ int clamd_bn_bwd_nsums(void);
  *   wino_persist   0|1     one workgroup per tile | persistent tile loop
  *   wino_mt        0|1|2   tile height: per-launch choice | 8 | 16 pixels
  *   bn_reduce_blocks / chsum_blocks   0 (per-launch choice) | n: grid cap of the per-channel reductions
- *   cu_reserve     CUs the persistent grids leave free (for RCCL channel workgroups under data parallelism) */
+ *   cu_reserve     CUs the persistent grids leave free (for RCCL channel workgroups under data parallelism)
+ *   pws_cl         0|1     persistent kernel, bf16: epilogue through a wave-private LDS transposition | a lane owns a pixel and 2 x 8
+ *                          consecutive channels per 32-channel block (filter fragment as the MFMA row operand): direct 16-byte stores */
 typedef struct clamd_tuning {
     int igemm_pws, igemm_ws, igemm_variant, pws_wres;
     int wgrad_ws, wgrad_dma, wgrad_xcd, wgrad_blocks, wgrad_tw16;
     int wino_band, wino_persist, wino_mt;
     int bn_reduce_blocks, chsum_blocks;
     int cu_reserve;
-    int reserved[9];
+    int pws_cl;
+    int reserved[8];
 } clamd_tuning;
 int clamd_sizeof_tuning(void);
 void clamd_tuning_init(clamd_tuning* t);
@@ -100,6 +103,10 @@ int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* b
                   float* stats, const void* bn_y, float* bn_sums, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p,
                   int relu, int m_fastest, int dtype, const clamd_tuning* tune, void* stream);
 int clamd_conv3x3_border_bias_ok(int B, int H, int W, int Cin_p, int Cout_p, int dtype, const clamd_tuning* tune);
+/* How many of the five sums a clamd_conv3x3 launch with bn_y / bn_sums takes: 5, or 2 where the persistent bf16 kernel runs it
+ * (channels-in-the-lane epilogue: sum g and sum g y as running sums per accumulator register; rows k = 2..4 are written as zeros and
+ * the convolution's bias gradient comes from clamd_bn_bwd_apply_sums, below).  0 on bad arguments. */
+int clamd_conv3x3_bn_sums(int B, int H, int W, int Cin_p, int Cout_p, int dtype, const clamd_tuning* tune);
 /* ---- nn.BatchNorm2d folded into the nn.Conv2d(k3,p1) behind it (models/unet.py:15-16,30-31; bnfold.hip) ---------------------
  * x = scale * r + shift with r the producer's saved conv+ReLU output and scale / shift from clamd_bn_finalize:
  *   conv3x3(x, W) = conv3x3(r, W * scale[ci]) + the sum of T[co][tap] = sum_ci W[co][ci][tap] * shift[ci] over the taps that read
@@ -263,6 +270,16 @@ int clamd_bn_bwd_finalize(const float* sums, int sum_rows, const float* gamma, c
 int clamd_bn_bwd_apply(const void* ga, int ga_ldc, const void* gp, int gp_ldc, const void* y, int y_ldc,
                        const float* scale, const float* shift, const float* k012, void* gz, int gz_ldc, int B,
                        int H, int W, int Cp, int dtype, void* stream);
+/* Two-sum form (the persistent bf16 convolution kernel, see clamd_conv3x3_bn_sums): the producing data-gradient launch wrote only
+ * sum g and sum g y (rows k = 0, 1; k = 2..4 zero), which is all k0, k1, k2, d gamma and d beta need; pass dbias = NULL to
+ * clamd_bn_bwd_finalize and take the convolution's bias gradient (models/unet.py:13,16: d conv-bias = sum of g_z) where g_z is formed:
+ * clamd_bn_bwd_apply_sums = clamd_bn_bwd_apply without pooling + partial rows gz_rows[nrows][Cp] of sum g_z (nrows =
+ * clamd_bn_bwd_apply_sums_rows(B, H, W, Cp), one row per workgroup, plain stores), then clamd_rows_sum adds rows 0..nrows-1 in a
+ * fixed order in fp64 and OVERWRITES out[0..C). */
+int clamd_bn_bwd_apply_sums_rows(int B, int H, int W, int Cp);
+int clamd_bn_bwd_apply_sums(const void* ga, int ga_ldc, const void* y, int y_ldc, const float* k012, void* gz, int gz_ldc,
+                            float* gz_rows, int nrows, int B, int H, int W, int Cp, int dtype, void* stream);
+int clamd_rows_sum(const float* rows, int nrows, float* out, int Cp, int C, void* stream);
 /* nn.MaxPool2d(2,2) alone (models/unet.py:12: the first layer of a DownBlock run as a stand-alone block, blocks.py; inside the UNet step
  * the pool is part of clamd_bn_apply / clamd_bn_bwd_*): x [B,H,W,ldc] -> pooled [B,H/2,W/2,ldc]; backward: gx [B,H,W,ldc] = gp at the first
  * maximum of each window (the tie rule of clamd_bn_apply and of torch's CPU kernel), 0 elsewhere.
@@ -297,6 +314,15 @@ size_t clamd_ce_bad_label_count_offset(void);
 int clamd_ce_fwd_bwd(const float* logits, const long long* labels, const float* old_logits, int K_old_total, int c_old,
                      double temperature, double lam, float* dlogits, float* loss3, void* workspace, size_t ws_bytes,
                      int B, int K, int H, int W, long long ignore_index, double grad_scale, void* stream);
+/* The same loss without the distillation term, in two launches that need no memset and no atomics: clamd_ce_count writes the count of
+ * the pixels that take part in the mean as one partial pair per workgroup into the workspace (plain stores), the loss / gradient pass
+ * (same workspace, ordered behind it by the caller) adds them.  Needs H * W % 4 == 0.  dl_nhwc (optional): d logits ALSO as
+ * an NHWC tensor [B,H,W,dl_ldc] of compute dtype dl_dtype, channels K .. dl_ldc-1 zero (dl_ldc >= 32) -- the operand of the 1x1
+ * head's data gradient (models/unet.py:72, trainer.py:175), which then needs no clamd_nchw_to_nhwc pass over d logits. */
+int clamd_ce_count(const long long* labels, int B, int K, int H, int W, long long ignore_index, void* workspace, size_t ws_bytes, void* stream);
+int clamd_ce_fwd_bwd_counted(const float* logits, const long long* labels, float* dlogits, void* dl_nhwc, int dl_ldc, int dl_dtype,
+                             float* loss3, void* workspace, size_t ws_bytes, int B, int K, int H, int W, long long ignore_index,
+                             double grad_scale, void* stream);
 /* torch.optim.Adam.step over all parameters in one launch (trainer.py:108-110,176); hyper/step/derived live on the
  * device so a captured graph can be replayed with a new learning rate.  l2_accum_dev (optional, with the L2-to-old-weights
  * term): 1 + nchunks floats, [0] = sum ||theta - theta_old||^2 of this step, [1..] = per-workgroup partials added in a fixed
@@ -323,6 +349,8 @@ int clamd_bf16_to_f32(const void* src_bf16, float* dst, long long n, void* strea
 /* p[i] *= *scale_dev for a DEVICE scalar, nothing at all when it is exactly 1 (the upstream gradient loss.backward()
  * hands to the loss function, trainer.py:175): no host sync, no pass over d logits in the common case. */
 int clamd_scale_by_device_scalar(float* p, long long n, const float* scale_dev, void* stream);
+/* ... and for an NHWC tensor of a compute dtype (n logical elements, a multiple of 8; the second copy of d logits above) */
+int clamd_scale_by_device_scalar_nhwc(void* p, long long n, int dtype, const float* scale_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -148,7 +148,8 @@ def test_engine_geometry_and_pack_table(C):
     assert dec2a.cin_segs == [(64, 64), (64, 64)] and dec2a.xin is e.cat[3]
     enc1b = [u for u in e.convs if u.name == 'enc1.3'][0]
     assert enc1b.out is e.cat[0] and enc1b.pooled is e.pool[0] and enc1b.out_ldc == 64
-    jobs = e.pack_table.jobs
+    jobs = e.pack_table.jobs + e.pack_late.jobs           # two launches: what enc1-enc3 need first, the rest on the second stream
+    assert not any(u.pack_late for u in e.convs[:6]) and all(u.pack_late for u in e.convs[6:])
     # wf + wd + bias per conv (no wd for enc1.0), 3 per tail; on the fp32 path the filters of the Winograd units
     # (3x3, even images of at least 8x8: every unit here except enc1.0 (im2col) and the two 4x4 centre convs) are
     # transformed by the Winograd pack table instead
@@ -172,7 +173,7 @@ def test_engine_geometry_and_pack_table(C):
     head = e.stages[-1]['tail']
     assert head.kind == 'head' and head.fold_b is e.convs[-1] and len(head.fold_table.jobs) == 1      # the 1x1 head folds the last BatchNorm
     assert len(jobs) + nw + len(fold) + 1 == 18 * 3 - 1 + 5 * 3
-    assert e.pack_table.nblocks == sum(((j[3] + 31) // 32) * ((j[4] + 31) // 32) for j in jobs)
+    assert e.pack_table.nblocks + e.pack_late.nblocks == sum(((j[3] + 31) // 32) * ((j[4] + 31) // 32) for j in jobs)
     assert C.cpad(3) == 32 and C.cpad(21) == 32 and C.cpad(1024) == 1024
 
 
@@ -277,3 +278,16 @@ def test_bf16x3_plane_layout_helpers_roundtrip():
     assert torch.equal(C.ops.split_decode(e[..., 16:32]), d[..., 16:32])
     z = C.ops.split_encode(torch.zeros(1, 1, 1, 32))
     assert int(z.view(torch.int32).abs().max()) == 0            # zero padding channels are all-zero bytes
+
+
+def test_no_test_function_is_shadowed():
+    """Two `def test_x` in one module: Python keeps the second and the first silently never runs (round 3: test_misuse_errors in
+    tests/test_unet_gpu.py).  Every test name must be defined once per file."""
+    import collections
+    import glob
+    import re
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, 'test_*.py'))):
+        names = re.findall(r'^def (test_\w+)\(', open(f).read(), flags=re.M)
+        dup = [n for n, c in collections.Counter(names).items() if c > 1]
+        assert not dup, f'{os.path.basename(f)}: defined more than once: {dup}'

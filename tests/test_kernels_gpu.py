@@ -258,9 +258,16 @@ def test_conv3x3_dgrad_and_wgrad(C, name, dcode, shape):
     pos = (ybr > 0).astype(np.float32)
     want = np.stack([rgx.sum((0, 2, 3)), (rgx * ybr).sum((0, 2, 3)), (rgx * pos).sum((0, 2, 3)), pos.sum((0, 2, 3)), ybr.sum((0, 2, 3))])
     got = bsums.sum(0).cpu().numpy()[:, [p for p, l in enumerate(pm_) if l >= 0]]
+    nsums = lib.load().clamd_conv3x3_bn_sums(B, H, W, cout_p, cin_p, dcode, None)
+    assert nsums in (2, 5) and (nsums == 5 or dcode == 1)
+    assert lib.load().clamd_conv3x3_bn_sums(B, H, W, cout_p, cin_p, dcode, lib.Tuning(pws_cl=0).ref()) == 5
+    if nsums == 2:      # the persistent bf16 kernel: sum g and sum g y only, rows 2-4 written as zeros (clamd_bn_bwd_apply_sums gives d conv-bias)
+        assert not np.isnan(bsums.cpu().numpy()).any() and float(bsums[:, 2:].abs().max()) == 0.0
+        want, got = want[:2], got[:2]
     scale = np.abs(want).max(1, keepdims=True) + 1e-6
     assert np.abs(got - want).max() <= (2e-2 if dcode == 1 else 1e-3) * scale.max(), np.abs(got - want).max()
-    np.testing.assert_allclose(got[3:], want[3:], rtol=1e-5, atol=1e-3)
+    if nsums == 5:
+        np.testing.assert_allclose(got[3:], want[3:], rtol=1e-5, atol=1e-3)
 
 
 # Every structure of the 3x3 kernels (baseline two-workgroups-per-CU, producer/consumer with 128/256/512-pixel tiles,
@@ -274,7 +281,7 @@ VARIANT_SHAPES = [  # B, Cin, Cout, H, W
     (5, 64, 40, 128, 160),    # 400 tiles > CUs: persistent workgroups walk several tiles (resident filter slab in bf16)
 ]
 CONV_VARIANTS = [('igemm_pws', 0, 'igemm_ws', 0), ('igemm_pws', 0, 'igemm_ws', 1), ('igemm_pws', 0, 'igemm_ws', 3),
-                 ('igemm_pws', 0, 'igemm_ws', 4), ('igemm_pws', 2, 'igemm_ws', 2), ('igemm_pws', 2, 'pws_wres', 0),
+                 ('igemm_pws', 0, 'igemm_ws', 4), ('igemm_pws', 2, 'pws_cl', 0), ('igemm_pws', 2, 'igemm_ws', 2), ('igemm_pws', 2, 'pws_wres', 0),
                  ('igemm_pws', 1, 'pws_wres', 1)]
 
 
@@ -288,7 +295,7 @@ def test_conv3x3_kernel_structures_agree(C, name, dcode, shape):
     lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
     T = C.ops.TORCH_DT[dcode]
     ref = O.relu_fwd(O.conv3x3_fwd(x, w, b))
-    first = None
+    first, first_cl = None, None
     for k1, v1, k2, v2 in CONV_VARIANTS:
         tn = lib.Tuning(**{k1: v1, k2: v2})
         y = torch.full((B, H, W, cout_p), 7.0, dtype=T, device='cuda')
@@ -305,10 +312,18 @@ def test_conv3x3_kernel_structures_agree(C, name, dcode, shape):
         st = stats.double().sum(0).cpu().numpy()
         np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=2e-3 if dcode == 1 else 1e-4, atol=1e-2 if dcode == 1 else 1e-3)
         np.testing.assert_allclose(st[1, :cout], (ref ** 2).sum((0, 2, 3)), rtol=4e-3 if dcode == 1 else 1e-4, atol=1e-2 if dcode == 1 else 1e-3)
+        # bf16, persistent kernel with the channels-in-the-lane epilogue (pws_cl, the default): the same MFMA chains started at the bias
+        # instead of at zero with the bias added last -- the same sum rounded at another place, so those launches agree bit for bit among
+        # themselves and with the other structures to the last bit of the stored bf16 value
+        cl = dcode == 1 and k1 == 'igemm_pws' and v1 > 0 and not (k2 == 'pws_cl' and v2 == 0)
         if first is None:
             first = y.clone()
+        elif cl and first_cl is None:
+            first_cl = y.clone()
+            d = (first.float() - y.float()).abs()
+            assert float((d / first.float().abs().clamp_min(1e-3)).max()) <= 2.0 ** -7 and float((d > 0).float().mean()) < 0.02, (k1, v1, k2, v2)
         else:
-            assert torch.equal(first, y), f'{k1}={v1} {k2}={v2} changed the activations'
+            assert torch.equal(first_cl if cl else first, y), f'{k1}={v1} {k2}={v2} changed the activations'
     # a wrong row count is refused, not silently mis-summed
     with pytest.raises(RuntimeError, match='partial rows'):
         lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, rows + 1, B, H, W, cin_p,
@@ -1102,6 +1117,28 @@ def test_bn_fwd_bwd_pool(C, name, dcode, shape, pool):
     np.testing.assert_allclose(db.cpu().numpy(), gb_ref, rtol=1e-3, atol=1e-3 * (np.abs(gb_ref).max() + 1e-6))
     np.testing.assert_allclose(dcb.cpu().numpy(), gz_ref.sum((0, 2, 3)), rtol=1e-3 if dcode != 1 else 3e-2,
                                atol=(1e-3 if dcode != 1 else 3e-2) * (np.abs(gz_ref.sum((0, 2, 3))).max() + 1e-6))
+    if not pool:
+        # two-sum form: finalize without the bias gradient (rows 2-4 unused), the apply pass writes the same g_z bit for bit and the
+        # partial rows of its per-channel sum; clamd_rows_sum adds them in a fixed order
+        sums2 = sums.clone(); sums2[:, 2:] = 0.0
+        vec2 = vec.clone()
+        dg2, db2, dcb2 = torch.zeros(Cc, device='cuda'), torch.zeros(Cc, device='cuda'), torch.full((Cc,), 3.0, device='cuda')
+        lib.call('clamd_bn_bwd_finalize', ptr(sums2), srows, ptr(gt_), ptr(vec2[2]), ptr(vec2[3]), ptr(vec2[4]), ptr(dg2), ptr(db2), None, cp, Cc, float(n), s)
+        nr = lib.load().clamd_bn_bwd_apply_sums_rows(B, H, W, cp)
+        gz2 = torch.zeros(B, H, W, cp, dtype=T, device='cuda')
+        out = []
+        for _ in range(2):
+            rows_ = torch.full((nr, cp), float('nan'), device='cuda')
+            lib.call('clamd_bn_bwd_apply_sums', ptr(gat), 2 * cp, ptr(yt), cp, ptr(vec2[4]), ptr(gz2), cp, ptr(rows_), nr, B, H, W, cp, dcode, s)
+            lib.call('clamd_rows_sum', ptr(rows_), nr, ptr(dcb2), cp, Cc, s)
+            sync()
+            out.append((rows_.clone(), dcb2.clone()))
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+        assert torch.equal(gz2, gz) and torch.equal(dg2, dg) and torch.equal(db2, db) and torch.equal(vec2[4:7], vec[4:7])
+        np.testing.assert_allclose(dcb2.cpu().numpy(), gz_ref.sum((0, 2, 3)), rtol=1e-3 if dcode != 1 else 3e-2,
+                                   atol=(1e-3 if dcode != 1 else 3e-2) * (np.abs(gz_ref.sum((0, 2, 3))).max() + 1e-6))
+        with pytest.raises(RuntimeError, match='nrows'):
+            lib.call('clamd_bn_bwd_apply_sums', ptr(gat), 2 * cp, ptr(yt), cp, ptr(vec2[4]), ptr(gz2), cp, ptr(rows_), nr + 1, B, H, W, cp, dcode, s)
 
 
 @pytest.mark.parametrize('name,dcode', DT)
@@ -1226,6 +1263,47 @@ def test_cross_entropy_edge_cases(C):
         assert rel_l2(t.grad.cpu().numpy(), ref_d) < 1e-5
     with pytest.raises(RuntimeError):
         crit(torch.randn(1, 33, 16, 16, device='cuda'), torch.zeros(1, 16, 16, dtype=torch.int64, device='cuda'))
+
+
+@pytest.mark.parametrize('name,dcode', DT)
+def test_cross_entropy_counted_form_and_nhwc_copy(C, name, dcode):
+    """clamd_ce_count + clamd_ce_fwd_bwd_counted (the training-step form: partial-row count, no memset / atomics) against
+    clamd_ce_fwd_bwd bit for bit -- loss, d logits, both counters -- for 5 / 21 / 32 classes with ignored and out-of-range labels; the
+    second copy of d logits (NHWC, compute dtype, channels K .. 31 zero) equals clamd_nchw_to_nhwc of the NCHW one bit for bit, and
+    clamd_scale_by_device_scalar_nhwc scales it as the fp32 kernel scales the NCHW tensor."""
+    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
+    L = lib.load()
+    rng = np.random.default_rng(21)
+    wsb = L.clamd_ce_workspace_bytes()
+    off = L.clamd_ce_bad_label_count_offset() // 4
+    for K, B, H, W in ((5, 2, 8, 12), (21, 3, 16, 20), (32, 1, 4, 4)):
+        z = dev(rnd(rng, B, K, H, W) * 4)
+        y = rng.integers(0, K, (B, H, W))
+        y[0, 0, :3] = -100; y[0, 1, 0] = K + 2; y[-1, -1, -1] = -7
+        yt = dev(y, torch.int64)
+        d0, l0, w0 = torch.empty_like(z), torch.empty(3, device='cuda'), torch.zeros(wsb // 4, device='cuda')
+        lib.call('clamd_ce_fwd_bwd', ptr(z), ptr(yt), None, 0, 0, 1.0, 0.0, ptr(d0), ptr(l0), ptr(w0), wsb, B, K, H, W, -100, 1.0, s)
+        d1, l1, w1 = torch.empty_like(z), torch.empty(3, device='cuda'), torch.full((wsb // 4,), float('nan'), device='cuda')
+        nh = torch.full((B, H, W, 32), 5.0, dtype=C.ops.TORCH_DT[dcode], device='cuda')
+        lib.call('clamd_ce_count', ptr(yt), B, K, H, W, -100, ptr(w1), wsb, s)
+        lib.call('clamd_ce_fwd_bwd_counted', ptr(z), ptr(yt), ptr(d1), ptr(nh), 32, dcode, ptr(l1), ptr(w1), wsb, B, K, H, W, -100, 1.0, s)
+        sync()
+        assert torch.equal(d0, d1) and torch.equal(l0, l1)
+        assert torch.equal(w0[off - 1:off + 1].view(torch.int32), w1[off - 1:off + 1].view(torch.int32)) and int(w1[off:off + 1].view(torch.int32)) == 2
+        conv = C.ops.to_nhwc(d1, dcode, cp=32)
+        assert torch.equal(conv.view(torch.int16), nh.view(torch.int16))
+        g = torch.tensor([0.5], device='cuda')
+        lib.call('clamd_scale_by_device_scalar', ptr(d1), d1.numel(), ptr(g), s)
+        lib.call('clamd_scale_by_device_scalar_nhwc', ptr(nh), nh.numel(), dcode, ptr(g), s)
+        sync()
+        assert torch.equal(C.ops.to_nhwc(d1, dcode, cp=32).view(torch.int16), nh.view(torch.int16))      # a power of two: exact in every dtype
+        one = torch.ones(1, device='cuda')
+        before = nh.clone()
+        lib.call('clamd_scale_by_device_scalar_nhwc', ptr(nh), nh.numel(), dcode, ptr(one), s)
+        sync()
+        assert torch.equal(before.view(torch.int16), nh.view(torch.int16))
+    with pytest.raises(RuntimeError, match='H \\* W % 4'):
+        lib.call('clamd_ce_fwd_bwd_counted', ptr(z), ptr(yt), ptr(d1), None, 0, 0, ptr(l1), ptr(w1), wsb, 1, 32, 1, 6, -100, 1.0, s)
 
 
 def test_distillation_loss_vs_oracle(C):
