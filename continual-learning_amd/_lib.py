@@ -76,7 +76,7 @@ SIGNATURES = {
     'clamd_convT2x2_dgrad_direct': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_wgrad_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
     'clamd_wgrad': (_I, [_I, _P, _I, _P, _I, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    'clamd_bn_finalize': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _P]),
+    'clamd_bn_finalize': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _P, _P]),
     'clamd_bn_apply': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_bn_bwd_reduce': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_bn_bwd_finalize': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _P]),
@@ -120,7 +120,7 @@ SIGNATURES = {
     'clamd_f32_to_bf16': (_I, [_P, _P, _LL, _P]),
     'clamd_bf16_to_f32': (_I, [_P, _P, _LL, _P]),
     'clamd_scale_by_device_scalar': (_I, [_P, _LL, _P, _P]),
-    'clamd_scale_by_device_scalar_nhwc': (_I, [_P, _LL, _I, _P, _P]),
+    'clamd_scale_by_device_scalar_nhwc': (_I, [_P, _LL, _I, _P, _P, _LL, _P]),
 }
 
 # include/clamd_debug.h: measurement scaffolding (tools/cu_steal.py), bound when present, never part of the product header

@@ -61,11 +61,9 @@ class _BlockFn(torch.autograd.Function):
                      cin_p, cout_p, 1, 1 if 9 * cout_p > B * H * W else 0, dcode, None, s)
                 vec = torch.zeros(7, cout_p, dtype=torch.float32, device=dev)       # scale, shift, mean, istd, k0, k1, k2
                 call('clamd_bn_finalize', ptr(stats), rows, ptr(gamma.detach()), ptr(beta.detach()), ptr(rm), ptr(rv), ptr(vec[0]), ptr(vec[1]),
-                     ptr(vec[2]), ptr(vec[3]), cout_p, cout, float(B * H * W), BN_MOMENTUM, BN_EPS, s)
+                     ptr(vec[2]), ptr(vec[3]), cout_p, cout, float(B * H * W), BN_MOMENTUM, BN_EPS, ptr(nbt) if training else None, s)
                 out = torch.empty_like(y)
                 call('clamd_bn_apply', ptr(y), cout_p, ptr(vec[0]), ptr(vec[1]), ptr(out), cout_p, None, 0, B, H, W, cout_p, dcode, s)
-                if training:
-                    nbt += 1
                 saved.append(('crb', cur, y, vec, wd, gamma.detach(), (cin, cin_p, cout, cout_p, H, W)))
                 cur = out
             elif op[0] == 'convT':

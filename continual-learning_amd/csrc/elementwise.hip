@@ -9,18 +9,21 @@
 namespace clamd {
 
 // ------------------------------------------------------------------------------------------------
-constexpr int FIN_THREADS = 1024;
-// Fixed-order sum of partial rows [row][NK][Cp] for the 8 channels c0..c0+7 of this block (FIN_THREADS threads): thread
-// (row lane, column) adds its rows in ascending order into four interleaved fp64 chains, the row lanes are then added in
-// ascending order.  The result depends only on (nrows, data): two runs are bit-identical (no float atomics anywhere).
+// The finalize kernels sit on the critical chain between two HBM-bound passes and, in the backward pass, run BESIDE a weight-gradient
+// kernel of the second stream that keeps 352-384 of a SIMD's 512 registers (wgrad_dma.hip: 2 waves x 192): a workgroup must fit into what
+// is left of a CU or it waits for a weight-gradient workgroup to retire -- the 1024-thread form of round 3 (4 waves x 40 registers per
+// SIMD) did, for 35-95 us per launch on 8 launches of a bf16 step (kernel trace, round 4).  256 threads = one 40-register wave per SIMD;
+// FIN_CH channels per workgroup (more, smaller workgroups instead of more threads).
+constexpr int FIN_THREADS = 256, FIN_CH = 2;
+// Fixed-order sum of partial rows [row][NK][Cp] for the FIN_CH channels c0.. of this block: thread (row lane, column) adds its rows in
+// ascending order into four interleaved fp64 chains, the row lanes are then added in ascending order.  The result depends only on
+// (nrows, data): two runs are bit-identical (no float atomics anywhere).
 template <int NK>
 __device__ inline void sum_partial_rows(const float* __restrict__ rows, int nrows, int Cp, int c0, double* red, double* out) {
-    // FIN_THREADS threads: the row loop is a chain of dependent-latency loads and a finalize launch sits on the critical chain between
-    // two HBM-bound passes; with 256 threads the 1024 rows of a 64-channel level-0 reduction took 49 us under load
-    constexpr int COLS = NK * 8, RL = FIN_THREADS / COLS;
+    constexpr int COLS = NK * FIN_CH, RL = FIN_THREADS / COLS;
     const int t = threadIdx.x, col = t % COLS, rl = t / COLS;
     if (rl < RL) {
-        const float* p = rows + (size_t)(col >> 3) * Cp + c0 + (col & 7);
+        const float* p = rows + (size_t)(col / FIN_CH) * Cp + c0 + (col % FIN_CH);
         const size_t rs = (size_t)NK * Cp;
         double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
         int r = rl;
@@ -32,7 +35,7 @@ __device__ inline void sum_partial_rows(const float* __restrict__ rows, int nrow
         red[rl * COLS + col] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
-    if (t < COLS) {
+    if (t < COLS) {      // out[k * FIN_CH + channel]
         double v = 0.;
         for (int q = 0; q < RL; ++q) v += red[q * COLS + t];
         out[t] = v;
@@ -40,22 +43,23 @@ __device__ inline void sum_partial_rows(const float* __restrict__ rows, int nrow
     __syncthreads();
 }
 
-// BN finalise: partial rows of (sum, sumsq) -> mean / invstd / scale / shift, running-stat update.  One block per 8 channels.
+// BN finalise: partial rows of (sum, sumsq) -> mean / invstd / scale / shift, running-stat update.  One block per FIN_CH channels.
 // Reference: nn.BatchNorm2d train mode, models/unet.py:15 (momentum 0.1, eps 1e-5, unbiased running var).
 // Mean and variance are formed in fp64 from the fp64 row sums (E[x^2] - mean^2 cancels in fp32 on low-variance channels).
 __global__ void __launch_bounds__(FIN_THREADS) bn_finalize_kernel(const float* __restrict__ stats, int nrows, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    float* scale, float* shift, float* save_mean, float* save_istd,
-                                   int Cp, int C, double count, double momentum, double eps) {
-    __shared__ double red[FIN_THREADS], tot[16];
-    const int c0 = blockIdx.x * 8;
+                                   int Cp, int C, double count, double momentum, double eps, long long* num_batches_tracked) {
+    __shared__ double red[FIN_THREADS], tot[2 * FIN_CH];
+    const int c0 = blockIdx.x * FIN_CH;
     if (stats) sum_partial_rows<2>(stats, nrows, Cp, c0, red, tot);
-    if (threadIdx.x >= 8) return;
+    if (threadIdx.x >= FIN_CH) return;
+    if (num_batches_tracked && stats && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;      // nn.BatchNorm2d's counter (train mode)
     const int c = c0 + threadIdx.x;
     double mean, var;
     if (stats) {
         mean = tot[threadIdx.x] / count;
-        var = tot[8 + threadIdx.x] / count - mean * mean;
+        var = tot[FIN_CH + threadIdx.x] / count - mean * mean;
         var = var > 0. ? var : 0.;
     } else {   // eval mode (trainer.py:271): normalise with the running statistics, update nothing
         mean = c < C ? (double)running_mean[c] : 0.;
@@ -278,14 +282,14 @@ __global__ void __launch_bounds__(FIN_THREADS) bn_bwd_finalize_kernel(const floa
                                        const float* __restrict__ save_mean, const float* __restrict__ save_istd,
                                        float* k012, float* dgamma, float* dbeta, float* dbias, int Cp, int C,
                                        double count) {
-    __shared__ double red[FIN_THREADS], tot[NSUM * 8];
-    const int c0 = blockIdx.x * 8;
+    __shared__ double red[FIN_THREADS], tot[NSUM * FIN_CH];
+    const int c0 = blockIdx.x * FIN_CH;
     sum_partial_rows<NSUM>(sums, nrows, Cp, c0, red, tot);
-    if (threadIdx.x >= 8) return;
+    if (threadIdx.x >= FIN_CH) return;
     const int c = c0 + threadIdx.x;
     double s[NSUM];
 #pragma unroll
-    for (int k = 0; k < NSUM; ++k) s[k] = tot[k * 8 + threadIdx.x];
+    for (int k = 0; k < NSUM; ++k) s[k] = tot[k * FIN_CH + threadIdx.x];
     const double mu = save_mean[c], istd = save_istd[c];
     const double g = c < C ? (double)gamma[c] : 0.;
     const double inv_n = 1. / count;
@@ -443,10 +447,10 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const T* __restrict__ 
 }
 
 __global__ void __launch_bounds__(FIN_THREADS) channel_sum_final_kernel(const float* __restrict__ partial, int nrows, float* out, int Cp, int C) {
-    __shared__ double red[FIN_THREADS], tot[8];
-    const int c0 = blockIdx.x * 8;
+    __shared__ double red[FIN_THREADS], tot[FIN_CH];
+    const int c0 = blockIdx.x * FIN_CH;
     sum_partial_rows<1>(partial, nrows, Cp, c0, red, tot);
-    if (threadIdx.x < 8 && c0 + threadIdx.x < C) out[c0 + threadIdx.x] = (float)tot[threadIdx.x];
+    if (threadIdx.x < FIN_CH && c0 + threadIdx.x < C) out[c0 + threadIdx.x] = (float)tot[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -614,11 +618,11 @@ extern "C" {
 
 int clamd_bn_finalize(const float* stats, int stat_rows, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float* scale, float* shift, float* save_mean, float* save_istd,
-                      int Cp, int C, double count, double momentum, double eps, void* stream) {
+                      int Cp, int C, double count, double momentum, double eps, long long* num_batches_tracked, void* stream) {
     if (Cp <= 0 || Cp % 8 || C > Cp) return clamd_fail("bn_finalize: bad channel counts");
     if (stats && stat_rows <= 0) return clamd_fail("bn_finalize: stat_rows must be the row count the producing launch wrote");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(Cp / 8), dim3(FIN_THREADS), 0, (hipStream_t)stream, stats, stat_rows, gamma,
-                       beta, running_mean, running_var, scale, shift, save_mean, save_istd, Cp, C, count, momentum, eps);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(Cp / FIN_CH), dim3(FIN_THREADS), 0, (hipStream_t)stream, stats, stat_rows, gamma,
+                       beta, running_mean, running_var, scale, shift, save_mean, save_istd, Cp, C, count, momentum, eps, num_batches_tracked);
     return clamd_check_launch("bn_finalize");
 }
 
@@ -703,7 +707,7 @@ int clamd_bn_bwd_finalize(const float* sums, int sum_rows, const float* gamma, c
                           void* stream) {
     if (Cp <= 0 || Cp % 8 || C > Cp) return clamd_fail("bn_bwd_finalize: bad channel counts");
     if (sum_rows <= 0) return clamd_fail("bn_bwd_finalize: sum_rows must be the row count the producing launch wrote");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(Cp / 8), dim3(FIN_THREADS), 0, (hipStream_t)stream, sums, sum_rows,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(Cp / FIN_CH), dim3(FIN_THREADS), 0, (hipStream_t)stream, sums, sum_rows,
                        gamma, save_mean, save_istd, k012, dgamma, dbeta, dbias, Cp, C, count);
     return clamd_check_launch("bn_bwd_finalize");
 }
@@ -761,7 +765,7 @@ int clamd_bn_bwd_apply_sums(const void* ga, int ga_ldc, const void* y, int y_ldc
 
 int clamd_rows_sum(const float* rows, int nrows, float* out, int Cp, int C, void* stream) {
     if (!rows || !out || nrows <= 0 || Cp <= 0 || Cp % 8 || C > Cp) return clamd_fail("rows_sum: bad arguments");
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(Cp / 8), dim3(FIN_THREADS), 0, (hipStream_t)stream, rows, nrows, out, Cp, C);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(Cp / FIN_CH), dim3(FIN_THREADS), 0, (hipStream_t)stream, rows, nrows, out, Cp, C);
     return clamd_check_launch("rows_sum");
 }
 
@@ -788,7 +792,7 @@ int clamd_channel_sum(const void* g, int ldc, float* out, long long npix, int Cp
     else if (dtype == CLAMD_SPLIT)
         hipLaunchKernelGGL(channel_sum_kernel<split_t>, gr, b, 0, s, (const split_t*)g, ldc, workspace, npix, Cp);
     else return clamd_fail("channel_sum: bad dtype");
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(Cp / 8), dim3(FIN_THREADS), 0, s, workspace, (int)gb, out, Cp, C);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(Cp / FIN_CH), dim3(FIN_THREADS), 0, s, workspace, (int)gb, out, Cp, C);
     return clamd_check_launch("channel_sum");
 }
 

@@ -544,11 +544,14 @@ __global__ void scale_by_dev_kernel(float* p, long long n, const float* __restri
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] *= v;
 }
 
-// ... the same for an NHWC tensor of a compute dtype (the second copy of d logits the fused loss writes), 8-channel groups
+// ... the same for an NHWC tensor of a compute dtype (the second copy of d logits the fused loss writes), 8-channel groups; with p32 != NULL
+// the fp32 tensor is scaled by the same launch (both copies of d logits in one)
 template <typename T>
-__global__ void scale_by_dev_t_kernel(T* p, long long ngroups, const float* __restrict__ scale) {
+__global__ void scale_by_dev_t_kernel(T* p, long long ngroups, const float* __restrict__ scale, float* p32, long long n32) {
     const float v = *scale;
     if (v == 1.f) return;
+    if (p32)
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (long long)gridDim.x * blockDim.x) p32[i] *= v;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < ngroups; i += (long long)gridDim.x * blockDim.x) {
         float t[8];
         Vec8<T>::load(p + i * 8, t);
@@ -713,15 +716,15 @@ int clamd_ce_fwd_bwd_counted(const float* logits, const long long* labels, float
     return clamd_check_launch("ce_fwd_bwd_counted");
 }
 
-int clamd_scale_by_device_scalar_nhwc(void* p, long long n, int dtype, const float* scale_dev, void* stream) {
-    if (n <= 0 || n % 8 || !scale_dev || !p) return clamd_fail("scale_by_device_scalar_nhwc: bad arguments (n must be a multiple of 8 channels)");
+int clamd_scale_by_device_scalar_nhwc(void* p, long long n, int dtype, const float* scale_dev, float* also_f32, long long n_f32, void* stream) {
+    if (n <= 0 || n % 8 || !scale_dev || !p || (also_f32 && n_f32 <= 0)) return clamd_fail("scale_by_device_scalar_nhwc: bad arguments (n must be a multiple of 8 channels)");
     if (int e = clamd_check_split(dtype, p, 16)) return e;
     long long g = (n / 8 + 255) / 256;
     if (g > 4096) g = 4096;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == CLAMD_BF16) hipLaunchKernelGGL(scale_by_dev_t_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, s, (bf16_t*)p, n / 8, scale_dev);
-    else if (dtype == CLAMD_F32) hipLaunchKernelGGL(scale_by_dev_t_kernel<float>, dim3((unsigned)g), dim3(256), 0, s, (float*)p, n / 8, scale_dev);
-    else if (dtype == CLAMD_SPLIT) hipLaunchKernelGGL(scale_by_dev_t_kernel<split_t>, dim3((unsigned)g), dim3(256), 0, s, (split_t*)p, n / 8, scale_dev);
+    if (dtype == CLAMD_BF16) hipLaunchKernelGGL(scale_by_dev_t_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, s, (bf16_t*)p, n / 8, scale_dev, also_f32, n_f32);
+    else if (dtype == CLAMD_F32) hipLaunchKernelGGL(scale_by_dev_t_kernel<float>, dim3((unsigned)g), dim3(256), 0, s, (float*)p, n / 8, scale_dev, also_f32, n_f32);
+    else if (dtype == CLAMD_SPLIT) hipLaunchKernelGGL(scale_by_dev_t_kernel<split_t>, dim3((unsigned)g), dim3(256), 0, s, (split_t*)p, n / 8, scale_dev, also_f32, n_f32);
     else return clamd_fail("scale_by_device_scalar_nhwc: bad dtype");
     return clamd_check_launch("scale_by_device_scalar_nhwc");
 }

@@ -77,10 +77,11 @@ class _CEFn(torch.autograd.Function):
         # g is the scalar upstream gradient on the DEVICE (exactly 1 for loss.backward()): the kernel tests it there and
         # touches d logits only when it is not 1 -- no host sync, no 176-MB multiply-by-one pass per step
         g = g.contiguous().float()
-        call('clamd_scale_by_device_scalar', ptr(dl), dl.numel(), ptr(g), _lib.stream_ptr())
         eng = ctx.sink
-        if eng is not None and eng.dl_src is not None and eng.dl_src[0] == dl.data_ptr():      # the NHWC copy follows
-            call('clamd_scale_by_device_scalar_nhwc', ptr(eng.dl), eng.dl.numel(), eng.dcode, ptr(g), _lib.stream_ptr())
+        if eng is not None and eng.dl_src is not None and eng.dl_src[0] == dl.data_ptr():      # the NHWC copy follows: both in one launch
+            call('clamd_scale_by_device_scalar_nhwc', ptr(eng.dl), eng.dl.numel(), eng.dcode, ptr(g), ptr(dl), dl.numel(), _lib.stream_ptr())
+        else:
+            call('clamd_scale_by_device_scalar', ptr(dl), dl.numel(), ptr(g), _lib.stream_ptr())
         return dl, None, None, None, None, None, None, None
 
 

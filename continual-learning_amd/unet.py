@@ -102,6 +102,7 @@ WGRAD_STREAM = os.environ.get('CLAMD_WGRAD_STREAM', '1') != '0'      # =0: every
 # The plain filter pack of everything behind enc3 (96 % of the parameters; HBM-bound) on the second stream under enc1-enc3 instead of in
 # front of the forward pass (=0: one launch chain on the main stream, as before round 4)
 PACK_LATE_STREAM = os.environ.get('CLAMD_PACK_LATE_STREAM', '1') != '0'
+PACK_LATE_AT = int(os.environ.get('CLAMD_PACK_LATE_AT', '2'))      # index of the convolution unit it is released beside (2 = enc2's first)
 
 # bench.py sets this to a list to get per-launch HIP-event timings of the MFMA kernels:
 # entries (tag, algorithmic_flops, start_event, end_event, algorithmic_bytes), recorded on the stream the kernel is
@@ -369,7 +370,7 @@ class _Engine:
         self.B, self.H, self.W, self.dev = B, H, W, device
         self.dcode, self.tdtype = _DTYPES[model.compute_dtype]
         self.wino = bool(WINOGRAD) and self.dcode == _lib.F32
-        self.pack_late_stream = bool(PACK_LATE_STREAM)
+        self.pack_late_stream, self.pack_late_at = bool(PACK_LATE_STREAM), int(PACK_LATE_AT)
         self.tuning = model.tuning
         self.NS = lib.clamd_bn_bwd_nsums()
         self.generation = 0
@@ -794,14 +795,7 @@ class _Engine:
             for t in self.wino_late:
                 t.run(sp)
         self._ev_pack_late = None
-        if self.pack_late is not None:      # behind the early Winograd transforms (fp32), which the second convolution is waiting for
-            if self.wg_stream is not None and KERNEL_TIMING is None and self.pack_late_stream:
-                self.wg_stream.wait_stream(torch.cuda.current_stream())      # the parameters are final on the current stream (Adam)
-                self.pack_late.run(dc, self.wg_stream.cuda_stream)
-                self._ev_pack_late = torch.cuda.Event()
-                self._ev_pack_late.record(self.wg_stream)
-            else:
-                self.pack_late.run(dc, s)
+        self._pack_late_pending = self.pack_late is not None      # released beside convolution PACK_LATE_AT (see _release_pack_late)
         if self.convs[0].im2col:
             call('clamd_nchw_im2col3', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
                  self.x_in.shape[-1], dc, s)
@@ -884,8 +878,6 @@ class _Engine:
             torch.cuda.current_stream().wait_stream(self.wg_stream)
             self._pack_pending = 0
         self._join_pack_late()
-        if training:
-            torch._foreach_add_(self.nbts, 1)
         return logits
 
     @staticmethod
@@ -944,8 +936,27 @@ class _Engine:
         call('clamd_bn_fold_pack', (24 if u.w24 else 16) if u.wino else 0, ptr(t.dev_table), len(t.jobs), t.nblocks, self.dcode,
              ptr(u.w), 9, ptr(a.vec[1]), ptr(u.b), ptr(u.cb), u.cout, u.cin, u.cout_p, s)
 
+    def _release_pack_late(self):
+        """Enqueues the late part of the plain filter pack: on the second stream, free to start with the convolution about to be launched on
+        the current one.  Released beside enc2's first convolution, not at the start of the forward pass: the pack is HBM-bound (180 MB in
+        bf16) and so are the im2col pass and the 3 -> 64-channel first layer -- beside those it only made them longer (kernel trace, round 4:
+        the first layer 64 -> 160 us with the pack running), the 128 x 128 levels leave HBM bandwidth."""
+        if not self._pack_late_pending:
+            return
+        self._pack_late_pending = False
+        if self.wg_stream is not None and KERNEL_TIMING is None and self.pack_late_stream:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.wg_stream.wait_event(ev)
+            self.pack_late.run(self.dcode, self.wg_stream.cuda_stream)
+            self._ev_pack_late = torch.cuda.Event()
+            self._ev_pack_late.record(self.wg_stream)
+        else:
+            self.pack_late.run(self.dcode, _lib.stream_ptr())
+
     def _join_pack_late(self):
         """The late part of the plain filter pack (second stream) is needed from here on."""
+        self._release_pack_late()
         if self._ev_pack_late is not None:
             torch.cuda.current_stream().wait_event(self._ev_pack_late)
             self._ev_pack_late = None
@@ -955,6 +966,8 @@ class _Engine:
         dc, tp = self.dcode, tune_ptr(self.tuning)
         if u.pack_late:
             self._join_pack_late()
+        elif u is self.convs[min(self.pack_late_at, len(self.convs) - 1)]:
+            self._release_pack_late()
         Bl = self.B if hf is None else self.B // 2
         _TIMED_UNIT[:] = [u.name + ' fwd', self.executed_fraction(u, 'fwd')]
         rows = u.stat_rows_launch
@@ -1000,7 +1013,8 @@ class _Engine:
     def _fwd_finalize(self, u, training, s):
         v = u.vec
         call('clamd_bn_finalize', ptr(u.stats) if training else None, u.stat_rows, ptr(u.gamma), ptr(u.beta), ptr(u.rm), ptr(u.rv),
-             ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), u.cout_p, u.cout, float(self.B * u.h * u.w_), BN_MOMENTUM, BN_EPS, s)
+             ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), u.cout_p, u.cout, float(self.B * u.h * u.w_), BN_MOMENTUM, BN_EPS,
+             ptr(u.nbt) if training else None, s)      # num_batches_tracked += 1 inside the launch (was a torch._foreach_add_ on the critical chain)
 
     def _fwd_post(self, u, s, hf):
         """BatchNorm apply (+ max-pool, concat placement) of unit u on the whole batch or one half of it."""

@@ -250,10 +250,11 @@ int clamd_wgrad(int mode, const void* a, int a_ldc, const void* b, int b_ldc, fl
 /* ---- BatchNorm / ReLU / MaxPool / concat plumbing (elementwise.hip) ------------------------------------------
  * nn.BatchNorm2d train mode (unet.py:15): partial rows stats[stat_rows][2][Cp] -> scale/shift (+ running stats,
  * momentum 0.1, unbiased var); rows are added in a fixed order in fp64, mean/variance formed in fp64.
- * stats == NULL: eval mode, normalise with the running statistics. */
+ * stats == NULL: eval mode, normalise with the running statistics.  num_batches_tracked (optional, int64 scalar): nn.BatchNorm2d's
+ * counter, incremented in train mode (stats != NULL). */
 int clamd_bn_finalize(const float* stats, int stat_rows, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float* scale, float* shift, float* save_mean, float* save_istd,
-                      int Cp, int C, double count, double momentum, double eps, void* stream);
+                      int Cp, int C, double count, double momentum, double eps, long long* num_batches_tracked, void* stream);
 /* out = y*scale+shift into `out` (possibly a concat slice: replaces torch.cat, unet.py:83-87); pooled (optional)
  * = nn.MaxPool2d(2,2) of out (unet.py:12,80). */
 int clamd_bn_apply(const void* y, int y_ldc, const float* scale, const float* shift, void* out, int out_ldc,
@@ -349,8 +350,9 @@ int clamd_bf16_to_f32(const void* src_bf16, float* dst, long long n, void* strea
 /* p[i] *= *scale_dev for a DEVICE scalar, nothing at all when it is exactly 1 (the upstream gradient loss.backward()
  * hands to the loss function, trainer.py:175): no host sync, no pass over d logits in the common case. */
 int clamd_scale_by_device_scalar(float* p, long long n, const float* scale_dev, void* stream);
-/* ... and for an NHWC tensor of a compute dtype (n logical elements, a multiple of 8; the second copy of d logits above) */
-int clamd_scale_by_device_scalar_nhwc(void* p, long long n, int dtype, const float* scale_dev, void* stream);
+/* ... and for an NHWC tensor of a compute dtype (n logical elements, a multiple of 8; the second copy of d logits above); also_f32
+ * (optional, n_f32 elements): an fp32 tensor scaled by the same launch. */
+int clamd_scale_by_device_scalar_nhwc(void* p, long long n, int dtype, const float* scale_dev, float* also_f32, long long n_f32, void* stream);
 
 #ifdef __cplusplus
 }

@@ -247,7 +247,7 @@ def test_abi_rejects_bad_arguments_before_any_launch(C):
         ('workspace too small', 'clamd_wgrad_winograd', (None, 32, None, 32, None, 0, None, 1, 16, 16, 32, 32, 32, 32, 32, 32, 32, 32, None, None)),
         ('bad mode', 'clamd_wgrad', (7, None, 32, None, 32, None, 0, None, 1, 16, 16, 32, 32, 32, 32, 32, 32, 32, 32, 0, None, None)),
         ('empty problem', 'clamd_wgrad', (0, None, 32, None, 32, None, 0, None, 0, 16, 16, 32, 32, 32, 32, 32, 32, 32, 32, 0, None, None)),
-        ('stat_rows', 'clamd_bn_finalize', (1, 0, None, None, None, None, None, None, None, None, 32, 32, 1.0, 0.1, 1e-5, None)),
+        ('stat_rows', 'clamd_bn_finalize', (1, 0, None, None, None, None, None, None, None, None, 32, 32, 1.0, 0.1, 1e-5, None, None)),
         ('sum_rows', 'clamd_bn_bwd_reduce', (1, 32, None, 0, 1, 32, None, None, 1, 3, 1, 16, 16, 32, 0, None, None)),
         ('workspace too small', 'clamd_channel_sum', (1, 32, 1, 64, 32, 32, 0, None, 0, None, None)),
         ('empty job table', 'clamd_wino_pack', (None, 0, 0, None)),
