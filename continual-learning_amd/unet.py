@@ -53,10 +53,11 @@ NARROW_DIRECT = os.environ.get('CLAMD_NARROW_DIRECT', '1') != '0'
 # epilogue, the weight gradient fixed up from the gradient's border sums.  The normalised tensor is never written: the bn_apply pass
 # of the first unit of enc1 / enc2 / dec4 / last (268 + 268 MB at level 0 in fp32) leaves the forward pass.  Up to
 # FOLD_FILTERS_MAX_CHANNELS input channels: the per-step filter pack is on the critical path, the apply pass shrinks with depth.
-# Interleaved A/B (bench.py, ms per step): fp32 21.30 -> 21.08, bf16x3 15.17 -> 14.84, bf16 6.81 = 6.81: in bf16 the apply passes are half
-# the bytes while the pack launch (12 us) on the critical chain and the fix-up launches cost the same, so 'auto' folds the 3x3 pairs on the
-# fp32-storage paths only (the 1x1 head folds everywhere); True = every compute dtype; False = never.
-FOLD_BN_INTO_FILTERS = {'0': False, 'false': False, 'all': True, 'true': True}.get(os.environ.get('CLAMD_FOLD_FILTERS', 'auto').lower(), 'auto')
+# Interleaved A/B (bench.py, ms per step): fp32 21.30 -> 21.08, bf16x3 15.17 -> 14.84; bf16 6.81 = 6.81 in round 3 (the apply passes are half
+# the bytes while the pack launch and the border tiles' table lookups cost the same) and 6.489 -> 6.415 in round 4, with the
+# channels-in-the-lane epilogue (igemm_pws.hip: the class-4 bias is the accumulator's start, only the lanes of border pixels of border
+# tiles add a difference row) and the pack launch at 7 us: every compute dtype folds now.  False = never.
+FOLD_BN_INTO_FILTERS = os.environ.get('CLAMD_FOLD_FILTERS', '1').lower() not in ('0', 'false')
 FOLD_FILTERS_MAX_CHANNELS = int(os.environ.get('CLAMD_FOLD_FILTERS_MAX_CHANNELS', '128'))
 # fp32 path: the same fold for the OUTPUT of an encoder block -- pooled into the next block, concatenated into the decoder (models/unet.py:80-87)
 # -- where both readers are narrow F(2x4) convolutions (enc1 -> enc2's first conv and last's first conv at config 2): the block's second conv
@@ -553,7 +554,7 @@ class _Engine:
             a, b = st['convs']
             # ... and where b transforms inside its kernel (or is a bf16 direct kernel): the algebraic fold of bnfold.hip
             b.fold_a, a.fold_a, a.fold_on, b.fold_on, a.apply_in_filters, b.apply_in_filters = None, None, False, False, False, False
-            if ((FOLD_BN_INTO_FILTERS is True or (FOLD_BN_INTO_FILTERS == 'auto' and self.dcode != _lib.BF16))
+            if (FOLD_BN_INTO_FILTERS
                     and not a.apply_folded and not b.pre_f and a.pooled is None and b.xin is a.out and len(b.cin_segs) == 1
                     and not a.split and not b.split and min(b.h, b.w_) >= 2 and b.cin_p <= FOLD_FILTERS_MAX_CHANNELS):
                 b.fold_a = a      # one direction only: a cycle between units would keep the engine's buffers alive until the garbage collector runs

