@@ -138,67 +138,12 @@ __global__ void __launch_bounds__(256) wino24_xform_kernel(const W24XformParams 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel on the transformed input
 // ---------------------------------------------------------------------------------------------------------------------
-// The five per-channel sums of the fused ReLU / BatchNorm backward (elementwise.hip, bn_bwd_reduce_kernel) taken in the epilogue of the
-// data-gradient launch that PRODUCES the gradient g_u: s0 = sum g_u, s1 = sum g_u y, s2 = sum g_u [y > 0], s3 = sum [y > 0], s4 = sum y.
-// The separate reduce pass reads g_u and y again from HBM (107 us per 64-channel 256 x 256 unit, on the critical chain of the backward
-// pass); here y is prefetched under the accumulator exchange and g_u is in registers.  Partial rows exactly like the statistics rows
-// of the forward launches (per workgroup of the persistent grid, registers across the tiles of one slab): fixed order, bit-reproducible.
-struct W24Sums {
-    float v[5][2][4];
-    __device__ inline void clear() {
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[k][i >> 2][i & 3] = 0.f;
-    }
-    __device__ inline void add1(int nt, int c, float g, float y) {
-        const float m = y > 0.f ? 1.f : 0.f;
-        v[0][nt][c] += g;
-        v[1][nt][c] = fmaf(g, y, v[1][nt][c]);
-        v[2][nt][c] = fmaf(g, m, v[2][nt][c]);
-        v[3][nt][c] += m;
-        v[4][nt][c] += y;
-    }
-    __device__ inline void add(int nt, const float4& g, const float4& y) {
-        add1(nt, 0, g.x, y.x); add1(nt, 1, g.y, y.y); add1(nt, 2, g.z, y.z); add1(nt, 3, g.w, y.w);
-    }
-    // every thread of the workgroup; LDS free.  Threads with equal (tid & 7) own the same channels: fold the 8 tiles of a wave (lane
-    // bits 3-5), then the four waves through LDS; word (kind, channel) of the row is owned by ONE thread for the whole launch.
-    __device__ inline void fold(float* sb, float* rows, bool per_wg, int slab, int tile, int Np) {
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float a = v[k][nt][c];
-                    a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
-                    if (lane < 8) sb[(w * 5 + k) * 64 + 32 * nt + 4 * lane + c] = a;
-                    v[k][nt][c] = 0.f;
-                }
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < 320; idx += 256) {
-            const int k = idx >> 6, c = idx & 63;
-            if (slab * 64 + c >= Np) continue;
-            const float t = (sb[(0 * 5 + k) * 64 + c] + sb[(1 * 5 + k) * 64 + c]) + (sb[(2 * 5 + k) * 64 + c] + sb[(3 * 5 + k) * 64 + c]);
-            if (!per_wg) rows[((size_t)tile * 5 + k) * Np + slab * 64 + c] = t;                       // row = pixel tile, written once
-            else {
-                float* dst = rows + ((size_t)blockIdx.x * 5 + k) * Np + slab * 64 + c;
-                // this thread's own earlier store to the word (zero fill or an earlier fold) must have reached L2: drain, read from L2
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const float old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst, old + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();
-    }
-    __device__ static inline void zero_rows(float* rows, int Np) {        // per-workgroup rows of the persistent grid: the owners zero their words
-        for (int idx = threadIdx.x; idx < 320; idx += 256)
-            for (int n = idx & 63; n < Np; n += 64) rows[((size_t)blockIdx.x * 5 + (idx >> 6)) * Np + n] = 0.f;
-    }
-};
-
+// SUMS (data-gradient launches): the two running sums of the consumer's fused ReLU / BatchNorm backward that depend on the gradient --
+// s0 = sum g_u, s1 = sum g_u y (y = that unit's saved activation, prefetched under the accumulator exchange) -- taken in the epilogue of
+// the launch that PRODUCES g_u, in the very registers and partial rows the forward launches use for sum / sum of squares (a data-gradient
+// launch has no statistics of its own): rows [row][5][Np] with k = 2..4 written as zeros.  The convolution's bias gradient (the three
+// other sums of bn_bwd_reduce_kernel) comes from clamd_bn_bwd_apply_sums.  Round 3 kept all five sums in 40 more registers across the
+// K loop of kernels that use all 512: 45-291 registers spilled; this form adds none.
 constexpr int W24G_EXP = 36;                                  // row pitch (floats) of the epilogue exchange block
 
 template <int TXN, bool RAGGED, int NSET, bool SUMS>
@@ -212,14 +157,17 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
 
     // statistics rows: exactly wino24_kernel's scheme (per-workgroup rows on the persistent grid, registers across the tiles
     // of one output slab, one fold per slab) -- the two kernels are interchangeable for bn_finalize
-    const bool per_wg_rows = p.stats != nullptr && gridDim.x < (unsigned)p.nblk;
-    if (per_wg_rows && threadIdx.x < 128)
-        for (int n = threadIdx.x & 63; n < p.Np; n += 64) p.stats[((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * p.Np + n] = 0.f;
+    float* const rows_base = SUMS ? p.bn_sums : p.stats;                  // SUMS: (sum g, sum g y) rows of five kinds, else (sum, sum of squares)
+    constexpr int NKR = SUMS ? 5 : 2;
+    const bool per_wg_rows = rows_base != nullptr && gridDim.x < (unsigned)p.nblk;
+    if (per_wg_rows)
+        for (int k = threadIdx.x >> 6; k < NKR; k += 4)
+            for (int n = threadIdx.x & 63; n < p.Np; n += 64) rows_base[((size_t)blockIdx.x * NKR + k) * p.Np + n] = 0.f;
     float racc = 0.f;
     int rslab = -1;
     auto flush_row = [&]() {
         if (rslab >= 0 && rslab * 64 + (int)(threadIdx.x & 63) < p.Np) {
-            float* dst = p.stats + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * p.Np + rslab * 64 + (threadIdx.x & 63);
+            float* dst = rows_base + ((size_t)blockIdx.x * NKR + (threadIdx.x >> 6)) * p.Np + rslab * 64 + (threadIdx.x & 63);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const float old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(dst, old + racc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -229,14 +177,6 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) { st1[i >> 2][i & 3] = 0.f; st2[i >> 2][i & 3] = 0.f; }
     int cur_tn = -1, cur_tm = 0;
-    // fused BatchNorm-backward sums of a data-gradient launch (SUMS): rows like the statistics rows
-    const bool sums_per_wg = SUMS && gridDim.x < (unsigned)p.nblk;
-    W24Sums bsum;
-    int sum_tn = -1, sum_tm = 0;
-    if constexpr (SUMS) {
-        bsum.clear();
-        if (sums_per_wg) W24Sums::zero_rows(p.bn_sums, p.Np);
-    }
     auto fold_stats = [&]() {
         float* sb = reinterpret_cast<float*>(smem);                            // [wave][2][64]
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -255,10 +195,16 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
             const int k = threadIdx.x >> 6, c = threadIdx.x & 63;
             const float t = sb[(0 * 2 + k) * 64 + c] + sb[(1 * 2 + k) * 64 + c] + sb[(2 * 2 + k) * 64 + c] + sb[(3 * 2 + k) * 64 + c];
             if (!per_wg_rows) {
-                if (cur_tn * 64 + c < p.Np) p.stats[((size_t)cur_tm * 2 + k) * p.Np + cur_tn * 64 + c] = t;
+                if (cur_tn * 64 + c < p.Np) rows_base[((size_t)cur_tm * NKR + k) * p.Np + cur_tn * 64 + c] = t;
             } else {
                 rslab = cur_tn; racc = t;
                 flush_row();
+            }
+        } else if (SUMS && !per_wg_rows) {      // threads 128 .. 255, one row per tile: its kinds 2, 3 and 4 are zeros
+            const int idx = threadIdx.x - 128, c = idx & 63;
+            if (cur_tn * 64 + c < p.Np) {
+                rows_base[((size_t)cur_tm * NKR + 2 + (idx >> 6)) * p.Np + cur_tn * 64 + c] = 0.f;
+                if (idx < 64) rows_base[((size_t)cur_tm * NKR + 4) * p.Np + cur_tn * 64 + c] = 0.f;
             }
         }
         __syncthreads();
@@ -293,8 +239,6 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
         const int x0 = (tm % tiles_x) * PW, y0 = ((tm / tiles_x) % tiles_y) * PH, b = tm / (tiles_x * tiles_y);
         const int n0 = tn * 64;
         if (cur_tn >= 0 && (tn != cur_tn || !per_wg_rows)) fold_stats();
-        if constexpr (SUMS)
-            if (sum_tn >= 0 && (tn != sum_tn || !sums_per_wg)) { bsum.fold(reinterpret_cast<float*>(smem), p.bn_sums, sums_per_wg, sum_tn, sum_tm, p.Np); sum_tn = -1; }      // workgroup-uniform
 
         // the tile after this one (the load stream does not stop at a tile boundary)
         const int vn = v + (int)gridDim.x;
@@ -430,8 +374,12 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
                     const int yy = y0 + 2 * oty + pp, xx = x0 + 4 * otx + q;
                     if (!RAGGED || (yy < p.H && xx < p.W)) {
                         *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = o;
-                        if constexpr (SUMS) bsum.add(nt, o, yv[q * 2 + pp]);
-                        if (!plain) {
+                        if constexpr (SUMS) {
+                            const float4 yq = yv[q * 2 + pp];
+                            st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
+                            st2[nt][0] = fmaf(o.x, yq.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, yq.y, st2[nt][1]);
+                            st2[nt][2] = fmaf(o.z, yq.z, st2[nt][2]); st2[nt][3] = fmaf(o.w, yq.w, st2[nt][3]);
+                        } else if (!plain) {
                             st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
                             st2[nt][0] = fmaf(o.x, o.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, o.y, st2[nt][1]);
                             st2[nt][2] = fmaf(o.z, o.z, st2[nt][2]); st2[nt][3] = fmaf(o.w, o.w, st2[nt][3]);
@@ -441,13 +389,10 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
             }
             if constexpr (SUMS) { if (nt == 0) load_y(1); }
         }
-        if (p.stats) { cur_tn = tn; cur_tm = tm; }
-        if constexpr (SUMS) { sum_tn = tn; sum_tm = tm; }
+        if (rows_base) { cur_tn = tn; cur_tm = tm; }
         __syncthreads();                                                   // exchange / statistics blocks are free again
     }
     if (cur_tn >= 0) fold_stats();
-    if constexpr (SUMS)
-        if (sum_tn >= 0) bsum.fold(reinterpret_cast<float*>(smem), p.bn_sums, sums_per_wg, sum_tn, sum_tm, p.Np);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -474,14 +419,17 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
     static_assert(2 * IN_SLOTS <= LDS && LDS * 16 <= 160 * 1024, "LDS budget");
     __shared__ uint4 smem[LDS];
 
-    const bool per_wg_rows = p.stats != nullptr && gridDim.x < (unsigned)p.nblk;
-    if (per_wg_rows && threadIdx.x < 128)
-        for (int n = threadIdx.x & 63; n < p.Np; n += 64) p.stats[((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * p.Np + n] = 0.f;
+    float* const rows_base = SUMS ? p.bn_sums : p.stats;                  // SUMS: (sum g, sum g y) rows of five kinds, else (sum, sum of squares)
+    constexpr int NKR = SUMS ? 5 : 2;
+    const bool per_wg_rows = rows_base != nullptr && gridDim.x < (unsigned)p.nblk;
+    if (per_wg_rows)
+        for (int k = threadIdx.x >> 6; k < NKR; k += 4)
+            for (int n = threadIdx.x & 63; n < p.Np; n += 64) rows_base[((size_t)blockIdx.x * NKR + k) * p.Np + n] = 0.f;
     float racc = 0.f;
     int rslab = -1;
     auto flush_row = [&]() {
         if (rslab >= 0 && rslab * 64 + (int)(threadIdx.x & 63) < p.Np) {
-            float* dst = p.stats + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 6)) * p.Np + rslab * 64 + (threadIdx.x & 63);
+            float* dst = rows_base + ((size_t)blockIdx.x * NKR + (threadIdx.x >> 6)) * p.Np + rslab * 64 + (threadIdx.x & 63);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const float old = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(dst, old + racc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -491,14 +439,6 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) { st1[i >> 2][i & 3] = 0.f; st2[i >> 2][i & 3] = 0.f; }
     int cur_tn = -1, cur_tm = 0;
-    // fused BatchNorm-backward sums of a data-gradient launch (SUMS): rows like the statistics rows
-    const bool sums_per_wg = SUMS && gridDim.x < (unsigned)p.nblk;
-    W24Sums bsum;
-    int sum_tn = -1, sum_tm = 0;
-    if constexpr (SUMS) {
-        bsum.clear();
-        if (sums_per_wg) W24Sums::zero_rows(p.bn_sums, p.Np);
-    }
     auto fold_stats = [&]() {
         float* sb = reinterpret_cast<float*>(smem);
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -517,10 +457,16 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
             const int k = threadIdx.x >> 6, c = threadIdx.x & 63;
             const float t = sb[(0 * 2 + k) * 64 + c] + sb[(1 * 2 + k) * 64 + c] + sb[(2 * 2 + k) * 64 + c] + sb[(3 * 2 + k) * 64 + c];
             if (!per_wg_rows) {
-                if (cur_tn * 64 + c < p.Np) p.stats[((size_t)cur_tm * 2 + k) * p.Np + cur_tn * 64 + c] = t;
+                if (cur_tn * 64 + c < p.Np) rows_base[((size_t)cur_tm * NKR + k) * p.Np + cur_tn * 64 + c] = t;
             } else {
                 rslab = cur_tn; racc = t;
                 flush_row();
+            }
+        } else if (SUMS && !per_wg_rows) {      // threads 128 .. 255, one row per tile: its kinds 2, 3 and 4 are zeros
+            const int idx = threadIdx.x - 128, c = idx & 63;
+            if (cur_tn * 64 + c < p.Np) {
+                rows_base[((size_t)cur_tm * NKR + 2 + (idx >> 6)) * p.Np + cur_tn * 64 + c] = 0.f;
+                if (idx < 64) rows_base[((size_t)cur_tm * NKR + 4) * p.Np + cur_tn * 64 + c] = 0.f;
             }
         }
         __syncthreads();
@@ -557,8 +503,6 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
         const int x0 = (tm % tiles_x) * PW, y0 = ((tm / tiles_x) % tiles_y) * PH, b = tm / (tiles_x * tiles_y);
         const int n0 = tn * 64;
         if (cur_tn >= 0 && (tn != cur_tn || !per_wg_rows)) fold_stats();
-        if constexpr (SUMS)
-            if (sum_tn >= 0 && (tn != sum_tn || !sums_per_wg)) { bsum.fold(reinterpret_cast<float*>(smem), p.bn_sums, sums_per_wg, sum_tn, sum_tm, p.Np); sum_tn = -1; }
 
         const int vn = v + (int)gridDim.x;
         const bool has_next = vn < p.nblk;
@@ -769,8 +713,12 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
                     }
                     if (!RAGGED || (yy < p.H && xx < p.W)) {
                         *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = o;
-                        if constexpr (SUMS) bsum.add(nt, o, yv[q * 2 + pp]);
-                        if (!plain) {
+                        if constexpr (SUMS) {
+                            const float4 yq = yv[q * 2 + pp];
+                            st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
+                            st2[nt][0] = fmaf(o.x, yq.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, yq.y, st2[nt][1]);
+                            st2[nt][2] = fmaf(o.z, yq.z, st2[nt][2]); st2[nt][3] = fmaf(o.w, yq.w, st2[nt][3]);
+                        } else if (!plain) {
                             st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
                             st2[nt][0] = fmaf(o.x, o.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, o.y, st2[nt][1]);
                             st2[nt][2] = fmaf(o.z, o.z, st2[nt][2]); st2[nt][3] = fmaf(o.w, o.w, st2[nt][3]);
@@ -780,13 +728,10 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
             }
             if constexpr (SUMS) { if (nt == 0) load_y(1); }
         }
-        if (p.stats) { cur_tn = tn; cur_tm = tm; }
-        if constexpr (SUMS) { sum_tn = tn; sum_tm = tm; }
+        if (rows_base) { cur_tn = tn; cur_tm = tm; }
         __syncthreads();                                                   // exchange / statistics blocks are free again
     }
     if (cur_tn >= 0) fold_stats();
-    if constexpr (SUMS)
-        if (sum_tn >= 0) bsum.fold(reinterpret_cast<float*>(smem), p.bn_sums, sums_per_wg, sum_tn, sum_tm, p.Np);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1085,6 +1030,7 @@ int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const floa
                                  float* stats, int stat_rows, const float* bn_y, float* bn_sums, int B, int H, int W, int Cin_p,
                                  int Cout_p, int relu, const clamd_tuning* tune, void* stream) {
     if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("conv3x3_winograd24_pre: bn_y and bn_sums go together");
+    if (bn_sums && (stats || bias || relu)) return clamd_fail("conv3x3_winograd24_pre: bn_y / bn_sums belong to a plain data-gradient launch (no bias, ReLU or statistics)");
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("conv3x3_winograd24_pre: empty problem");
     if ((H & 1) || (W & 3)) return clamd_fail("conv3x3_winograd24_pre: H must be even and W a multiple of 4 (2x4 output tiles)");
     if (Cin_p % 32 || Cin_p < 64 || Cout_p % 64 || y_ldc % 8) return clamd_fail("conv3x3_winograd24_pre: needs Cin_p % 32 == 0, Cin_p >= 64, Cout_p % 64 == 0");
@@ -1121,6 +1067,7 @@ int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const flo
                                             float* stats, int stat_rows, const float* bn_y, float* bn_sums, int B, int H, int W,
                                             int Cin_p, int Cout_p, int relu, const clamd_tuning* tune, void* stream) {
     if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("conv3x3_winograd24_direct_filters: bn_y and bn_sums go together");
+    if (bn_sums && (stats || bias || relu)) return clamd_fail("conv3x3_winograd24_direct_filters: bn_y / bn_sums belong to a plain data-gradient launch (no bias, ReLU or statistics)");
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("conv3x3_winograd24_direct_filters: empty problem");
     if ((H & 1) || (W & 3)) return clamd_fail("conv3x3_winograd24_direct_filters: H must be even and W a multiple of 4 (2x4 output tiles)");
     if (Cin_p % 32 || Cout_p % 64 || x_ldc % 8 || y_ldc % 8) return clamd_fail("conv3x3_winograd24_direct_filters: needs Cin_p % 32 == 0, Cout_p % 64 == 0");

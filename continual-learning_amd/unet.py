@@ -680,8 +680,9 @@ class _Engine:
                 src = getattr(u, 'sum_src', None)
                 if src is None:       # the 3x3 data-gradient launch of the next conv of this stage (K = its output channels)
                     b = next(c for c in self.convs if c.consumer is u)
-                    if b.wino:
+                    if b.wino:      # wino24g.hip: the two gradient-dependent sums in the statistics registers of the data-gradient launch
                         u.sum_rows = rows(_lib.OP_CONV3X3_WINOGRAD24, B, b.h, b.w_, b.cout_p, b.cin_p, dc, tuning=tn)
+                        u.gz_nrows = _lib.load().clamd_bn_bwd_apply_sums_rows(B, u.h, u.w_, u.cout_p)
                     else:
                         u.sum_rows = rows(_lib.OP_CONV3X3, B, b.h, b.w_, b.cout_p, b.cin_p, dc, fused_bn=True, tuning=tn)
                         # the persistent bf16 kernel takes sum g and sum g y only: the conv-bias gradient then comes from the apply pass

@@ -167,10 +167,11 @@ int clamd_wgrad_winograd24(const float* gz, int gz_ldc, const float* x, int x_ld
  * convolution (models/unet.py:15-16,30-31: clamd_bn_finalize's scale / shift on the producer's conv+ReLU output) folded into
  * the load, with the zero padding applied AFTER the affine as nn.Conv2d does; the clamd_bn_apply pass of that unit is then not
  * needed when nothing else reads its output.
- * bn_y / bn_sums (optional, data-gradient launches, also of clamd_conv3x3_winograd24_direct_filters): as for clamd_conv3x3 -- when y of
- * this launch is the gradient w.r.t. a BatchNorm output, the five per-channel sums of clamd_bn_bwd_reduce are accumulated in the
- * epilogue (bn_y = that unit's saved activation [B,H,W,Cout_p], dense; bn_sums = [stat_rows][5][Cout_p]) and the separate
- * reduce pass over the gradient and the activation is not needed. */
+ * bn_y / bn_sums (optional, plain data-gradient launches -- no bias, ReLU or statistics -- also of clamd_conv3x3_winograd24_direct_filters):
+ * when y of this launch is the gradient g w.r.t. a BatchNorm output, the TWO gradient-dependent sums of clamd_bn_bwd_reduce (sum g,
+ * sum g y_saved: rows k = 0, 1 of bn_sums = [stat_rows][5][Cout_p]; k = 2..4 are written as zeros) are accumulated in the epilogue
+ * (bn_y = that unit's saved activation [B,H,W,Cout_p], dense) and the separate reduce pass over the gradient and the activation is not
+ * needed; the convolution's bias gradient then comes from clamd_bn_bwd_apply_sums (the two-sum form, see clamd_bn_bwd_apply). */
 size_t clamd_winograd24_input_elems(int B, int H, int W, int Cp);
 int clamd_winograd24_transform_input(const float* x, int x_ldc, const float* scale, const float* shift, float* v, int B, int H, int W,
                                      int Cp, void* stream);

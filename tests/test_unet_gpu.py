@@ -871,7 +871,7 @@ def test_batchnorm_of_an_encoder_block_folded_into_both_readers(C, monkeypatch):
 
 
 def test_winograd_dgrad_with_fused_bn_backward_sums(C, monkeypatch):
-    """unet.FUSE_WINO_SUMS (opt-in): the five BatchNorm-backward sums of a stage's first unit taken in the epilogue of the Winograd
+    """unet.FUSE_WINO_SUMS: the two gradient-dependent BatchNorm-backward sums of a stage's first unit taken in the epilogue of the Winograd
     data-gradient launch (pre-transformed and direct-filter kernels of wino24g.hip) instead of the separate bn_bwd_reduce pass: the
     same sums over other partial rows -> the same step up to fp32 rounding of the rows; bit-identical to itself."""
     from continual_learning_amd import unet as U
