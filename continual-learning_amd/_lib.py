@@ -23,7 +23,7 @@ class Tuning(ctypes.Structure):
     state; an engine owns one of these and passes it to every launch (None = library defaults)."""
     _fields_ = [(n, c_int) for n in ('igemm_pws', 'igemm_ws', 'igemm_variant', 'pws_wres', 'wgrad_ws', 'wgrad_dma',
                                      'wgrad_xcd', 'wgrad_blocks', 'wgrad_tw16', 'wino_band', 'wino_persist', 'wino_mt',
-                                     'bn_reduce_blocks', 'chsum_blocks', 'cu_reserve', 'pws_cl')] + [('reserved', c_int * 8)]
+                                     'bn_reduce_blocks', 'chsum_blocks', 'cu_reserve')] + [('reserved', c_int * 9)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -72,8 +72,6 @@ SIGNATURES = {
     'clamd_conv1x1_argmax': (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_convT2x2_fwd': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_convT2x2_dgrad': (_I, [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    'clamd_convT2x2_fwd_direct': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    'clamd_convT2x2_dgrad_direct': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_wgrad_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
     'clamd_wgrad': (_I, [_I, _P, _I, _P, _I, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_bn_finalize': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _P, _P]),
@@ -101,8 +99,8 @@ SIGNATURES = {
     'clamd_conv3x3_winograd24': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_winograd24_input_elems': (_SZ, [_I, _I, _I, _I]),
     'clamd_winograd24_transform_input': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
-    'clamd_conv3x3_winograd24_pre': (_I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
-    'clamd_conv3x3_winograd24_direct_filters': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'clamd_conv3x3_winograd24_pre': (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'clamd_conv3x3_winograd24_direct_filters': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_wgrad_winograd24_pre_operand_elems': (_SZ, [_I, _I, _I, _I]),
     'clamd_wgrad_winograd24_pre_transform': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     'clamd_wgrad_winograd24_pre_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I]),

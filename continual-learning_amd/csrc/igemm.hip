@@ -579,7 +579,7 @@ int clamd_conv3x3_bn_sums(int B, int H, int W, int Cin_p, int Cout_p, int dtype,
     IgemmParams p{nullptr, Cin_p, nullptr, nullptr, nullptr, Cout_p, nullptr, B, H, W, Cin_p, Cout_p, 0, 0, 0, nullptr, nullptr};
     p.bn_y = (const void*)&p;          // only tested against null by the planner
     const clamd_tuning& tn = clamd_tune(tune);
-    return (dtype == CLAMD_BF16 && tn.pws_cl && plan_conv3x3(p, dtype, tn).kind == 2) ? 2 : 5;
+    return (dtype == CLAMD_BF16 && plan_conv3x3(p, dtype, tn).kind == 2) ? 2 : 5;
 }
 
 int clamd_conv1x1(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,

@@ -43,7 +43,7 @@ __device__ unsigned long long g_pws_diag[8];
 // transposition (32 ds_write_b32 + 8 ds_read_b128 per 32 x 64 block in the CLM = 0 epilogue), the bias is the accumulator's initial
 // value, and the per-channel statistics are running sums per accumulator register (64 registers, reduced over the 32 pixel lanes once
 // per workgroup).  Per 256-pixel tile and wave ~170 instead of ~430 non-MFMA instructions on a forward launch.
-//   CLM 0: the wave-private transposition epilogue (fp32 / bf16x3 storage)          1: plain (data gradient: no bias, ReLU, statistics)
+//   CLM 0: the wave-private transposition epilogue (fp32 / bf16x3 storage only)     1: plain (data gradient: no bias, ReLU, statistics)
 //   CLM 2: bias (+ border-class table, CLS) + ReLU + statistics                      3: plain + the two running sums of the consumer's
 //                                                                                       BatchNorm backward (sum g, sum g y: rows k = 0, 1)
 template <typename T, int TW, bool RAGGED, bool CLS = false, int CLM = 0>      // CLS: bias from a border-class table (IgemmParams::bias_classes)
@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
     // bound: 34.7k cycles either way) and slower in the read-back (6.0k -> 8.9k cycles), -DPWS_EPW=72 to reproduce.
     constexpr int EPW = PWS_EPW;
     constexpr bool CL = CLM != 0;
-    static_assert(!CL || sizeof(T) == 2, "channels-in-the-lane epilogues: bf16 storage");
+    static_assert(CL == (sizeof(T) == 2), "bf16 storage takes the channels-in-the-lane epilogues, fp32 / bf16x3 storage the transposition");
     static_assert(!CLS || CLM == 0 || CLM == 2, "the border-class table belongs to the bias epilogue");
     constexpr int EPI_SLOTS = CL ? 0 : (4 * 32 * EPW + 8 * 64) / 4;       // 4 waves x [32][EPW] fp32 + statistics hand-over
     static_assert((2 * STAGE + EPI_SLOTS) * 16 <= 160 * 1024, "two LDS stages + the epilogue region must fit one CU");
@@ -84,17 +84,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
     const int nk = p.Kp / KC;                                    // even (checked by the launcher)
     const int S = T_ * nk;                                       // flattened K-steps
 
-    float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};              // consumers: running sum / sum of squares, columns 32*nt + r
-    // bf16 data-gradient launches may also accumulate the five per-channel sums of the consumer's fused ReLU/BatchNorm
-    // backward (IgemmParams::bn_y / bn_sums): registers across tiles, one flush per workgroup; the saved activation
-    // pieces are fetched while the last K-step of the tile is still multiplying.
-    constexpr bool BN = sizeof(T) == 2 && CLM == 0;
-    const bool do_bn = BN && p.bn_y != nullptr;
-    float bs[BN ? 5 : 1][8];
-#pragma unroll
-    for (int k = 0; k < (BN ? 5 : 1); ++k)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bs[k][j] = 0.f;
+    float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};              // consumers (CLM 0): running sum / sum of squares, columns 32*nt + r
 
     if (producer) {
         // ------------------------------------------------------------------ producers: global -> registers -> LDS
@@ -440,9 +430,6 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();
         const bool plain = !p.relu && !p.bias && !p.stats;         // wave-uniform
         const unsigned y_img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.y_ldc * (unsigned)sizeof(T);
-        const unsigned bn_img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.Np * (unsigned)sizeof(T);   // bn_y: dense pitch Np
-        unsigned bn_vo[BN ? MT : 1][4];
-        uint4 ypc[BN ? MT : 1][4];                 // saved-activation pieces (8 bf16 channels) of the tile being finished
         unsigned st_vo[MT][4];                     // tile-relative byte offsets of the 8-channel pieces this lane stores
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -450,7 +437,6 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             for (int ps = 0; ps < 4; ++ps) {
                 const int m = 32 * MT * cw + 32 * mt + ps * 8 + (lane >> 3), n = n0 + (lane & 7) * 8;
                 st_vo[mt][ps] = n < p.Np ? (unsigned)(((m / TW) * p.W + m % TW) * p.y_ldc + n) * (unsigned)sizeof(T) : BUF_OOB;
-                if constexpr (BN) bn_vo[mt][ps] = n < p.Np ? (unsigned)(((m / TW) * p.W + m % TW) * p.Np + n) * (unsigned)sizeof(T) : BUF_OOB;
             }
 
         unsigned long long d0 = PWD_T(), d1, d2, dk = 0, db = 0, de = 0, dea = 0, deb = 0, dec_ = 0;
@@ -469,26 +455,6 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             for (int ks = 0; ks < nk; ++ks) {
                 d0 = PWD_T();
                 const uint4* sm = smem + (ks & 1) * STAGE;         // nk is even: the stage parity restarts with every tile
-                if constexpr (BN) {
-                    if (do_bn && ks == nk - 1) {                   // wave-uniform
-                        const int tm_ = mg + ti * gm;
-                        const int x0_ = (tm_ % tiles_x) * TW, y0_ = ((tm_ / tiles_x) % tiles_y) * TH, b_ = tm_ / (tiles_x * tiles_y);
-                        const __amdgpu_buffer_rsrc_t brs = make_rsrc((const char*)p.bn_y + (size_t)b_ * bn_img, bn_img);
-                        const unsigned bso = (unsigned)((y0_ * p.W + x0_) * p.Np) * (unsigned)sizeof(T);
-                        const bool full_ = !RAGGED || (y0_ + TH <= p.H && x0_ + TW <= p.W);
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                            for (int ps = 0; ps < 4; ++ps) {
-                                unsigned vo = bn_vo[mt][ps];
-                                if (!full_) {
-                                    const int m = 32 * MT * cw + 32 * mt + ps * 8 + (lane >> 3);
-                                    if (!(y0_ + m / TW < p.H && x0_ + m % TW < p.W)) vo = BUF_OOB;
-                                }
-                                ypc[mt][ps] = buf_ld16(brs, vo, bso);
-                            }
-                    }
-                }
                 if constexpr (SPLIT) {
                     uint4 f[2][2 * MT + 4];      // [buffer][a_hi[mt], a_lo[mt] ..., bh0, bl0, bh1, bl1]
 #define PWS_FRAG_S(t_, d_)                                                                                        \
@@ -681,24 +647,6 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
 #else
                     buf_st8<T>(yrs, vo, y_so, v);
 #endif
-                    if constexpr (BN) {
-                        if (do_bn) {
-                            float yv[8];
-                            const uint4 u = ypc[mt][ps];
-                            yv[0] = __uint_as_float(u.x << 16); yv[1] = __uint_as_float(u.x & 0xffff0000u);
-                            yv[2] = __uint_as_float(u.y << 16); yv[3] = __uint_as_float(u.y & 0xffff0000u);
-                            yv[4] = __uint_as_float(u.z << 16); yv[5] = __uint_as_float(u.z & 0xffff0000u);
-                            yv[6] = __uint_as_float(u.w << 16); yv[7] = __uint_as_float(u.w & 0xffff0000u);
-                            const bool ok = vo != BUF_OOB;         // pixel inside the image and channel group inside Np
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const float g = ok ? v[j] : 0.f;
-                                const float pos = yv[j] > 0.f ? 1.f : 0.f;
-                                bs[0][j] += g; bs[1][j] = fmaf(g, yv[j], bs[1][j]); bs[2][j] = fmaf(g, pos, bs[2][j]);
-                                bs[3][j] += pos; bs[4][j] += yv[j];
-                            }
-                        }
-                    }
                 }
                 dea += e1 - e0; deb += e2 - e1; dec_ += PWD_T() - e2;
             }
@@ -758,27 +706,6 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             if (n0 + c < p.Np) p.stats[((size_t)mg * 2 + k) * p.Np + n0 + c] = t;
         }
     }
-    if constexpr (BN) {
-        if (do_bn) {
-            float* ebuf = reinterpret_cast<float*>(smem + 2 * STAGE);      // the wave-private transposition blocks are free now
-            if (!producer) {
-#pragma unroll
-                for (int k = 0; k < 5; ++k)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float t = bs[k][j];
-                        t += __shfl_xor(t, 8); t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
-                        if (lane < 8) ebuf[cw * 32 * EPW + k * 64 + lane * 8 + j] = t;
-                    }
-            }
-            __syncthreads();
-            for (int i = tid; i < 5 * 64; i += 512) {
-                const int k = i >> 6, c = i & 63;
-                const float t = ebuf[0 * 32 * EPW + i] + ebuf[1 * 32 * EPW + i] + ebuf[2 * 32 * EPW + i] + ebuf[3 * 32 * EPW + i];
-                if (n0 + c < p.Np) p.bn_sums[((size_t)mg * 5 + k) * p.Np + n0 + c] = t;
-            }
-        }
-    }
 }
 
 }  // namespace clamd
@@ -795,7 +722,7 @@ namespace clamd {
 // Workgroups per 64-channel output slab (= partial statistics rows of a launch), or -1 when this kernel declines the shape.
 int pws_rows(const IgemmParams& p, int dtype, const clamd_tuning& tn) {
     const int esz = dtype == CLAMD_BF16 ? 2 : 4, kc = dtype == CLAMD_BF16 ? 32 : 16;
-    if (p.bn_y && esz != 2) return -1;                       // fused BN-backward sums here: bf16 only (register budget)
+    if (p.bn_y && (esz != 2 || p.bias || p.relu || p.stats || p.bias_classes)) return -1;   // the two-sum epilogue: bf16, plain data-gradient launches
     if (p.Kp % (2 * kc)) return -1;                          // K-steps are staged in pairs
     const int TW = p.W >= 32 ? 32 : 16, TH = 256 / TW;
     const long long ntm = (long long)((p.W + TW - 1) / TW) * ((p.H + TH - 1) / TH) * p.B;
@@ -820,19 +747,16 @@ static int launch_pws_t(const IgemmParams& p, hipStream_t s, int dtype, const cl
 #define PWS_LAUNCH_K(TW_, RG_, CLS_, CLM_) hipLaunchKernelGGL((igemm_pws_kernel<T, TW_, RG_, CLS_, CLM_>), dim3((unsigned)nblk), dim3(512), 0, s, p, (int)gm, tn.pws_wres)
 #define PWS_LAUNCH(TW_, RG_)                                                                                                      \
     do {                                                                                                                           \
-        if constexpr (sizeof(T) == 2) {                                                                                            \
-            /* bf16: the channels-in-the-lane epilogues (tuning pws_cl = 0: the transposition epilogue, for A/B tools) */            \
+        if constexpr (sizeof(T) == 2) {      /* bf16: the channels-in-the-lane epilogues */                                         \
             const bool plain_ = !p.bias && !p.relu && !p.stats && !p.bias_classes;                                                 \
-            if (tn.pws_cl && p.bn_y && plain_) { PWS_LAUNCH_K(TW_, RG_, false, 3); break; }                                        \
-            if (tn.pws_cl && !p.bn_y) {                                                                                            \
-                if (plain_) PWS_LAUNCH_K(TW_, RG_, false, 1);                                                                      \
-                else if (p.bias_classes) PWS_LAUNCH_K(TW_, RG_, true, 2);                                                          \
-                else PWS_LAUNCH_K(TW_, RG_, false, 2);                                                                             \
-                break;                                                                                                             \
-            }                                                                                                                      \
+            if (p.bn_y) PWS_LAUNCH_K(TW_, RG_, false, 3);                /* plain, checked by pws_rows */                           \
+            else if (plain_) PWS_LAUNCH_K(TW_, RG_, false, 1);                                                                     \
+            else if (p.bias_classes) PWS_LAUNCH_K(TW_, RG_, true, 2);                                                              \
+            else PWS_LAUNCH_K(TW_, RG_, false, 2);                                                                                 \
+        } else {                                                                                                                   \
+            if (p.bias_classes) PWS_LAUNCH_K(TW_, RG_, true, 0);                                                                   \
+            else PWS_LAUNCH_K(TW_, RG_, false, 0);                                                                                 \
         }                                                                                                                          \
-        if (p.bias_classes) PWS_LAUNCH_K(TW_, RG_, true, 0);                                                                       \
-        else PWS_LAUNCH_K(TW_, RG_, false, 0);                                                                                     \
     } while (0)
     if (wide) { if (ragged) PWS_LAUNCH(32, true); else PWS_LAUNCH(32, false); }
     else { if (ragged) PWS_LAUNCH(16, true); else PWS_LAUNCH(16, false); }

@@ -137,16 +137,9 @@ __global__ void __launch_bounds__(256) wino24_xform_kernel(const W24XformParams 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel on the transformed input
-// ---------------------------------------------------------------------------------------------------------------------
-// SUMS (data-gradient launches): the two running sums of the consumer's fused ReLU / BatchNorm backward that depend on the gradient --
-// s0 = sum g_u, s1 = sum g_u y (y = that unit's saved activation, prefetched under the accumulator exchange) -- taken in the epilogue of
-// the launch that PRODUCES g_u, in the very registers and partial rows the forward launches use for sum / sum of squares (a data-gradient
-// launch has no statistics of its own): rows [row][5][Np] with k = 2..4 written as zeros.  The convolution's bias gradient (the three
-// other sums of bn_bwd_reduce_kernel) comes from clamd_bn_bwd_apply_sums.  Round 3 kept all five sums in 40 more registers across the
-// K loop of kernels that use all 512: 45-291 registers spilled; this form adds none.
 constexpr int W24G_EXP = 36;                                  // row pitch (floats) of the epilogue exchange block
 
-template <int TXN, bool RAGGED, int NSET, bool SUMS>
+template <int TXN, bool RAGGED, int NSET>
 __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
     constexpr int TYN = 32 / TXN;
     constexpr int PW = 4 * TXN, PH = 2 * TYN;
@@ -157,8 +150,8 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
 
     // statistics rows: exactly wino24_kernel's scheme (per-workgroup rows on the persistent grid, registers across the tiles
     // of one output slab, one fold per slab) -- the two kernels are interchangeable for bn_finalize
-    float* const rows_base = SUMS ? p.bn_sums : p.stats;                  // SUMS: (sum g, sum g y) rows of five kinds, else (sum, sum of squares)
-    constexpr int NKR = SUMS ? 5 : 2;
+    float* const rows_base = p.stats;
+    constexpr int NKR = 2;
     const bool per_wg_rows = rows_base != nullptr && gridDim.x < (unsigned)p.nblk;
     if (per_wg_rows)
         for (int k = threadIdx.x >> 6; k < NKR; k += 4)
@@ -199,12 +192,6 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
             } else {
                 rslab = cur_tn; racc = t;
                 flush_row();
-            }
-        } else if (SUMS && !per_wg_rows) {      // threads 128 .. 255, one row per tile: its kinds 2, 3 and 4 are zeros
-            const int idx = threadIdx.x - 128, c = idx & 63;
-            if (cur_tn * 64 + c < p.Np) {
-                rows_base[((size_t)cur_tm * NKR + 2 + (idx >> 6)) * p.Np + cur_tn * 64 + c] = 0.f;
-                if (idx < 64) rows_base[((size_t)cur_tm * NKR + 4) * p.Np + cur_tn * 64 + c] = 0.f;
             }
         }
         __syncthreads();
@@ -309,23 +296,6 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
 
         // ---- epilogue: wino24_kernel's.  Y = A4^T M A6: A6^T in-lane (j -> q), A4^T across the four waves through LDS ----------
         const int tl = tid >> 3, ng = tid & 7;                                // reader: tile, 4-channel group
-        // SUMS: the saved activation at this thread's output positions, one output-channel half (8 x 16 bytes) at a time: the first half
-        // is requested here and lands under the accumulator exchange, the second under the read-back of the first
-        float4 yv[SUMS ? 8 : 1];
-        auto load_y = [&](int nt) {
-            if constexpr (SUMS) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int pp = 0; pp < 2; ++pp) {
-                        const int yy = y0 + 2 * (tl / TXN) + pp, xx = x0 + 4 * (tl % TXN) + q;
-                        const bool ok = !RAGGED || (yy < p.H && xx < p.W);
-                        yv[q * 2 + pp] = ok ? *reinterpret_cast<const float4*>(p.bn_y + (((size_t)b * p.H + yy) * p.W + xx) * p.Np + n0 + 32 * nt + 4 * ng)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-            }
-        };
-        load_y(0);
         float* const ex = reinterpret_cast<float*>(smem);                                // reader: tile, 4-channel group
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();
         const bool plain = !p.relu && !p.bias && !p.stats;
@@ -374,12 +344,7 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
                     const int yy = y0 + 2 * oty + pp, xx = x0 + 4 * otx + q;
                     if (!RAGGED || (yy < p.H && xx < p.W)) {
                         *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = o;
-                        if constexpr (SUMS) {
-                            const float4 yq = yv[q * 2 + pp];
-                            st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
-                            st2[nt][0] = fmaf(o.x, yq.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, yq.y, st2[nt][1]);
-                            st2[nt][2] = fmaf(o.z, yq.z, st2[nt][2]); st2[nt][3] = fmaf(o.w, yq.w, st2[nt][3]);
-                        } else if (!plain) {
+                        if (!plain) {
                             st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
                             st2[nt][0] = fmaf(o.x, o.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, o.y, st2[nt][1]);
                             st2[nt][2] = fmaf(o.z, o.z, st2[nt][2]); st2[nt][3] = fmaf(o.w, o.w, st2[nt][3]);
@@ -387,7 +352,6 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
                     }
                 }
             }
-            if constexpr (SUMS) { if (nt == 0) load_y(1); }
         }
         if (rows_base) { cur_tn = tn; cur_tm = tm; }
         __syncthreads();                                                   // exchange / statistics blocks are free again
@@ -405,7 +369,7 @@ __global__ void __launch_bounds__(256, 1) wino24g_kernel(const WinoParams p) {
 // input alternates between two register sets (no copies), the filter sets are refilled two chunks ahead behind their MFMAs and the
 // stream runs on into the next tile.  Same V formulas, same MFMA chains, same epilogue: bit-identical to wino24_kernel.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TXN, bool RAGGED, bool SUMS, bool CLS = false>      // CLS: bias from a border-class table (WinoParams::bias_classes)
+template <int TXN, bool RAGGED, bool CLS = false>      // CLS: bias from a border-class table (WinoParams::bias_classes)
 __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
     constexpr int TYN = 32 / TXN;
     constexpr int PW = 4 * TXN, PH = 2 * TYN;
@@ -419,8 +383,8 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
     static_assert(2 * IN_SLOTS <= LDS && LDS * 16 <= 160 * 1024, "LDS budget");
     __shared__ uint4 smem[LDS];
 
-    float* const rows_base = SUMS ? p.bn_sums : p.stats;                  // SUMS: (sum g, sum g y) rows of five kinds, else (sum, sum of squares)
-    constexpr int NKR = SUMS ? 5 : 2;
+    float* const rows_base = p.stats;
+    constexpr int NKR = 2;
     const bool per_wg_rows = rows_base != nullptr && gridDim.x < (unsigned)p.nblk;
     if (per_wg_rows)
         for (int k = threadIdx.x >> 6; k < NKR; k += 4)
@@ -461,12 +425,6 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
             } else {
                 rslab = cur_tn; racc = t;
                 flush_row();
-            }
-        } else if (SUMS && !per_wg_rows) {      // threads 128 .. 255, one row per tile: its kinds 2, 3 and 4 are zeros
-            const int idx = threadIdx.x - 128, c = idx & 63;
-            if (cur_tn * 64 + c < p.Np) {
-                rows_base[((size_t)cur_tm * NKR + 2 + (idx >> 6)) * p.Np + cur_tn * 64 + c] = 0.f;
-                if (idx < 64) rows_base[((size_t)cur_tm * NKR + 4) * p.Np + cur_tn * 64 + c] = 0.f;
             }
         }
         __syncthreads();
@@ -638,23 +596,6 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
 
         // ---- epilogue: wino24_kernel's -----------------------------------------------------------------------------------------
         const int tl = tid >> 3, ng = tid & 7;                                // reader: tile, 4-channel group
-        // SUMS: the saved activation at this thread's output positions, one output-channel half (8 x 16 bytes) at a time: the first half
-        // is requested here and lands under the accumulator exchange, the second under the read-back of the first
-        float4 yv[SUMS ? 8 : 1];
-        auto load_y = [&](int nt) {
-            if constexpr (SUMS) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int pp = 0; pp < 2; ++pp) {
-                        const int yy = y0 + 2 * (tl / TXN) + pp, xx = x0 + 4 * (tl % TXN) + q;
-                        const bool ok = !RAGGED || (yy < p.H && xx < p.W);
-                        yv[q * 2 + pp] = ok ? *reinterpret_cast<const float4*>(p.bn_y + (((size_t)b * p.H + yy) * p.W + xx) * p.Np + n0 + 32 * nt + 4 * ng)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-            }
-        };
-        load_y(0);
         float* const ex = reinterpret_cast<float*>(smem);
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();
         const bool plain = !p.relu && !p.bias && !p.stats;
@@ -713,12 +654,7 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
                     }
                     if (!RAGGED || (yy < p.H && xx < p.W)) {
                         *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = o;
-                        if constexpr (SUMS) {
-                            const float4 yq = yv[q * 2 + pp];
-                            st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
-                            st2[nt][0] = fmaf(o.x, yq.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, yq.y, st2[nt][1]);
-                            st2[nt][2] = fmaf(o.z, yq.z, st2[nt][2]); st2[nt][3] = fmaf(o.w, yq.w, st2[nt][3]);
-                        } else if (!plain) {
+                        if (!plain) {
                             st1[nt][0] += o.x; st1[nt][1] += o.y; st1[nt][2] += o.z; st1[nt][3] += o.w;
                             st2[nt][0] = fmaf(o.x, o.x, st2[nt][0]); st2[nt][1] = fmaf(o.y, o.y, st2[nt][1]);
                             st2[nt][2] = fmaf(o.z, o.z, st2[nt][2]); st2[nt][3] = fmaf(o.w, o.w, st2[nt][3]);
@@ -726,7 +662,6 @@ __global__ void __launch_bounds__(256, 1) wino24h_kernel(const WinoParams p) {
                     }
                 }
             }
-            if constexpr (SUMS) { if (nt == 0) load_y(1); }
         }
         if (rows_base) { cur_tn = tn; cur_tm = tm; }
         __syncthreads();                                                   // exchange / statistics blocks are free again
@@ -1027,10 +962,8 @@ int clamd_winograd24_transform_input(const float* x, int x_ldc, const float* sca
 }
 
 int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const float* bias, float* y, int y_ldc,
-                                 float* stats, int stat_rows, const float* bn_y, float* bn_sums, int B, int H, int W, int Cin_p,
+                                 float* stats, int stat_rows, int B, int H, int W, int Cin_p,
                                  int Cout_p, int relu, const clamd_tuning* tune, void* stream) {
-    if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("conv3x3_winograd24_pre: bn_y and bn_sums go together");
-    if (bn_sums && (stats || bias || relu)) return clamd_fail("conv3x3_winograd24_pre: bn_y / bn_sums belong to a plain data-gradient launch (no bias, ReLU or statistics)");
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("conv3x3_winograd24_pre: empty problem");
     if ((H & 1) || (W & 3)) return clamd_fail("conv3x3_winograd24_pre: H must be even and W a multiple of 4 (2x4 output tiles)");
     if (Cin_p % 32 || Cin_p < 64 || Cout_p % 64 || y_ldc % 8) return clamd_fail("conv3x3_winograd24_pre: needs Cin_p % 32 == 0, Cin_p >= 64, Cout_p % 64 == 0");
@@ -1040,11 +973,10 @@ int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const floa
     if (tiles * ntn > 0x7fffffff) return clamd_fail("conv3x3_winograd24_pre: grid out of range");
     if ((unsigned long long)tiles * (Cin_p / 8) * 24 * 1024 >= (1ull << 32) || (long long)24 * Cout_p * Cin_p * 4 >= (1ll << 31))
         return clamd_fail("conv3x3_winograd24_pre: transformed input exceeds 2^32 bytes or filter 2^31 bytes");
-    if ((stats || bn_sums) && stat_rows != clamd_winograd24_stat_rows(B, H, W, Cout_p, tn))
+    if (stats && stat_rows != clamd_winograd24_stat_rows(B, H, W, Cout_p, tn))
         return clamd_fail("conv3x3_winograd24_pre: stat_rows does not match clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD24, ...)");
     if (relu & ~1) return clamd_fail("conv3x3_winograd24_pre: relu must be 0 or 1 (no border-class bias here)");
     WinoParams p{v, 0, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 1, 0};
-    p.bn_y = bn_y; p.bn_sums = bn_sums;
     p.band = wino_band(tiles, ntn, 3.0 * B * H * W * Cin_p, 24.0 * Cin_p * Cout_p, tn.wino_band);
     p.nblk = (int)(tiles * ntn);
     const unsigned grid = tn.wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_usable_cus(tn)) : (unsigned)p.nblk;
@@ -1052,11 +984,7 @@ int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const floa
     w24g_tile(W, ph, pw);
     const bool ragged = (H % ph) != 0 || (W % pw) != 0;
     hipStream_t s = (hipStream_t)stream;
-#define W24G_LAUNCH(TXN_, RG_)                                                                                         \
-    do {                                                                                                               \
-        if (bn_sums) hipLaunchKernelGGL((wino24g_kernel<TXN_, RG_, 2, true>), dim3(grid), dim3(256), 0, s, p);         \
-        else hipLaunchKernelGGL((wino24g_kernel<TXN_, RG_, 2, false>), dim3(grid), dim3(256), 0, s, p);                \
-    } while (0)
+#define W24G_LAUNCH(TXN_, RG_) hipLaunchKernelGGL((wino24g_kernel<TXN_, RG_, 2>), dim3(grid), dim3(256), 0, s, p)
     if (pw == 32) { if (ragged) W24G_LAUNCH(8, true); else W24G_LAUNCH(8, false); }
     else { if (ragged) W24G_LAUNCH(4, true); else W24G_LAUNCH(4, false); }
 #undef W24G_LAUNCH
@@ -1064,10 +992,8 @@ int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const floa
 }
 
 int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
-                                            float* stats, int stat_rows, const float* bn_y, float* bn_sums, int B, int H, int W,
+                                            float* stats, int stat_rows, int B, int H, int W,
                                             int Cin_p, int Cout_p, int relu, const clamd_tuning* tune, void* stream) {
-    if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("conv3x3_winograd24_direct_filters: bn_y and bn_sums go together");
-    if (bn_sums && (stats || bias || relu)) return clamd_fail("conv3x3_winograd24_direct_filters: bn_y / bn_sums belong to a plain data-gradient launch (no bias, ReLU or statistics)");
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("conv3x3_winograd24_direct_filters: empty problem");
     if ((H & 1) || (W & 3)) return clamd_fail("conv3x3_winograd24_direct_filters: H must be even and W a multiple of 4 (2x4 output tiles)");
     if (Cin_p % 32 || Cout_p % 64 || x_ldc % 8 || y_ldc % 8) return clamd_fail("conv3x3_winograd24_direct_filters: needs Cin_p % 32 == 0, Cout_p % 64 == 0");
@@ -1077,14 +1003,12 @@ int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const flo
     const clamd_tuning& tn = clamd_tune(tune);
     const long long tiles = w24g_tiles(B, H, W), ntn = Cout_p / 64;
     if (tiles * ntn > 0x7fffffff) return clamd_fail("conv3x3_winograd24_direct_filters: grid out of range");
-    if ((stats || bn_sums) && stat_rows != clamd_winograd24_stat_rows(B, H, W, Cout_p, tn))
+    if (stats && stat_rows != clamd_winograd24_stat_rows(B, H, W, Cout_p, tn))
         return clamd_fail("conv3x3_winograd24_direct_filters: stat_rows does not match clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD24, ...)");
     if ((relu & ~3) || ((relu & CLAMD_BIAS_BORDER_CLASSES) && !bias))
         return clamd_fail("conv3x3_winograd24_direct_filters: bad relu flags (bit 1 needs the [9][Cout_p] bias table)");
     WinoParams p{x, x_ldc, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu & 1, 1, 0};
-    p.bn_y = bn_y; p.bn_sums = bn_sums;
     p.bias_classes = (relu & CLAMD_BIAS_BORDER_CLASSES) ? 1 : 0;
-    if (p.bias_classes && bn_sums) return clamd_fail("conv3x3_winograd24_direct_filters: the border-class bias (forward) and bn_sums (data gradient) exclude each other");
     p.band = wino_band(tiles, ntn, (double)B * H * W * Cin_p, 24.0 * Cin_p * Cout_p, tn.wino_band);
     p.nblk = (int)(tiles * ntn);
     const unsigned grid = tn.wino_persist ? (unsigned)std::min<long long>(p.nblk, clamd_usable_cus(tn)) : (unsigned)p.nblk;
@@ -1094,8 +1018,7 @@ int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const flo
     hipStream_t s = (hipStream_t)stream;
 #define W24H_LAUNCH(TXN_, RG_)                                                                                         \
     do {                                                                                                               \
-        if (bn_sums) hipLaunchKernelGGL((wino24h_kernel<TXN_, RG_, true>), dim3(grid), dim3(256), 0, s, p);            \
-        else if (p.bias_classes) hipLaunchKernelGGL((wino24h_kernel<TXN_, RG_, false, true>), dim3(grid), dim3(256), 0, s, p); \
+        if (p.bias_classes) hipLaunchKernelGGL((wino24h_kernel<TXN_, RG_, true>), dim3(grid), dim3(256), 0, s, p);     \
         else hipLaunchKernelGGL((wino24h_kernel<TXN_, RG_, false>), dim3(grid), dim3(256), 0, s, p);                   \
     } while (0)
     if (pw == 32) { if (ragged) W24H_LAUNCH(8, true); else W24H_LAUNCH(8, false); }

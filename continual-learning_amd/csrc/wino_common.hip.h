@@ -14,10 +14,6 @@ struct WinoParams {
     int B, H, W, Kp, Np, relu;
     int band;                    // output-channel slabs per band of the block order (see clamd_conv3x3_winograd)
     int nblk;                    // (pixel tile, slab) pairs; the grid is min(nblk, CUs) persistent workgroups
-    // wino24g.hip, data-gradient launches only: this launch writes the gradient g_u w.r.t. a BatchNorm output; bn_y = that unit's saved
-    // post-ReLU activation [B,H,W,Np] (dense), bn_sums = partial rows [row][5][Np] of the five sums of bn_bwd_reduce_kernel
-    const float* bn_y = nullptr;
-    float* bn_sums = nullptr;
     // forward launches behind a folded BatchNorm (clamd_bn_fold_bias): bias is a [9][Np] table indexed by the border class of the output pixel
     int bias_classes = 0;
 };

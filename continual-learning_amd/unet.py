@@ -65,35 +65,10 @@ FOLD_FILTERS_MAX_CHANNELS = int(os.environ.get('CLAMD_FOLD_FILTERS_MAX_CHANNELS'
 # max(s x + t) = s min(x) + t), and the two readers take scale / shift in their filters and bias tables.  The pooled bn_apply pass of enc1
 # (603 MB, the largest elementwise pass of the step) becomes a 335 MB pooling pass.
 FOLD_POOLED = os.environ.get('CLAMD_FOLD_POOLED', '1') != '0'
-# fp32 path: ConvTranspose2d forward / data gradient as register-blocked GEMMs with operands loaded straight into the MFMA operand
-# registers (csrc/pw_direct.hip) instead of the LDS-staged 256-pixel x 64-channel tiles of igemm_kernel.
-# BUILT, MEASURED, OFF BY DEFAULT.  Alone the kernels are faster (tools/convt_direct_ab.py: forward 0.67 -> 0.64 ms, data gradient
-# 0.64 -> 0.57 ms per step), inside the step they are slower (tools/step_ab.py fp32 CONVT_DIRECT 0 fwd dgrad 1: 21.44 / 21.50 / 21.84 /
-# 21.74 ms): one wave per SIMD with all 512 registers leaves no room on a CU for the other stream's HBM-bound passes, which the
-# two-workgroups-per-CU igemm_kernel (fewer registers per wave) does -- the same lesson as the half-batch pipeline.
-CONVT_DIRECT = os.environ.get('CLAMD_CONVT_DIRECT', '0')          # '0' | '1' (both) | 'fwd' | 'dgrad'
-# fp32 path: the five BatchNorm-backward sums of the first unit of a stage taken in the epilogue of the Winograd data-gradient launch that
-# produces its gradient (wino24g.hip: pre-transformed and direct-filter kernels) instead of the separate bn_bwd_reduce pass.
-# BUILT, MEASURED, OFF BY DEFAULT: tools/step_ab.py fp32 FUSE_WINO_SUMS False True -> 21.19 vs 21.22 ms per step.  The 40 running sums
-# live across the K loop of kernels that already use all 512 registers (45 / 77 registers spill around the loop, none inside it), and the
-# reduce passes they replace mostly ran beside a weight-gradient kernel of the second stream anyway.
-FUSE_WINO_SUMS = os.environ.get('CLAMD_FUSE_WINO_SUMS', '0') != '0'
 # fp32 path, pre-transformed weight gradients: the gradient-side transform (HBM-bound) on a THIRD stream, so that it runs beside the
 # weight-gradient GEMM of the unit before (which leaves 188 registers per SIMD free) instead of in front of its own GEMM on the second
 # stream, and that GEMM can start the moment the data gradient of its unit has finished.
 WGRAD_XFORM_STREAM = os.environ.get('CLAMD_WGRAD_XFORM_STREAM', '1') != '0'
-# Forward pass in two half-batches where a half still fills the chip (levels 0-2 at config 2): conv -> BatchNorm statistics ->
-# apply -> conv is a chain through the whole batch, so the HBM-bound passes (bn_apply, the input transforms) have nothing to run
-# beside -- unless the batch is cut in two: the second half's apply / transform runs on the second stream UNDER the first half's
-# next convolution (statistics rows of the two launches are concatenated; BatchNorm still normalises over the whole batch).
-# Same kernels, pointer offsets only; results differ from the unsplit run only in the (fixed) order the statistics rows are summed.
-# BUILT, MEASURED, OFF BY DEFAULT (tools/step_ab.py <dtype> HALF_BATCH False True, interleaved in one process): fp32 21.40 -> 21.67,
-# bf16 6.65 -> 6.93, bf16x3 14.39 -> 14.63 ms per step.  The forward convolution kernels hold a whole CU (one wave per SIMD with
-# 447-512 registers, 120-147 KB of LDS): unlike beside the weight-gradient kernels of the backward pass (88-168 registers free) there
-# is no room for a BatchNorm-pass wave on a CU that runs one, so the "overlapped" pass only takes CUs away from the convolution, and
-# every split convolution pays a second launch ramp and tile tail.
-HALF_BATCH = os.environ.get('CLAMD_HALF_BATCH', '0') != '0'
-HALF_BATCH_MIN_PIXELS = int(os.environ.get('CLAMD_HALF_BATCH_MIN_PIXELS', '32768'))     # pixels of one half: 8 images at 64 x 64
 # Weight-gradient kernels (and the bias-gradient channel sums of the ConvTranspose / head layers) go to a second HIP stream:
 # they are off the critical chain of the backward pass (dgrad -> BatchNorm-backward reduce / finalize / apply -> dgrad ...),
 # and the HBM-bound BatchNorm passes of the NEXT unit fit beside a weight-gradient workgroup on the same CU (one wave per
@@ -457,7 +432,6 @@ class _Engine:
             u.vx = torch.empty(lib.clamd_winograd24_input_elems(B, u.h, u.w_, u.cin_p), dtype=torch.float32, device=dev) if u.pre_f else None
             # 64 input channels (8 chunks per tile): the in-kernel-transform kernel with the filters loaded straight into the operand
             # registers (wino24h_kernel) is 4-6 % faster there and 1-4 % slower on longer K loops (tools/wino24h_ab.py)
-            u.split = HALF_BATCH and B % 2 == 0 and (B // 2) * u.h * u.w_ >= HALF_BATCH_MIN_PIXELS
             u.direct_f = NARROW_DIRECT and u.w24 and not u.pre_f and u.cin_p == 64 and u.cout_p % 64 == 0
             u.direct_d = NARROW_DIRECT and u.w24d and not u.pre_d and not first_of_net and u.cout_p == 64 and u.cin_p % 64 == 0
             ntap = 1 if u.im2col else ((24 if u.w24 else 16) if u.wino else 9)   # Winograd: [Cin_p/8][16|24][Cout_p][8] transformed filters
@@ -527,13 +501,6 @@ class _Engine:
                 tail.y_slice = up[..., tail.cout_p:]               # second half of the concat buffer one level up
                 tail.gy_slice = self.gcat[level - 1][..., tail.cout_p:]
                 tail.y_ldc = up.shape[-1]
-                # tools/convt_direct_ab.py: the data gradient gains on every shape (0.64 -> 0.57 ms per step), the forward only where
-                # K = Cin is long (1024 / 512 channels: 0.73 -> 0.77, 0.63 -> 0.81 of the pipe); with 256 / 128 input channels the
-                # scattered pixel-shuffle stores of the short tiles cost what the loop gains
-                ok = self.dcode == _lib.F32 and tail.cin_p % 128 == 0 and tail.cout_p % 32 == 0 and tail.consumer is None
-                cd_ = str(CONVT_DIRECT).lower()
-                tail.direct = ok and cd_ in ('1', 'true', 'dgrad')
-                tail.direct_f = ok and cd_ in ('1', 'true', 'fwd') and tail.cin_p >= 512
             else:
                 tail.cout_p = self.Kp
                 tail.wf = torch.zeros(tail.cout_p * tail.cin_p, dtype=T, device=dev)
@@ -556,7 +523,7 @@ class _Engine:
             b.fold_a, a.fold_a, a.fold_on, b.fold_on, a.apply_in_filters, b.apply_in_filters = None, None, False, False, False, False
             if (FOLD_BN_INTO_FILTERS
                     and not a.apply_folded and not b.pre_f and a.pooled is None and b.xin is a.out and len(b.cin_segs) == 1
-                    and not a.split and not b.split and min(b.h, b.w_) >= 2 and b.cin_p <= FOLD_FILTERS_MAX_CHANNELS):
+                    and min(b.h, b.w_) >= 2 and b.cin_p <= FOLD_FILTERS_MAX_CHANNELS):
                 b.fold_a = a      # one direction only: a cycle between units would keep the engine's buffers alive until the garbage collector runs
                 b.cb = torch.zeros(9, b.cout_p, dtype=torch.float32, device=dev)
         for u in convs:
@@ -567,9 +534,9 @@ class _Engine:
             b, nxt = self.stages[k]['convs'][1], self.stages[k + 1]['convs'][0]
             dec = next((st_['convs'][0] for st_ in self.stages if st_['kind'] == 'dec' and st_['convs'][0].xin is self.cat[k]), None)
             ok = (FOLD_POOLED and FOLD_BN_INTO_FILTERS and self.dcode == _lib.F32 and dec is not None and nxt.xin is self.pool[k]
-                  and all(c.w24 and not c.pre_f and c.fold_a is None and not c.split and c.cin_p <= FOLD_FILTERS_MAX_CHANNELS and min(c.h, c.w_) >= 2
+                  and all(c.w24 and not c.pre_f and c.fold_a is None and c.cin_p <= FOLD_FILTERS_MAX_CHANNELS and min(c.h, c.w_) >= 2
                           and all(lg == ph for lg, ph in c.cin_segs) for c in (nxt, dec))
-                  and b.w24 and not b.pre_f and not b.split and b.cout == b.cout_p and len(dec.cin_segs) == 2
+                  and b.w24 and not b.pre_f and b.cout == b.cout_p and len(dec.cin_segs) == 2
                   and dec.cin_segs[0] == (b.cout, b.cout_p))
             if not ok:
                 continue
@@ -590,20 +557,13 @@ class _Engine:
             # ... and the 1x1 head behind the last BatchNorm: pointwise, no border classes -- in every compute dtype
             t.fold_b = None
             b = st['convs'][1]
-            if (FOLD_BN_INTO_FILTERS and t.kind == 'head' and not b.split and b.pooled is None and t.x is b.out
+            if (FOLD_BN_INTO_FILTERS and t.kind == 'head' and b.pooled is None and t.x is b.out
                     and b.cout_p <= FOLD_FILTERS_MAX_CHANNELS):
                 t.fold_b = b
                 b.apply_in_filters = True
                 t.bias_fold = torch.zeros(t.cout_p, dtype=torch.float32, device=dev)
         nfw = max([lib.clamd_bn_fold_wgrad_workspace_bytes(B, u.cout_p) // 4 for u in convs if u.fold_a is not None] + [0])
         self.fold_ws = torch.empty(nfw, dtype=torch.float32, device=dev) if nfw else None
-        for st in self.stages:      # half-batch pipeline: a's second-half apply may run under b's first-half convolution; across stages
-            a, b = st['convs']     # only along the encoder (b.pooled feeds the next stage's first convolution directly)
-            a.pipe_next = a.split and b.split
-            b.pipe_next = False
-        for k in range(3):
-            b, nxt = self.stages[k]['convs'][1], self.stages[k + 1]['convs'][0]
-            b.pipe_next = b.split and nxt.split and nxt.xin is b.pooled
         for s in self.stages:
             t = s.get('tail')
             if t is not None and t.consumer is not None:
@@ -667,27 +627,22 @@ class _Engine:
                 u.fold_a.apply_in_filters = u.fold_on      # the producer's bn_apply pass is skipped
         for u in self.convs:
             u.gz_nrows = 0
-            Bl = B // 2 if u.split else B          # images per forward launch (half-batch pipeline: two launches, rows concatenated)
             if u.im2col:
-                r = rows(_lib.OP_CONV1X1, Bl, u.h, u.w_, u.cin_p, u.cout_p, dc)
+                r = rows(_lib.OP_CONV1X1, B, u.h, u.w_, u.cin_p, u.cout_p, dc)
             elif u.wino:
-                r = rows(_lib.OP_CONV3X3_WINOGRAD24 if u.w24 else _lib.OP_CONV3X3_WINOGRAD, Bl, u.h, u.w_, u.cin_p, u.cout_p, dc, tuning=tn)
+                r = rows(_lib.OP_CONV3X3_WINOGRAD24 if u.w24 else _lib.OP_CONV3X3_WINOGRAD, B, u.h, u.w_, u.cin_p, u.cout_p, dc, tuning=tn)
             else:
-                r = rows(_lib.OP_CONV3X3, Bl, u.h, u.w_, u.cin_p, u.cout_p, dc, tuning=tn)
+                r = rows(_lib.OP_CONV3X3, B, u.h, u.w_, u.cin_p, u.cout_p, dc, tuning=tn)
             u.stat_rows_launch = r
-            u.stat_rows = 2 * r if u.split else r
+            u.stat_rows = r
             if u.fused_reduce:
                 src = getattr(u, 'sum_src', None)
                 if src is None:       # the 3x3 data-gradient launch of the next conv of this stage (K = its output channels)
                     b = next(c for c in self.convs if c.consumer is u)
-                    if b.wino:      # wino24g.hip: the two gradient-dependent sums in the statistics registers of the data-gradient launch
-                        u.sum_rows = rows(_lib.OP_CONV3X3_WINOGRAD24, B, b.h, b.w_, b.cout_p, b.cin_p, dc, tuning=tn)
+                    u.sum_rows = rows(_lib.OP_CONV3X3, B, b.h, b.w_, b.cout_p, b.cin_p, dc, fused_bn=True, tuning=tn)
+                    # the persistent bf16 kernel takes sum g and sum g y only: the conv-bias gradient then comes from the apply pass
+                    if _lib.load().clamd_conv3x3_bn_sums(B, b.h, b.w_, b.cout_p, b.cin_p, dc, tune_ptr(tn)) == 2:
                         u.gz_nrows = _lib.load().clamd_bn_bwd_apply_sums_rows(B, u.h, u.w_, u.cout_p)
-                    else:
-                        u.sum_rows = rows(_lib.OP_CONV3X3, B, b.h, b.w_, b.cout_p, b.cin_p, dc, fused_bn=True, tuning=tn)
-                        # the persistent bf16 kernel takes sum g and sum g y only: the conv-bias gradient then comes from the apply pass
-                        if _lib.load().clamd_conv3x3_bn_sums(B, b.h, b.w_, b.cout_p, b.cin_p, dc, tune_ptr(tn)) == 2:
-                            u.gz_nrows = _lib.load().clamd_bn_bwd_apply_sums_rows(B, u.h, u.w_, u.cout_p)
                 elif src.kind == 'head':
                     u.sum_rows = rows(_lib.OP_CONV1X1, B, u.h, u.w_, src.cout_p, src.cin_p, dc, fused_bn=True)
                 else:                 # ConvTranspose2d data gradient: the launch runs on the convT INPUT grid (= this unit's)
@@ -804,47 +759,16 @@ class _Engine:
         else:
             call('clamd_nchw_to_nhwc', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
                  self.x_in.shape[-1], 1.0, dc, s)
-        # two streams only outside the per-launch timing mode; the split itself is structural (statistics rows) and always applies
-        s2 = self.wg_stream if (self.wg_stream is not None and KERNEL_TIMING is None) else None
-        cur = torch.cuda.current_stream()
-        defer = None                      # the producer's second-half apply, waiting for a convolution to run under
         for st in self.stages:
             for u in st['convs']:
-                if not u.split:
-                    self._fwd_pre(u, s, None)
-                    self._fwd_fold(u, s)
-                    self._fwd_conv(u, training, s, None)
-                    self._fwd_finalize(u, training, s)
-                    self._fwd_post(u, s, None)
-                    continue
-                self._fwd_pre(u, s, 0)
-                if s2 is not None:
-                    ev_a = torch.cuda.Event(); ev_a.record(cur)
-                    s2.wait_event(ev_a)                       # not before the first half's convolution is about to start
-                    sp2 = s2.cuda_stream
-                    if defer is not None:
-                        defer(sp2)
-                    self._fwd_pre(u, sp2, 1)
-                    ev_b = torch.cuda.Event(); ev_b.record(s2)
-                    self._fwd_conv(u, training, s, 0)
-                    cur.wait_event(ev_b)
-                else:
-                    if defer is not None:
-                        defer(s)
-                    self._fwd_pre(u, s, 1)
-                    self._fwd_conv(u, training, s, 0)
-                defer = None
-                self._fwd_conv(u, training, s, 1)
+                self._fwd_pre(u, s)
+                self._fwd_fold(u, s)
+                self._fwd_conv(u, training, s)
                 self._fwd_finalize(u, training, s)
-                self._fwd_post(u, s, 0)
-                if u.pipe_next:
-                    defer = (lambda sp, u=u: self._fwd_post(u, sp, 1))
-                else:
-                    self._fwd_post(u, s, 1)
+                self._fwd_post(u, s)
             t = st.get('tail')
             if t is None:
-                continue               # encoder: the pooled output feeds the next stage's first convolution (defer may be pending)
-            assert defer is None
+                continue               # encoder: the pooled output feeds the next stage's first convolution
             self._join_pack_late()
             h, w = H >> t.level, W >> t.level
             tx, tx_ldc, tbias = t.x, t.x.shape[-1], t.bias_p
@@ -853,10 +777,7 @@ class _Engine:
                 call('clamd_bn_fold_pack', 0, ptr(ft.dev_table), len(ft.jobs), ft.nblocks, dc, ptr(t.w), 1, ptr(fb.vec[1]), ptr(t.b),
                      ptr(t.bias_fold), t.cout, t.cin, t.cout_p, s)
                 tx, tx_ldc, tbias = fb.y, fb.cout_p, t.bias_fold
-            if t.kind == 'convT' and t.direct_f:
-                call('clamd_convT2x2_fwd_direct', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(t.y_slice), t.y_ldc,
-                     B, h, w, t.cin_p, t.cout_p, s)
-            elif t.kind == 'convT':
+            if t.kind == 'convT':
                 call('clamd_convT2x2_fwd', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(t.y_slice), t.y_ldc,
                      B, h, w, t.cin_p, t.cout_p, dc, s)
             elif predict and t.cout_p <= 64:      # arg-max fused into the head's epilogue: the logits never reach HBM
@@ -903,26 +824,16 @@ class _Engine:
         output activation once each, filters (or their gradient) once."""
         return self.esize * (self.B * u.h * u.w_ * (u.cin + u.cout) + 9 * u.cin * u.cout)
 
-    def _hv(self, t, hf):
-        """Half `hf` (0 / 1) of a batch-major activation tensor, or the whole tensor (hf None)."""
-        if hf is None or t is None:
-            return t
-        hb = self.B // 2
-        return t[hf * hb:(hf + 1) * hb]
-
-    def _fwd_pre(self, u, s, hf):
-        """Input transform of a pre-transformed convolution (wino24g.hip) on the whole batch or one half of it."""
+    def _fwd_pre(self, u, s):
+        """Input transform of a pre-transformed convolution (wino24g.hip)."""
         if not u.pre_f:
             return
-        Bl = self.B if hf is None else self.B // 2
         # the BatchNorm of the unit in front folded into the transform where nothing else reads its output (u.fold_src)
         f = u.fold_src
         xsrc, xldc, fs, fh = (f.y, f.cout_p, f.vec[0], f.vec[1]) if f is not None else (u.xin, u.xin_ldc, None, None)
-        n = u.vx.numel() // 2
-        vx = u.vx if hf is None else u.vx[hf * n:(hf + 1) * n]              # tile blocks are image-major
         _TIMED_UNIT[:] = [u.name + ' fwd', self.executed_fraction(u, 'fwd')]
-        _timed('wino_transform', 0.0, 16 * Bl * u.h * u.w_ * u.cin_p,        # reads the activation once, writes 3x its size
-               'clamd_winograd24_transform_input', ptr(self._hv(xsrc, hf)), xldc, ptr(fs), ptr(fh), ptr(vx), Bl, u.h, u.w_, u.cin_p, s)
+        _timed('wino_transform', 0.0, 16 * self.B * u.h * u.w_ * u.cin_p,        # reads the activation once, writes 3x its size
+               'clamd_winograd24_transform_input', ptr(xsrc), xldc, ptr(fs), ptr(fh), ptr(u.vx), self.B, u.h, u.w_, u.cin_p, s)
 
     def _fwd_fold(self, u, s):
         """Forward filters of a fold candidate (bnfold.hip): packed here, behind the producer's bn_finalize -- with its scale and the
@@ -963,21 +874,18 @@ class _Engine:
             torch.cuda.current_stream().wait_event(self._ev_pack_late)
             self._ev_pack_late = None
 
-    def _fwd_conv(self, u, training, s, hf):
-        """conv3x3 + bias + ReLU (+ BatchNorm statistics rows) of unit u on the whole batch or one half of it."""
+    def _fwd_conv(self, u, training, s):
+        """conv3x3 + bias + ReLU (+ BatchNorm statistics rows) of unit u."""
         dc, tp = self.dcode, tune_ptr(self.tuning)
         if u.pack_late:
             self._join_pack_late()
         elif u is self.convs[min(self.pack_late_at, len(self.convs) - 1)]:
             self._release_pack_late()
-        Bl = self.B if hf is None else self.B // 2
+        Bl = self.B
         _TIMED_UNIT[:] = [u.name + ' fwd', self.executed_fraction(u, 'fwd')]
         rows = u.stat_rows_launch
-        st = None
-        if training:
-            k = rows * 2 * u.cout_p
-            st = u.stats if hf is None else u.stats[hf * k:(hf + 1) * k]
-        xin, y = self._hv(u.xin, hf), self._hv(u.y, hf)
+        st = u.stats if training else None
+        xin, y = u.xin, u.y
         xin_ldc, bias, relu = u.xin_ldc, u.bias_p, 1
         if u.fold_on:      # reads the producer's conv+ReLU output; its BatchNorm lives in the filters and in the bias table
             xin, xin_ldc, bias, relu = u.fold_a.y, u.fold_a.cout_p, u.cb, 3
@@ -999,15 +907,12 @@ class _Engine:
                 torch.cuda.current_stream().wait_stream(self.wg_stream)
                 self._pack_pending = 0
             if u.pre_f:
-                n = u.vx.numel() // 2
-                vx = u.vx if hf is None else u.vx[hf * n:(hf + 1) * n]
-                _timed('igemm_conv3x3', flops, nbytes, 'clamd_conv3x3_winograd24_pre', ptr(vx), ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p,
-                       ptr(st), rows, None, None, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
+                _timed('igemm_conv3x3', flops, nbytes, 'clamd_conv3x3_winograd24_pre', ptr(u.vx), ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p,
+                       ptr(st), rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
             else:
                 name = ('clamd_conv3x3_winograd24_direct_filters' if u.direct_f else 'clamd_conv3x3_winograd24') if u.w24 else 'clamd_conv3x3_winograd'
-                extra = (None, None) if u.direct_f else ()           # bn_y, bn_sums: data-gradient launches only
                 _timed('igemm_conv3x3', flops, nbytes, name, ptr(xin), xin_ldc, ptr(u.wf), ptr(bias), ptr(y), u.y_ldc, ptr(st), rows,
-                       *extra, Bl, u.h, u.w_, u.cin_p, u.cout_p, relu, tp, s)
+                       Bl, u.h, u.w_, u.cin_p, u.cout_p, relu, tp, s)
         else:
             _timed('igemm_conv3x3', flops, nbytes, 'clamd_conv3x3', ptr(xin), xin_ldc, ptr(u.wf), ptr(bias), ptr(y), u.cout_p,
                    ptr(st), None, None, rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, relu, u.m_fastest, dc, tp, s)
@@ -1018,8 +923,8 @@ class _Engine:
              ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), u.cout_p, u.cout, float(self.B * u.h * u.w_), BN_MOMENTUM, BN_EPS,
              ptr(u.nbt) if training else None, s)      # num_batches_tracked += 1 inside the launch (was a torch._foreach_add_ on the critical chain)
 
-    def _fwd_post(self, u, s, hf):
-        """BatchNorm apply (+ max-pool, concat placement) of unit u on the whole batch or one half of it."""
+    def _fwd_post(self, u, s):
+        """BatchNorm apply (+ max-pool, concat placement) of unit u."""
         if u.apply_folded:          # the only reader of the BatchNorm output is the next convolution's input transform
             return
         if u.pool_fold:             # ... or the filters and bias tables of both readers of an encoder block's output: only the pooling is left
@@ -1028,10 +933,8 @@ class _Engine:
         if u.apply_in_filters:      # ... or its filters and bias table (bnfold.hip)
             return
         v = u.vec
-        Bl = self.B if hf is None else self.B // 2
-        pooled = self._hv(u.pooled, hf)
-        call('clamd_bn_apply', ptr(self._hv(u.y, hf)), u.cout_p, ptr(v[0]), ptr(v[1]), ptr(self._hv(u.out, hf)), u.out_ldc,
-             ptr(pooled), u.pooled.shape[-1] if u.pooled is not None else 0, Bl, u.h, u.w_, u.cout_p, self.dcode, s)
+        call('clamd_bn_apply', ptr(u.y), u.cout_p, ptr(v[0]), ptr(v[1]), ptr(u.out), u.out_ldc,
+             ptr(u.pooled), u.pooled.shape[-1] if u.pooled is not None else 0, self.B, u.h, u.w_, u.cout_p, self.dcode, s)
 
     # ------------------------------------------------------------------------------------------ backward
     def _wg_stream_ptr(self):
@@ -1099,13 +1002,9 @@ class _Engine:
                     if fb is not None:      # the weight gradient ran on the un-normalised tensor: dW = scale * dW + shift * (bias gradient)
                         call('clamd_bn_fold_wgrad_pointwise', g[t.keys[1]], ptr(fb.vec[0]), ptr(fb.vec[1]), g[t.keys[0]], t.cout, t.cin, sw)
                 else:
-                    if t.direct:
-                        call('clamd_convT2x2_dgrad_direct', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
-                             B, h, w, t.cin_p, t.cout_p, s)
-                    else:
-                        call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
-                             ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
-                             t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cin_p, t.cout_p, dc, s)
+                    call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
+                         ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
+                         t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cin_p, t.cout_p, dc, s)
                     sw = self._wg_stream_ptr()
                     call('clamd_wgrad', _lib.WGRAD_UP2, ptr(t.x), t.x.shape[-1], ptr(t.gy_slice), t.y_ldc, ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cin_p, t.cout_p, t.cin, t.cout,
@@ -1141,8 +1040,8 @@ class _Engine:
     def _fuse_sums(self, b):
         """Does the data-gradient launch of conv `b` (3x3, K = b.cout_p gradient channels) also reduce the BN-backward sums
         of the unit in front of it?"""
-        if b.wino:                     # Winograd data gradient: only the wino24g.hip kernels have the BatchNorm-sums epilogue
-            return bool(FUSE_WINO_SUMS) and (b.pre_d or b.direct_d)
+        if b.wino:                     # the Winograd data-gradient kernels have no such epilogue (round 4: built with two sums in the statistics
+            return False               # registers, measured 21.06 -> 21.11 ms per step, removed: the reduce passes it replaces run beside a weight gradient)
         if FUSE_BN_SUMS == 'auto':     # persistent bf16 kernel: <= 256 input channels, K-steps in pairs (64 channels)
             return self.dcode == _lib.BF16 and b.cout_p <= 256 and b.cout_p % 64 == 0
         return bool(FUSE_BN_SUMS)
@@ -1191,18 +1090,11 @@ class _Engine:
                 _timed('wino_transform', 0.0, 16 * B * u.h * u.w_ * u.cout_p,      # reads the gradient once, writes 3x its size
                        'clamd_winograd24_transform_input', ptr(u.gz), u.cout_p, None, None, ptr(self.vg), B, u.h, u.w_, u.cout_p, s)
                 _timed('igemm_conv3x3', flops, self._conv_bytes(u),
-                       'clamd_conv3x3_winograd24_pre', ptr(self.vg), ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
-                       u.consumer.sum_rows if u.consumer is not None else 0,
-                       ptr(u.consumer.y) if u.consumer is not None else None, ptr(u.consumer.sums) if u.consumer is not None else None,
+                       'clamd_conv3x3_winograd24_pre', ptr(self.vg), ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
                        B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
             elif u.g_in is not None and u.wino:
-                _timed('igemm_conv3x3', flops, self._conv_bytes(u),
-                       *((('clamd_conv3x3_winograd24_direct_filters', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
-                           u.consumer.sum_rows if u.consumer is not None else 0,
-                           ptr(u.consumer.y) if u.consumer is not None else None, ptr(u.consumer.sums) if u.consumer is not None else None)
-                          if u.direct_d else
-                          ('clamd_conv3x3_winograd24' if u.w24d else 'clamd_conv3x3_winograd', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in),
-                           u.g_in.shape[-1], None, 0))),
+                name = 'clamd_conv3x3_winograd24_direct_filters' if u.direct_d else ('clamd_conv3x3_winograd24' if u.w24d else 'clamd_conv3x3_winograd')
+                _timed('igemm_conv3x3', flops, self._conv_bytes(u), name, ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
                        B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
             elif u.g_in is not None:
                 _timed('igemm_conv3x3', flops, self._conv_bytes(u),

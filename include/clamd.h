@@ -57,17 +57,14 @@ int clamd_bn_bwd_nsums(void);
  *   wino_persist   0|1     one workgroup per tile | persistent tile loop
  *   wino_mt        0|1|2   tile height: per-launch choice | 8 | 16 pixels
  *   bn_reduce_blocks / chsum_blocks   0 (per-launch choice) | n: grid cap of the per-channel reductions
- *   cu_reserve     CUs the persistent grids leave free (for RCCL channel workgroups under data parallelism)
- *   pws_cl         0|1     persistent kernel, bf16: epilogue through a wave-private LDS transposition | a lane owns a pixel and 2 x 8
- *                          consecutive channels per 32-channel block (filter fragment as the MFMA row operand): direct 16-byte stores */
+ *   cu_reserve     CUs the persistent grids leave free (for RCCL channel workgroups under data parallelism) */
 typedef struct clamd_tuning {
     int igemm_pws, igemm_ws, igemm_variant, pws_wres;
     int wgrad_ws, wgrad_dma, wgrad_xcd, wgrad_blocks, wgrad_tw16;
     int wino_band, wino_persist, wino_mt;
     int bn_reduce_blocks, chsum_blocks;
     int cu_reserve;
-    int pws_cl;
-    int reserved[8];
+    int reserved[9];
 } clamd_tuning;
 int clamd_sizeof_tuning(void);
 void clamd_tuning_init(clamd_tuning* t);
@@ -103,9 +100,9 @@ int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* b
                   float* stats, const void* bn_y, float* bn_sums, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p,
                   int relu, int m_fastest, int dtype, const clamd_tuning* tune, void* stream);
 int clamd_conv3x3_border_bias_ok(int B, int H, int W, int Cin_p, int Cout_p, int dtype, const clamd_tuning* tune);
-/* How many of the five sums a clamd_conv3x3 launch with bn_y / bn_sums takes: 5, or 2 where the persistent bf16 kernel runs it
- * (channels-in-the-lane epilogue: sum g and sum g y as running sums per accumulator register; rows k = 2..4 are written as zeros and
- * the convolution's bias gradient comes from clamd_bn_bwd_apply_sums, below).  0 on bad arguments. */
+/* How many of the five sums a PLAIN (no bias, ReLU, statistics) clamd_conv3x3 launch with bn_y / bn_sums takes: 5, or 2 where the
+ * persistent bf16 kernel runs it (channels-in-the-lane epilogue: sum g and sum g y as running sums per accumulator register; rows
+ * k = 2..4 are written as zeros and the convolution's bias gradient comes from clamd_bn_bwd_apply_sums, below).  0 on bad arguments. */
 int clamd_conv3x3_bn_sums(int B, int H, int W, int Cin_p, int Cout_p, int dtype, const clamd_tuning* tune);
 /* ---- nn.BatchNorm2d folded into the nn.Conv2d(k3,p1) behind it (models/unet.py:15-16,30-31; bnfold.hip) ---------------------
  * x = scale * r + shift with r the producer's saved conv+ReLU output and scale / shift from clamd_bn_finalize:
@@ -166,24 +163,19 @@ int clamd_wgrad_winograd24(const float* gz, int gz_ldc, const float* x, int x_ld
  * scale / shift (optional, [Cp] each): the transform reads x * scale + shift instead of x -- the nn.BatchNorm2d in front of the
  * convolution (models/unet.py:15-16,30-31: clamd_bn_finalize's scale / shift on the producer's conv+ReLU output) folded into
  * the load, with the zero padding applied AFTER the affine as nn.Conv2d does; the clamd_bn_apply pass of that unit is then not
- * needed when nothing else reads its output.
- * bn_y / bn_sums (optional, plain data-gradient launches -- no bias, ReLU or statistics -- also of clamd_conv3x3_winograd24_direct_filters):
- * when y of this launch is the gradient g w.r.t. a BatchNorm output, the TWO gradient-dependent sums of clamd_bn_bwd_reduce (sum g,
- * sum g y_saved: rows k = 0, 1 of bn_sums = [stat_rows][5][Cout_p]; k = 2..4 are written as zeros) are accumulated in the epilogue
- * (bn_y = that unit's saved activation [B,H,W,Cout_p], dense) and the separate reduce pass over the gradient and the activation is not
- * needed; the convolution's bias gradient then comes from clamd_bn_bwd_apply_sums (the two-sum form, see clamd_bn_bwd_apply). */
+ * needed when nothing else reads its output. */
 size_t clamd_winograd24_input_elems(int B, int H, int W, int Cp);
 int clamd_winograd24_transform_input(const float* x, int x_ldc, const float* scale, const float* shift, float* v, int B, int H, int W,
                                      int Cp, void* stream);
 int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const float* bias, float* y, int y_ldc,
-                                 float* stats, int stat_rows, const float* bn_y, float* bn_sums, int B, int H, int W, int Cin_p,
+                                 float* stats, int stat_rows, int B, int H, int W, int Cin_p,
                                  int Cout_p, int relu, const clamd_tuning* tune, void* stream);
 /* The narrow layers (64 / 128 channels, levels 0-1 of models/unet.py:49-72, where 3x the activation bytes through HBM would
  * cost more than the in-kernel transform): clamd_conv3x3_winograd24 with the FILTER fragments loaded straight into the MFMA
  * operand registers instead of being staged through LDS (wino24h_kernel, wino24g.hip).  Same arguments, same packed filters,
  * bit-identical results and statistics rows; needs Cout_p % 64 == 0 and Cin_p % 32 == 0. */
 int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
-                                            float* stats, int stat_rows, const float* bn_y, float* bn_sums, int B, int H, int W,
+                                            float* stats, int stat_rows, int B, int H, int W,
                                             int Cin_p, int Cout_p, int relu, const clamd_tuning* tune, void* stream);
 /* Weight gradient of the same convolution as a batched GEMM over the 24 Winograd planes (K = tiles) on operands transformed
  * once: v = the forward image of the convolution INPUT (clamd_winograd24_transform_input, kept from the forward pass: it is
@@ -225,15 +217,6 @@ int clamd_convT2x2_fwd(const void* x, int x_ldc, const void* w_packed, const flo
 /* data gradient of the above: gy [B,2h,2w,...] -> gx [B,h,w,Cin_p].  w_packed [Cin_p][4][Cout_p]. */
 int clamd_convT2x2_dgrad(const void* gy, int gy_ldc, const void* w_packed, void* gx, int gx_ldc, const void* bn_y,
                          float* bn_sums, int stat_rows, int B, int h, int w, int Cin_p, int Cout_p, int dtype, void* stream);
-
-/* The same two GEMMs on the exact-fp32 path with both operands loaded straight into the MFMA operand registers (pw_direct.hip:
- * every wave owns a (32..128)-pixel x 128-column tile, MT + 4 buffer loads per 16 MT MFMAs, no LDS, no barrier).  Same packed
- * weights, same results to fp32 rounding (another summation order inside 32-channel blocks).  Cin_p % 32 == 0 (forward) /
- * Cin_p % 128 == 0 (data gradient), Cout_p % 32 == 0, activation pitches multiples of 32 channels. */
-int clamd_convT2x2_fwd_direct(const float* x, int x_ldc, const float* w_packed, const float* bias, float* y, int y_ldc, int B,
-                              int h, int w, int Cin_p, int Cout_p, void* stream);
-int clamd_convT2x2_dgrad_direct(const float* gy, int gy_ldc, const float* w_packed, float* gx, int gx_ldc, int B, int h, int w,
-                                int Cin_p, int Cout_p, void* stream);
 
 /* ---- weight gradients (wgrad.hip) --------------------------------------------------------------------------
  * out[r][c][t] = sum_pixels a[p, r] * b[nbr_t(p), c]  written in the parameter's own fp32 layout:

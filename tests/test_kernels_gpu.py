@@ -260,7 +260,7 @@ def test_conv3x3_dgrad_and_wgrad(C, name, dcode, shape):
     got = bsums.sum(0).cpu().numpy()[:, [p for p, l in enumerate(pm_) if l >= 0]]
     nsums = lib.load().clamd_conv3x3_bn_sums(B, H, W, cout_p, cin_p, dcode, None)
     assert nsums in (2, 5) and (nsums == 5 or dcode == 1)
-    assert lib.load().clamd_conv3x3_bn_sums(B, H, W, cout_p, cin_p, dcode, lib.Tuning(pws_cl=0).ref()) == 5
+    assert lib.load().clamd_conv3x3_bn_sums(B, H, W, cout_p, cin_p, dcode, lib.Tuning(igemm_pws=0).ref()) == 5      # the other structures: all five
     if nsums == 2:      # the persistent bf16 kernel: sum g and sum g y only, rows 2-4 written as zeros (clamd_bn_bwd_apply_sums gives d conv-bias)
         assert not np.isnan(bsums.cpu().numpy()).any() and float(bsums[:, 2:].abs().max()) == 0.0
         want, got = want[:2], got[:2]
@@ -281,7 +281,7 @@ VARIANT_SHAPES = [  # B, Cin, Cout, H, W
     (5, 64, 40, 128, 160),    # 400 tiles > CUs: persistent workgroups walk several tiles (resident filter slab in bf16)
 ]
 CONV_VARIANTS = [('igemm_pws', 0, 'igemm_ws', 0), ('igemm_pws', 0, 'igemm_ws', 1), ('igemm_pws', 0, 'igemm_ws', 3),
-                 ('igemm_pws', 0, 'igemm_ws', 4), ('igemm_pws', 2, 'pws_cl', 0), ('igemm_pws', 2, 'igemm_ws', 2), ('igemm_pws', 2, 'pws_wres', 0),
+                 ('igemm_pws', 0, 'igemm_ws', 4), ('igemm_pws', 2, 'igemm_ws', 2), ('igemm_pws', 2, 'pws_wres', 0),
                  ('igemm_pws', 1, 'pws_wres', 1)]
 
 
@@ -312,10 +312,10 @@ def test_conv3x3_kernel_structures_agree(C, name, dcode, shape):
         st = stats.double().sum(0).cpu().numpy()
         np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=2e-3 if dcode == 1 else 1e-4, atol=1e-2 if dcode == 1 else 1e-3)
         np.testing.assert_allclose(st[1, :cout], (ref ** 2).sum((0, 2, 3)), rtol=4e-3 if dcode == 1 else 1e-4, atol=1e-2 if dcode == 1 else 1e-3)
-        # bf16, persistent kernel with the channels-in-the-lane epilogue (pws_cl, the default): the same MFMA chains started at the bias
+        # bf16, persistent kernel (channels-in-the-lane epilogue): the same MFMA chains started at the bias
         # instead of at zero with the bias added last -- the same sum rounded at another place, so those launches agree bit for bit among
         # themselves and with the other structures to the last bit of the stored bf16 value
-        cl = dcode == 1 and k1 == 'igemm_pws' and v1 > 0 and not (k2 == 'pws_cl' and v2 == 0)
+        cl = dcode == 1 and k1 == 'igemm_pws' and v1 > 0
         if first is None:
             first = y.clone()
         elif cl and first_cl is None:
@@ -624,7 +624,7 @@ def test_batchnorm_folded_into_conv3x3(C, kernel, dcode, shape):
             lib.call('clamd_conv3x3_winograd24', ptr(rt), cin_p, ptr(wf), ptr(table), ptr(y), cout_p, ptr(stats), rows, B, H, W, cin_p, cout_p,
                      flags, None, s)
         else:
-            lib.call('clamd_conv3x3_winograd24_direct_filters', ptr(rt), cin_p, ptr(wf), ptr(table), ptr(y), cout_p, ptr(stats), rows, None, None,
+            lib.call('clamd_conv3x3_winograd24_direct_filters', ptr(rt), cin_p, ptr(wf), ptr(table), ptr(y), cout_p, ptr(stats), rows,
                      B, H, W, cin_p, cout_p, flags, None, s)
     sync()
     assert bool(torch.isfinite(table).all()) and float(table[:, cout:].abs().max() if cout < cout_p else 0.0) == 0.0
@@ -708,7 +708,7 @@ def test_conv3x3_winograd24_pretransformed(C, shape):
         lib.call('clamd_conv3x3_winograd24', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), rows, B, H, W, cin_p, cout_p, 1, tp, s)
         v = torch.full((L.clamd_winograd24_input_elems(B, H, W, cin_p),), float('nan'), device='cuda')
         lib.call('clamd_winograd24_transform_input', ptr(xt), cin_p, None, None, ptr(v), B, H, W, cin_p, s)
-        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), cout_p, ptr(stats_p), rows, None, None, B, H, W, cin_p, cout_p, 1, tp, s)
+        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), cout_p, ptr(stats_p), rows, B, H, W, cin_p, cout_p, 1, tp, s)
         sync()
         assert not bool(torch.isnan(v).any()), 'the transform must write every element of V'
         assert torch.equal(y, y_p)
@@ -719,7 +719,7 @@ def test_conv3x3_winograd24_pretransformed(C, shape):
         if tn is not None and (tn.wino_band == 1 or tn.wino_persist == 0):
             assert torch.equal(stats, stats_p)
         stats_q = torch.full_like(stats, float('nan'))
-        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), cout_p, ptr(stats_q), rows, None, None, B, H, W, cin_p, cout_p, 1, tp, s)
+        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), cout_p, ptr(stats_q), rows, B, H, W, cin_p, cout_p, 1, tp, s)
         sync()
         assert torch.equal(stats_p, stats_q), 'statistics rows differ between two identical launches'
         assert rel_l2(C.ops.from_nhwc(y_p, cout, 0).cpu().numpy(), ref) < TOL[0]
@@ -729,7 +729,7 @@ def test_conv3x3_winograd24_pretransformed(C, shape):
         lib.call('clamd_conv3x3_winograd24', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, 0, B, H, W, cout_p, cin_p, 0, tp, s)
         vg = torch.empty(L.clamd_winograd24_input_elems(B, H, W, cout_p), device='cuda')
         lib.call('clamd_winograd24_transform_input', ptr(gzt), cout_p, None, None, ptr(vg), B, H, W, cout_p, s)
-        lib.call('clamd_conv3x3_winograd24_pre', ptr(vg), ptr(wd), None, ptr(gx_p), cin_p, None, 0, None, None, B, H, W, cout_p, cin_p, 0, tp, s)
+        lib.call('clamd_conv3x3_winograd24_pre', ptr(vg), ptr(wd), None, ptr(gx_p), cin_p, None, 0, B, H, W, cout_p, cin_p, 0, tp, s)
         sync()
         assert torch.equal(gx, gx_p)
         got_gx = gx_p.cpu().numpy().transpose(0, 3, 1, 2)
@@ -737,38 +737,13 @@ def test_conv3x3_winograd24_pretransformed(C, shape):
         # the narrow-layer variant: in-kernel transform, filters straight into the operand registers -- bit-identical as well
         y_h = torch.full((B, H, W, cout_p), 9.0, device='cuda')
         stats_h = torch.full_like(stats, float('nan'))
-        lib.call('clamd_conv3x3_winograd24_direct_filters', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y_h), cout_p, ptr(stats_h), rows, None, None,
+        lib.call('clamd_conv3x3_winograd24_direct_filters', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y_h), cout_p, ptr(stats_h), rows,
                  B, H, W, cin_p, cout_p, 1, tp, s)
         gx_h = torch.full((B, H, W, cin_p), 5.0, device='cuda')
-        lib.call('clamd_conv3x3_winograd24_direct_filters', ptr(gzt), cout_p, ptr(wd), None, ptr(gx_h), cin_p, None, 0, None, None, B, H, W,
+        lib.call('clamd_conv3x3_winograd24_direct_filters', ptr(gzt), cout_p, ptr(wd), None, ptr(gx_h), cin_p, None, 0, B, H, W,
                  cout_p, cin_p, 0, tp, s)
         sync()
         assert torch.equal(y, y_h) and torch.equal(gx, gx_h)
-        # the two gradient-dependent BatchNorm-backward sums of the unit in front (sum g, sum g y), taken in the epilogue of the data-gradient
-        # launch (both kernels) in the registers / rows the forward launches use for their statistics: the gradient itself unchanged, rows 0-1
-        # equal to the stand-alone clamd_bn_bwd_reduce pass (other partial rows, same totals), rows 2-4 zeros (the bias gradient comes from
-        # clamd_bn_bwd_apply_sums)
-        if cin_p % 64 == 0:
-            ya = torch.relu(torch.randn(B, H, W, cin_p, device='cuda'))             # the consumer's saved post-ReLU activation
-            sc, sh = torch.rand(cin_p, device='cuda') + 0.5, torch.randn(cin_p, device='cuda')
-            rrows = lib.stat_rows(lib.OP_BN_BWD_REDUCE, B, H, W, 0, cin_p, 0, tuning=tn)
-            ref_sums = torch.full((rrows, 5, cin_p), float('nan'), device='cuda')
-            lib.call('clamd_bn_bwd_reduce', ptr(gx), cin_p, None, 0, ptr(ya), cin_p, ptr(sc), ptr(sh), ptr(ref_sums), rrows, B, H, W, cin_p, 0, tp, s)
-            srows = lib.stat_rows(lib.OP_CONV3X3_WINOGRAD24, B, H, W, cout_p, cin_p, 0, tuning=tn)
-            for name, a0, a1 in (('clamd_conv3x3_winograd24_pre', (ptr(vg),), ()), ('clamd_conv3x3_winograd24_direct_filters', (ptr(gzt), cout_p), ())):
-                gx_s = torch.full((B, H, W, cin_p), 6.0, device='cuda')
-                sums, sums2 = (torch.full((srows, 5, cin_p), float('nan'), device='cuda') for _ in range(2))
-                for sm_ in (sums, sums2):
-                    lib.call(name, *a0, ptr(wd), None, ptr(gx_s), cin_p, None, srows, ptr(ya), ptr(sm_), B, H, W, cout_p, cin_p, 0, tp, s)
-                sync()
-                assert torch.equal(gx_s, gx), name
-                assert torch.equal(sums, sums2), f'{name}: the sums rows differ between two identical launches'
-                got, want = sums.double().sum(0).cpu().numpy(), ref_sums.double().sum(0).cpu().numpy()
-                np.testing.assert_allclose(got[:2], want[:2], rtol=2e-5, atol=2e-3 * float(np.abs(want).max() ** 0.5 + 1))
-                assert float(sums[:, 2:].abs().max()) == 0.0, name
-            with pytest.raises(RuntimeError, match='plain data-gradient'):
-                lib.call('clamd_conv3x3_winograd24_pre', ptr(vg), ptr(wd), ptr(bp), ptr(gx_s), cin_p, None, srows, ptr(ya), ptr(sums), B, H, W,
-                         cout_p, cin_p, 0, tp, s)
         assert torch.equal(stats, stats_h), 'same block order as clamd_conv3x3_winograd24: identical rows'
     # BatchNorm folded into the transform: V(raw * scale + shift, zero padding AFTER the affine) == V of the materialised tensor
     scale = torch.rand(cin_p, device='cuda') + 0.5
@@ -783,7 +758,7 @@ def test_conv3x3_winograd24_pretransformed(C, shape):
     assert torch.equal(v_ref, v_fold)
     # refused shapes
     with pytest.raises(RuntimeError, match='Cout_p % 64'):
-        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), 32, None, 0, None, None, B, H, W, cin_p, 32, 1, None, s)
+        lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bp), ptr(y_p), 32, None, 0, B, H, W, cin_p, 32, 1, None, s)
 
 
 W24G_WGRAD_SHAPES = [  # B, Cin segs, Cout, H, W (Cin_p, Cout_p multiples of 256)
@@ -836,50 +811,6 @@ def test_wgrad_winograd24_pretransformed(C, shape):
              cout, cout_p, c_seg0, c_seg0p, None, s)
     sync()
     assert rel_l2(outs[0].cpu().numpy(), gw2.cpu().numpy()) < 1e-5
-
-
-@pytest.mark.parametrize('shape', [(2, 128, 64, 8, 8), (1, 256, 100, 6, 10), (3, 128, 32, 5, 7), (2, 512, 256, 16, 16)],
-                         ids=lambda sh: f'{sh[0]}x{sh[1]}->{sh[2]}@{sh[3]}x{sh[4]}')
-def test_convT2x2_direct_fp32(C, shape):
-    """pw_direct.hip: nn.ConvTranspose2d(k2,s2) forward (into a concat slice) and data gradient with operands loaded straight
-    into the MFMA operand registers (every row-tile size: 32 / 64 / 128 pixels per wave, ragged pixel counts), against the oracle
-    at the fp32 bound and against igemm_kernel (same products, other summation order)."""
-    B, cin, cout, h, w_ = shape
-    rng = np.random.default_rng(14)
-    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
-    cin_p, cout_p = C.ops.cpad(cin), C.ops.cpad(cout)
-    x = rnd(rng, B, cin, h, w_)
-    w = rnd(rng, cin, cout, 2, 2) * (1 / np.sqrt(cin))
-    b = rnd(rng, cout)
-    xt, wt, bt = C.ops.to_nhwc(dev(x), 0), dev(w), dev(b)
-    wf = torch.zeros(4 * cout_p * cin_p, device='cuda'); wd = torch.zeros(cin_p * 4 * cout_p, device='cuda')
-    bp = torch.zeros(cout_p, device='cuda')
-    tab = C.ops.PackTable(0); tab.convT(wt, wf, wd, cin, cout); tab.vector(bt, bp, cout); tab.finalize('cuda').run(0)
-    cat = torch.full((B, 2 * h, 2 * w_, 2 * cout_p), 3.0, device='cuda')
-    cat_old = torch.full((B, 2 * h, 2 * w_, 2 * cout_p), 3.0, device='cuda')
-    lib.call('clamd_convT2x2_fwd_direct', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(cat[..., cout_p:]), 2 * cout_p, B, h, w_, cin_p, cout_p, s)
-    lib.call('clamd_convT2x2_fwd', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(cat_old[..., cout_p:]), 2 * cout_p, B, h, w_, cin_p, cout_p, 0, s)
-    sync()
-    ref = O.convT2x2_fwd(x, w, b)
-    got = cat[..., cout_p:cout_p + cout].cpu().numpy().transpose(0, 3, 1, 2)
-    assert rel_l2(got, ref) < TOL[0]
-    assert float((cat[..., :cout_p] - 3.0).abs().max()) == 0.0                    # the other half of the concat buffer: untouched
-    assert float(cat[..., cout_p + cout:].abs().max()) == 0.0 if cout < cout_p else True   # padded channels: zero weights + zero bias
-    assert rel_l2(cat.cpu().numpy(), cat_old.cpu().numpy()) < 2e-6
-    gy = rnd(rng, B, cout, 2 * h, 2 * w_)
-    gfull = np.zeros((B, 2 * h, 2 * w_, 2 * cout_p), np.float32)
-    gfull[..., cout_p:cout_p + cout] = gy.transpose(0, 2, 3, 1)
-    gcat = dev(gfull)
-    gx = torch.full((B, h, w_, cin_p), 7.0, device='cuda')
-    gx2 = torch.full((B, h, w_, cin_p), 8.0, device='cuda')
-    for o_ in (gx, gx2):
-        lib.call('clamd_convT2x2_dgrad_direct', ptr(gcat[..., cout_p:]), 2 * cout_p, ptr(wd), ptr(o_), cin_p, B, h, w_, cin_p, cout_p, s)
-    sync()
-    assert torch.equal(gx, gx2)
-    rgx = O.convT2x2_bwd(x, w, gy)[0]
-    assert rel_l2(C.ops.from_nhwc(gx, cin, 0).cpu().numpy(), rgx) < TOL[0]
-    with pytest.raises(RuntimeError, match='Cin_p % 128'):
-        lib.call('clamd_convT2x2_dgrad_direct', ptr(gcat[..., cout_p:]), 2 * cout_p, ptr(wd), ptr(gx), 64, B, h, w_, 64, cout_p, s)
 
 
 def _random_conv_shapes(n, seed):

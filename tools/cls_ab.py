@@ -37,7 +37,7 @@ for dcode, name in ((0, 'fp32'), (1, 'bf16'), (2, 'bf16x3')):
             rows = lib.stat_rows(lib.OP_CONV3X3_WINOGRAD24, B, hw, hw, cin, cout, 0)
             st = torch.empty(rows, 2, cout, device='cuda')
             fn = 'clamd_conv3x3_winograd24_direct_filters' if cin == 64 else 'clamd_conv3x3_winograd24'
-            extra = (None, None) if cin == 64 else ()
+            extra = ()
             run = lambda fl: lib.call(fn, ptr(x), cin, ptr(wf), ptr(table), ptr(y), cout, ptr(st), rows, *extra, B, hw, hw, cin, cout, fl, None, s)
         else:
             wf = torch.zeros(9 * cout * cin, dtype=T, device='cuda')

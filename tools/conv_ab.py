@@ -1,7 +1,7 @@
 """Interleaved A/B of igemm schedule variants in ONE process (conv3x3, UNet layer shapes).
 
-    python tools/conv_ab.py bf16 0,1 pws_cl                 # forward launches (bias + ReLU + statistics rows)
-    CONV_MODE=dgrad python tools/conv_ab.py bf16 0,1 pws_cl     # plain data-gradient launches (no bias / ReLU / statistics)
+    python tools/conv_ab.py bf16 0,1,2 igemm_variant            # forward launches (bias + ReLU + statistics rows)
+    CONV_MODE=dgrad python tools/conv_ab.py bf16 0,1 pws_wres    # plain data-gradient launches (no bias / ReLU / statistics)
     CONV_MODE=dgrad_bn ...                                   # ... with the BatchNorm-backward sums of the consumer in the epilogue
 """
 import os, sys
@@ -58,8 +58,7 @@ for cin, cout, hw in layers:
             best[v] = min(best[v], e0.elapsed_time(e1) / iters * 1e-3)
             if rd == 0:
                 if ref is None: ref = y.float().clone()
-                elif v < 3 and key != 'pws_cl': assert torch.equal(ref, y.float()), f'variant {v} changed the result'
-                elif key == 'pws_cl': print('      max |diff| between the two epilogues', float((ref - y.float()).abs().max()))
+                elif v < 3: assert torch.equal(ref, y.float()), f'variant {v} changed the result'
     fl = 2.0 * B * hw * hw * 9 * cin * cout
     print(f'{cin:5d}->{cout:5d} @{hw:3d}: ' + '  '.join(f'v{v} {best[v]*1e6:7.1f}us {fl/best[v]/1e12:7.1f}TF' for v in variants))
     for v in variants: tot[v][0] += fl; tot[v][1] += best[v]

@@ -28,7 +28,7 @@ def union(iv):
     return tot + ce - cs
 
 
-mf = [(s, e) for s, e, n, q in step if any(x in n for x in ('wino', 'igemm', 'wgrad_kernel', 'wgrad_dma', 'pw_direct')) and 'reduce' not in n and 'pack' not in n and 'xform' not in n]
+mf = [(s, e) for s, e, n, q in step if any(x in n for x in ('wino', 'igemm', 'wgrad_kernel', 'wgrad_dma')) and 'reduce' not in n and 'pack' not in n and 'xform' not in n]
 al = [(s, e) for s, e, n, q in step]
 print(f'step {k}: wall {(t1 - t0) / 1e6:.3f} ms, {len(step)} kernels on queues {sorted(set(q for *_, q in step))}; some kernel running '
       f'{union(al) / 1e6:.3f} ms, an MFMA kernel running {union(mf) / 1e6:.3f} ms (sum of their durations {sum(e - s for s, e in mf) / 1e6:.3f} ms)')

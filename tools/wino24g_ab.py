@@ -55,9 +55,9 @@ for cin, cout, hw in SH:
     if pre_wg:
         yt = torch.empty(L.clamd_wgrad_winograd24_pre_operand_elems(B, hw, hw, cout), device='cuda')
     for rnd in range(3):
-        res['w24'] = timed(lambda: lib.call('clamd_conv3x3_winograd24', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(st), rows, None, None, B, hw, hw, cin, cout, 1, None, s))
+        res['w24'] = timed(lambda: lib.call('clamd_conv3x3_winograd24', ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(st), rows, B, hw, hw, cin, cout, 1, None, s))
         res['xf'] = timed(lambda: lib.call('clamd_winograd24_transform_input', ptr(x), cin, None, None, ptr(v), B, hw, hw, cin, s))
-        res['pre'] = timed(lambda: lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bias), ptr(y), cout, ptr(st), rows, None, None, B, hw, hw, cin, cout, 1, None, s))
+        res['pre'] = timed(lambda: lib.call('clamd_conv3x3_winograd24_pre', ptr(v), ptr(wf), ptr(bias), ptr(y), cout, ptr(st), rows, B, hw, hw, cin, cout, 1, None, s))
         res['wg'] = timed(lambda: lib.call(wg_name, ptr(gz), cout, ptr(x), cin, ptr(ws), wsb, ptr(gw), B, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, None, s))
         if pre_wg:
             res['wgp'] = timed(lambda: lib.call('clamd_wgrad_winograd24_pre', ptr(gz), cout, ptr(v), ptr(yt), ptr(ws), wsb, ptr(gw), B, hw, hw,

@@ -30,7 +30,7 @@ for cin, cout, hw in SH:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                extra = (None, None) if key == 'direct' else ()
+                extra = ()
                 lib.call(name, ptr(x), cin, ptr(wf), ptr(bias), ptr(y), cout, ptr(st), rows, *extra, B, hw, hw, cin, cout, 1, None, s)
             e1.record(); e1.synchronize()
             res[key] = e0.elapsed_time(e1) / reps * 1e3

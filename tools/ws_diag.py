@@ -11,7 +11,7 @@ pws = len(sys.argv) > 3 and sys.argv[3] == 'pws'      # persistent kernel: consu
 dc = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}[dt]
 T = C.ops.TORCH_DT[dc]
 B = 16
-tn = C._lib.Tuning(igemm_ws=mode, igemm_pws=2 if pws else 0, pws_cl=int(os.environ.get("PWS_CL", "1")))
+tn = C._lib.Tuning(igemm_ws=mode, igemm_pws=2 if pws else 0)
 diag = lib.clamd_debug_pws_diag if pws else lib.clamd_debug_ws_diag
 out = (ctypes.c_ulonglong * 8)()
 for cin, cout, hw in [(64, 64, 256), (128, 64, 256), (128, 128, 128), (256, 256, 64), (1024, 512, 32)]:
