@@ -20,22 +20,38 @@
 // 32-channel block, so the outputs leave as 16-byte stores, the bias is the initial value of plane 1 (the one column of A6^T that is all
 // ones) and the statistics are running sums per accumulator register.
 #include <algorithm>
+#include <type_traits>
 #include "common.hip.h"
 #include "clamd_internal.h"
 #include "wino_common.hip.h"
 
 namespace clamd {
 
+#ifdef CLAMD_DIAG
+// diagnostic build only (python build.py --variant diag --diag; tools/w41_diag.py): cycles per phase, summed over workgroups (wave 0, lane 0)
+__device__ unsigned long long g_w41_diag[8];
+#define W41_T() __builtin_amdgcn_s_memtime()
+#define W41_ADD(i_, v_) do { if (threadIdx.x == 0) atomicAdd(&g_w41_diag[i_], (unsigned long long)(v_)); } while (0)
+#else
+#define W41_T() 0ull
+#define W41_ADD(i_, v_) do { } while (0)
+#endif
+
 constexpr int W41_TH = 16, W41_TW = 32, W41_SEG = W41_TW / 4;
 constexpr int W41_HH = W41_TH + 2;
-constexpr int W41_XS = 6 * W41_HH * W41_SEG * 2;            // 16-byte slots: [j][halo row][segment][4-channel group]
-constexpr int W41_WS = 18 * 64 * 2;                         //                [j * 3 + ky][output channel][4-channel group]
+// LDS images in 16-byte slots, the two 4-channel groups of a chunk in separate planes so that the 32 lanes of a fragment read walk
+// consecutive slots (conflict-free ds_read_b128); the planes are 4 slots out of phase so that staging stores, whose lanes alternate
+// between the planes, hit disjoint banks:   V [group][j][halo row][segment]      filters [group][j * 3 + ky][output channel]
+constexpr int W41_XG = 6 * W41_HH * W41_SEG + 4, W41_XS = 2 * W41_XG;
+constexpr int W41_WG = 18 * 64 + 4, W41_WS = 2 * W41_WG;
 constexpr int W41_STAGE = W41_XS + W41_WS;
 
-typedef __attribute__((address_space(3))) void w41_lds_void;
-// 16 bytes per lane from a buffer straight into LDS at (wave-uniform) lds + lane * 16; out-of-range lanes write zeros (wgrad_dma.hip)
-__device__ inline void w41_dma16(__amdgpu_buffer_rsrc_t rs, char* lds, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (w41_lds_void*)lds, 16, voff, soff, 0, 0);
+template <int N, int I = 0, typename F>
+__device__ inline void w41_unroll(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        w41_unroll<N, I + 1>(f);
+    }
 }
 
 // EPI 0: plain (data gradient)   1: bias + ReLU + statistics rows   2: the same with the bias from a border-class table (folded BatchNorm)
@@ -46,6 +62,7 @@ __global__ void __launch_bounds__(256, 1) wino41_kernel(const WinoParams p, cons
     __shared__ uint4 smem[2 * W41_STAGE];
     __shared__ float cls_tab[EPI == 2 ? 9 * 64 : 1];
     __shared__ float bias_lds[EPI >= 1 ? 64 : 1];
+    __shared__ float w41_dummy[256];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -60,11 +77,14 @@ __global__ void __launch_bounds__(256, 1) wino41_kernel(const WinoParams p, cons
 
     // ---- staging.  Input: unit (halo row hy < 16, segment s, 4-channel group g) = thread tid: six pixels x 16 bytes -> B6^T -> six transformed
     // values x 16 bytes; the two last halo rows (32 more units) are split by channel over waves 0-1: thread (unit, channel) moves six dwords.
-    // Filters: no transform, LDS-DMA (buffer_load ... lds): slot = tid + 256 q, a wave's 64 slots are 1 KB contiguous in both images.
+    // Filters: no transform, slot = tid + 256 q through registers (LDS-DMA was tried: hipcc makes a wave wait for its own pending DMA before the
+    // first ds_read that follows, i.e. the whole memory latency sat in front of every chunk's MFMAs).
     const unsigned img = (unsigned)p.H * (unsigned)p.W * (unsigned)p.x_ldc * 4u;
     const unsigned pstep = (unsigned)p.x_ldc * 4u;
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(p.w, (unsigned)((size_t)18 * p.Np * p.Kp * 4));
-    const bool low = wave < 2;                                   // waves 0-1 also take the channel-split units (wave-uniform)
+    const __amdgpu_buffer_rsrc_t wrs_dead = make_rsrc(p.w, 0u), xrs_dead = make_rsrc(p.x, 0u);      // the step behind the last one: loads without traffic
+    const bool low = wave < 2;                                   // waves 0-1 also take the channel-split units (wave-uniform); the others go
+    //                                                              through the same instructions with out-of-range loads and a dummy LDS word
     unsigned vb0, vb1;                                           // byte offset of a unit's pixel i = 0 (BUF_OOB: the whole halo row is padding)
     bool ok0_first, ok0_last, ok1_first, ok1_last;               // pixel 0 / pixel 5 of the unit inside the image (columns -1 / W are padding)
     __amdgpu_buffer_rsrc_t xrs;
@@ -77,9 +97,9 @@ __global__ void __launch_bounds__(256, 1) wino41_kernel(const WinoParams p, cons
             ok0_first = x0 + 4 * s > 0; ok0_last = x0 + 4 * s + 4 < p.W;
         }
         {
-            const int u = tid >> 2, ch = tid & 3;                // waves 0-1: unit 256 + u (u < 32), channel ch of its group
+            const int u = (tid >> 2) & 31, ch = tid & 3;         // waves 0-1: unit 256 + u, channel ch of its group
             const int g = u & 1, s = (u >> 1) & 7, hy = 16 + (u >> 4), yy = y0 + hy - 1;
-            vb1 = (yy >= 0 && yy < p.H) ? (unsigned)(((yy * p.W + x0 + 4 * s - 1) * p.x_ldc + 4 * g + ch) * 4) : BUF_OOB;
+            vb1 = (low && yy >= 0 && yy < p.H) ? (unsigned)(((yy * p.W + x0 + 4 * s - 1) * p.x_ldc + 4 * g + ch) * 4) : BUF_OOB;
             ok1_first = x0 + 4 * s > 0; ok1_last = x0 + 4 * s + 4 < p.W;
         }
     };
@@ -88,23 +108,22 @@ __global__ void __launch_bounds__(256, 1) wino41_kernel(const WinoParams p, cons
     const unsigned w_vo = n0 + ((tid & 127) >> 1) < p.Np ? (unsigned)((((size_t)(tid >> 7) * p.Np + n0 + ((tid & 127) >> 1)) * 8 + 4 * (tid & 1)) * 4) : BUF_OOB;
     const unsigned w_q = (unsigned)((size_t)2 * p.Np * 8 * 4);             // slot + 256 = two (j, ky) planes further
     const unsigned w_chunk = (unsigned)((size_t)18 * p.Np * 8 * 4);
-    auto gload = [&](int c, int stg) {
+    uint4 rw[9];
+    // 21 loads, no branch (the whole step is ONE basic block so that they can be issued between its MFMAs)
+    auto gload = [&](const __amdgpu_buffer_rsrc_t xr, const __amdgpu_buffer_rsrc_t wr, int c) {
         const unsigned so = (unsigned)(c * 32);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const bool ok = i == 0 ? ok0_first : (i == 5 ? ok0_last : true);
-            rin[i] = buf_ld16(xrs, ok ? vb0 + i * pstep : BUF_OOB, so);
+            rin[i] = buf_ld16(xr, ok ? vb0 + i * pstep : BUF_OOB, so);
         }
-        if (low) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const bool ok = i == 0 ? ok1_first : (i == 5 ? ok1_last : true);
-                rin1[i] = __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? vb1 + i * pstep : BUF_OOB, so, 0);
-            }
+        for (int i = 0; i < 6; ++i) {
+            const bool ok = i == 0 ? ok1_first : (i == 5 ? ok1_last : true);
+            rin1[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, ok ? vb1 + i * pstep : BUF_OOB, so, 0));      // the builtin returns the raw dword
         }
-        char* wdst = reinterpret_cast<char*>(smem + stg * W41_STAGE + W41_XS + 64 * wave);
 #pragma unroll
-        for (int q = 0; q < 9; ++q) w41_dma16(wrs, wdst + q * 256 * 16, w_vo, (unsigned)c * w_chunk + q * w_q);
+        for (int q = 0; q < 9; ++q) rw[q] = buf_ld16(wr, w_vo, (unsigned)c * w_chunk + q * w_q);
     };
     // B6^T: v0 = 4 d0 - 5 d2 + d4; v1, v2 = (d4 - 4 d2) +- (d3 - 4 d1); v3, v4 = (d4 - d2) +- 2 (d3 - d1); v5 = 4 d1 - 5 d3 + d5
     auto bt6 = [](const float (&d)[6], float (&o)[6]) {
@@ -112,6 +131,11 @@ __global__ void __launch_bounds__(256, 1) wino41_kernel(const WinoParams p, cons
         o[0] = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4])); o[1] = t0 + t1; o[2] = t0 - t1; o[3] = t2 + t3; o[4] = t2 - t3;
         o[5] = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
     };
+    // slots of this thread in a stage: its unit's six V values, its nine filter pieces, its channel-split word (waves 2-3: a dummy word behind the stages)
+    const int xslot = (tid & 1) * W41_XG + (tid >> 1);                                       // + j * (HH * SEG)
+    const int wslot = W41_XS + (tid & 1) * W41_WG + (tid >> 1);                              // + 128 q
+    const int u1 = 256 + ((tid >> 2) & 31);
+    const int xword = low ? ((u1 & 1) * W41_XG + (u1 >> 1)) * 4 + (tid & 3) : -1;            // float index; + j * (HH * SEG) * 4
     auto stage_store = [&](int stg) {
         uint4* st = smem + stg * W41_STAGE;
         uint4 v[6];
@@ -128,20 +152,20 @@ __global__ void __launch_bounds__(256, 1) wino41_kernel(const WinoParams p, cons
             }
         }
 #pragma unroll
-        for (int j = 0; j < 6; ++j) st[j * (W41_HH * W41_SEG * 2) + tid] = v[j];       // slot (hy * 8 + s) * 2 + g == tid
-        if (low) {
-            float o[6];
-            bt6(rin1, o);
-            float* sf = reinterpret_cast<float*>(st) + (256 + (tid >> 2)) * 4 + (tid & 3);
+        for (int j = 0; j < 6; ++j) st[xslot + j * (W41_HH * W41_SEG)] = v[j];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) sf[j * (W41_HH * W41_SEG * 2) * 4] = o[j];
-        }
+        for (int q = 0; q < 9; ++q) st[wslot + 128 * q] = rw[q];
+        float o[6];
+        bt6(rin1, o);
+        float* sf = xword >= 0 ? reinterpret_cast<float*>(st) + xword : w41_dummy + tid;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sf[xword >= 0 ? j * (W41_HH * W41_SEG) * 4 : 0] = o[j];
     };
 
     // ---- consumer side: lane (r, h) = super-pixel 32 wave + r (row 4 wave + r / 8, segment r % 8), channel pieces 8 h
     const int rperm = (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1);      // filter row behind MFMA row r (igemm_pws.hip)
     const int sp = 32 * wave + r, row_l = sp >> 3, seg = sp & 7;
-    const int xs_base = (row_l * W41_SEG + seg) * 2 + h;                 // + (j * HH + ky) * 16
+    const int xs_base = h * W41_XG + row_l * W41_SEG + seg;              // + (j * HH + ky) * 8
     float cs1[EPI >= 1 ? 2 : 1][16], cs2[EPI >= 1 ? 2 : 1][16];
     if constexpr (EPI >= 1) {
 #pragma unroll
@@ -164,11 +188,19 @@ __global__ void __launch_bounds__(256, 1) wino41_kernel(const WinoParams p, cons
     // ---- (tile, chunk) pipeline, one running step counter: the loads / filter DMA of step s + 1 are in flight under the MFMAs of step s
     // (across tile boundaries too), transformed and stored behind them, one barrier per step
     const int S = T_ * nk;
+    int l_tile = 0, l_c = 0;                                     // load cursor: (tile, chunk) of the step whose data the registers hold
+    auto advance = [&]() {                                        // -> the next step's (tile, chunk); re-derives the tile's offsets when it changes
+        if (++l_c == nk) { l_c = 0; ++l_tile; if (l_tile < T_) set_tile(mg + l_tile * gm); }
+    };
     set_tile(mg);
-    gload(0, 0);
-    stage_store(0);
+    gload(xrs, wrs, 0);
+    stage_store(0);                                              // step 0 -> stage 0
+    advance();
+    gload(S > 1 ? xrs : xrs_dead, S > 1 ? wrs : wrs_dead, l_c);  // step 1 -> registers
     __syncthreads();
-    int l_tile = 0, l_c = 0, s = 0;                              // load cursor, step
+    int s = 0;                                                   // step
+    unsigned long long dg[5] = {0, 0, 0, 0, 0};
+    (void)dg;
     for (int ti = 0; ti < T_; ++ti) {
         f32x16 acc[6][2];
 #pragma unroll
@@ -188,38 +220,91 @@ __global__ void __launch_bounds__(256, 1) wino41_kernel(const WinoParams p, cons
                 }
         }
         for (int c = 0; c < nk; ++c, ++s) {
-            const bool more = s + 1 < S;
-            if (more) {
-                if (++l_c == nk) { l_c = 0; ++l_tile; set_tile(mg + l_tile * gm); }
-                gload(l_c, (s + 1) & 1);
-            }
-            // ---- 144 MFMAs on stage s & 1: per (j, ky) one pixel fragment and two filter fragments, the next step's three reads behind the MFMAs
+            const unsigned long long t0 = W41_T();
+            advance();                                       // the registers hold step s + 1; the loads below fetch step s + 2
+            const bool more2 = s + 2 < S;
+            // ---- ONE basic block from here to the barrier: the 144 MFMAs of step s with their 54 fragment reads; the transform of step s + 1
+            // (in registers since the previous block) and its 21 LDS stores; the 21 loads of step s + 2 (dead descriptors past the end).  Alone,
+            // each of the non-MFMA parts cost 1.5-2.2k cycles per step beside 8.3k of MFMAs (stamps, tools/w41_diag.py: a load instruction is 64
+            // scattered lines and issues at ~100 cycles); placed between the MFMAs (w41_sched) they cost issue slots only.
+            const unsigned long long t1 = W41_T();
             {
                 const uint4* xs = smem + (s & 1) * W41_STAGE + xs_base;
-                const uint4* ws = smem + (s & 1) * W41_STAGE + W41_XS + h;
+                const uint4* ws = smem + (s & 1) * W41_STAGE + W41_XS + h * W41_WG;
                 uint4 f[2][3];
 #define W41_FRAG(jk_, d_)                                                                        \
     do {                                                                                         \
-        d_[0] = xs[(((jk_) / 3) * W41_HH + (jk_) % 3) * (W41_SEG * 2)];                          \
-        d_[1] = ws[((jk_) * 64 + rperm) * 2];                                                    \
-        d_[2] = ws[((jk_) * 64 + 32 + rperm) * 2];                                               \
+        d_[0] = xs[(((jk_) / 3) * W41_HH + (jk_) % 3) * W41_SEG];                                \
+        d_[1] = ws[(jk_) * 64 + rperm];                                                          \
+        d_[2] = ws[(jk_) * 64 + 32 + rperm];                                                     \
     } while (0)
-                W41_FRAG(0, f[0]);
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                // Side work of the block in 36 pieces, one per group of four MFMAs, fenced (sched_barrier) so that it STAYS between them -- the
+                // sched_group_barrier pipelines that order the other kernels put these loads either all in front of the MFMAs or all behind them:
+                //   0-3 transform channel c of the unit in rin (step s + 1)   4 the channel-split unit   5-8 the nine filter stores   9-11 the six V
+                //   stores   12-13 the channel-split stores   14-34 the 21 loads of step s + 2, one each (first use 16 groups = 3.6k cycles later)
+                uint4* const st = smem + ((s + 1) & 1) * W41_STAGE;
+                const __amdgpu_buffer_rsrc_t xr = more2 ? xrs : xrs_dead, wr = more2 ? wrs : wrs_dead;
+                const unsigned so = (unsigned)(l_c * 32), wo = (unsigned)l_c * w_chunk;
+                uint4 v[6];
+                float o1[6];
+                auto side = [&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    if constexpr (g < 4) {
+                        float d[6], o[6];
 #pragma unroll
-                for (int jk = 0; jk < 18; ++jk) {
-                    if (jk + 1 < 18) W41_FRAG(jk + 1, f[(jk + 1) & 1]);
+                        for (int i = 0; i < 6; ++i) d[i] = __uint_as_float(g == 0 ? rin[i].x : g == 1 ? rin[i].y : g == 2 ? rin[i].z : rin[i].w);
+                        bt6(d, o);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            const unsigned bq = __float_as_uint(o[j]);
+                            if (g == 0) v[j].x = bq; else if (g == 1) v[j].y = bq; else if (g == 2) v[j].z = bq; else v[j].w = bq;
+                        }
+                    } else if constexpr (g == 4) {
+                        bt6(rin1, o1);
+                    } else if constexpr (g < 9) {
+                        constexpr int q0 = (g - 5) * 9 / 4, q1 = (g - 4) * 9 / 4;
+#pragma unroll
+                        for (int q = q0; q < q1; ++q) st[wslot + 128 * q] = rw[q];
+                    } else if constexpr (g < 12) {
+                        st[xslot + (2 * (g - 9)) * (W41_HH * W41_SEG)] = v[2 * (g - 9)];
+                        st[xslot + (2 * (g - 9) + 1) * (W41_HH * W41_SEG)] = v[2 * (g - 9) + 1];
+                    } else if constexpr (g < 14) {
+                        float* sf = xword >= 0 ? reinterpret_cast<float*>(st) + xword : w41_dummy + tid;
+#pragma unroll
+                        for (int j = 3 * (g - 12); j < 3 * (g - 12) + 3; ++j) sf[xword >= 0 ? j * (W41_HH * W41_SEG) * 4 : 0] = o1[j];
+                    } else if constexpr (g < 20) {
+                        constexpr int i = g - 14;
+                        const bool ok = i == 0 ? ok0_first : (i == 5 ? ok0_last : true);
+                        rin[i] = buf_ld16(xr, ok ? vb0 + i * pstep : BUF_OOB, so);
+                    } else if constexpr (g < 26) {
+                        constexpr int i = g - 20;
+                        const bool ok = i == 0 ? ok1_first : (i == 5 ? ok1_last : true);
+                        rin1[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, ok ? vb1 + i * pstep : BUF_OOB, so, 0));
+                    } else if constexpr (g < 35) {
+                        constexpr int q = g - 26;
+                        rw[q] = buf_ld16(wr, w_vo, wo + q * w_q);
+                    }
+                };
+                W41_FRAG(0, f[0]);
+                w41_unroll<18>([&](auto jkc) {
+                    constexpr int jk = decltype(jkc)::value;
+                    if constexpr (jk + 1 < 18) W41_FRAG(jk + 1, f[(jk + 1) & 1]);      // seven MFMAs and more cover the latency
                     const uint4* q = f[jk & 1];
+                    side(std::integral_constant<int, 2 * jk>{});
                     mma16<float>(q[1], q[0], acc[jk / 3][0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    side(std::integral_constant<int, 2 * jk + 1>{});
                     mma16<float>(q[2], q[0], acc[jk / 3][1]);
-                    if (jk + 1 < 18) sched_mfma_reads<8, 3>();
-                    else __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-                }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
 #undef W41_FRAG
             }
-            if (more) stage_store((s + 1) & 1);
+            const unsigned long long t3 = W41_T();
             __syncthreads();
+            const unsigned long long t4 = W41_T();
+            dg[0] += t1 - t0; dg[1] += t3 - t1; dg[3] += t4 - t3;
         }
+        const unsigned long long t5 = W41_T();
 
         // ---- epilogue of tile ti: A6^T in-lane, (border-class bias,) ReLU, statistics, 16-byte stores
         const int tm = mg + ti * gm;
@@ -283,8 +368,11 @@ __global__ void __launch_bounds__(256, 1) wino41_kernel(const WinoParams p, cons
                 }
             }
         }
+        dg[4] += W41_T() - t5;
     }
 
+    W41_ADD(0, dg[0]); W41_ADD(1, dg[1]); W41_ADD(2, dg[2]); W41_ADD(3, dg[3]); W41_ADD(4, dg[4]); W41_ADD(7, 1);
+    // [0] tile cursor  [1] the step's block (loads, MFMAs, transform, stage stores)  [3] barrier  [4] epilogues  [7] workgroups
     // ---- statistics: one row per workgroup, fixed order (igemm_pws.hip): [kind][channel][wave][pixel lane], pitch 33, through the free stages
     if constexpr (EPI >= 1) {
         if (p.stats) {
@@ -363,6 +451,14 @@ long long clamd_winograd41_stat_rows(int B, int H, int W, int Cout_p, const clam
 }  // namespace clamd
 
 using namespace clamd;
+
+#ifdef CLAMD_DIAG
+extern "C" int clamd_debug_w41_diag(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(clamd::g_w41_diag), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(clamd::g_w41_diag), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 int clamd_launch_wino41_pack(const void* jobs_dev, int njobs, int total_blocks, const clamd::FoldBias* fold, hipStream_t stream) {
     if (njobs <= 0 || total_blocks <= 0) return clamd_fail("wino41_pack: empty job table");
