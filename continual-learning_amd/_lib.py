@@ -15,7 +15,7 @@ F32, BF16, SPLIT = 0, 1, 2      # SPLIT = 'bf16x3': fp32 storage, 3-term split-b
 WGRAD_CONV3, WGRAD_PW, WGRAD_UP2 = 0, 1, 2
 
 _P, _I, _D, _LL, _SZ = c_void_p, c_int, c_double, c_longlong, c_size_t
-OP_CONV3X3, OP_CONV3X3_WINOGRAD, OP_CONV1X1, OP_CONVT2X2_DGRAD, OP_BN_BWD_REDUCE, OP_CONV3X3_WINOGRAD24, OP_CONV3X3_WINOGRAD41 = range(7)
+OP_CONV3X3, OP_CONV3X3_WINOGRAD, OP_CONV1X1, OP_CONVT2X2_DGRAD, OP_BN_BWD_REDUCE, OP_CONV3X3_WINOGRAD24 = range(6)
 
 
 class Tuning(ctypes.Structure):
@@ -96,9 +96,6 @@ SIGNATURES = {
     'clamd_wgrad_winograd': (_I, [_P, _I, _P, _I, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_conv3x3_winograd': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_wino24_pack': (_I, [_P, _I, _I, _P]),
-    'clamd_wino41_pack': (_I, [_P, _I, _I, _P]),
-    'clamd_conv3x3_winograd41_ok': (_I, [_I, _I, _I, _I, _I]),
-    'clamd_conv3x3_winograd41': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_conv3x3_winograd24': (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_winograd24_input_elems': (_SZ, [_I, _I, _I, _I]),
     'clamd_winograd24_transform_input': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -122,8 +122,7 @@ int clamd_bn_fold_pack(int form, const void* jobs_dev, int njobs, int total_bloc
     if (form == 0) return clamd_launch_pack(jobs_dev, njobs, total_blocks, dtype, &f, (hipStream_t)stream);
     if (form == 16) return clamd_launch_wino_pack(jobs_dev, njobs, total_blocks, &f, (hipStream_t)stream);
     if (form == 24) return clamd_launch_wino24_pack(jobs_dev, njobs, total_blocks, &f, (hipStream_t)stream);
-    if (form == 18) return clamd_launch_wino41_pack(jobs_dev, njobs, total_blocks, &f, (hipStream_t)stream);
-    return clamd_fail("bn_fold_pack: form must be 0 (clamd_pack), 16 (clamd_wino_pack), 24 (clamd_wino24_pack) or 18 (clamd_wino41_pack)");
+    return clamd_fail("bn_fold_pack: form must be 0 (clamd_pack), 16 (clamd_wino_pack) or 24 (clamd_wino24_pack)");
 }
 
 int clamd_bn_fold_wgrad_pointwise(const float* sum_g, const float* scale, const float* shift, float* dw, int Cout, int Cin, void* stream) {

@@ -57,4 +57,3 @@ namespace clamd { struct FoldBias; }
 int clamd_launch_pack(const void* jobs_dev, int njobs, int total_blocks, int dtype, const clamd::FoldBias* fold, hipStream_t stream);
 int clamd_launch_wino_pack(const void* jobs_dev, int njobs, int total_blocks, const clamd::FoldBias* fold, hipStream_t stream);
 int clamd_launch_wino24_pack(const void* jobs_dev, int njobs, int total_blocks, const clamd::FoldBias* fold, hipStream_t stream);
-int clamd_launch_wino41_pack(const void* jobs_dev, int njobs, int total_blocks, const clamd::FoldBias* fold, hipStream_t stream);

@@ -42,7 +42,5 @@ int wino_band(long long tiles, long long slabs, double x_elems, double f_elems, 
 // wino24.hip
 long long clamd_winograd24_stat_rows(int B, int H, int W, int Cout_p, const clamd_tuning& tn);
 int launch_wino24(WinoParams p, const clamd_tuning& tn, int stat_rows, hipStream_t stream);
-// wino41.hip
-long long clamd_winograd41_stat_rows(int B, int H, int W, int Cout_p, const clamd_tuning& tn);
 
 }  // namespace clamd

@@ -76,7 +76,7 @@ void clamd_tuning_init(clamd_tuning* t);
  * Two runs on the same inputs are bit-identical.  The caller sizes the buffer with clamd_stat_rows() for the SAME
  * arguments it launches with and passes that row count to the launch (checked) and to the finalize call. */
 enum { CLAMD_OP_CONV3X3 = 0, CLAMD_OP_CONV3X3_WINOGRAD = 1, CLAMD_OP_CONV1X1 = 2, CLAMD_OP_CONVT2X2_DGRAD = 3,
-       CLAMD_OP_BN_BWD_REDUCE = 4, CLAMD_OP_CONV3X3_WINOGRAD24 = 5, CLAMD_OP_CONV3X3_WINOGRAD41 = 6 };
+       CLAMD_OP_BN_BWD_REDUCE = 4, CLAMD_OP_CONV3X3_WINOGRAD24 = 5 };
 /* rows a launch of `op` writes: (B,H,W) = pixel grid of the launch, Cin_p/Cout_p as passed to it (BN_BWD_REDUCE: Cout_p = Cp,
  * Cin_p != 0 means the pooled variant), fused_bn != 0 when bn_y/bn_sums are passed.  Negative on error. */
 int clamd_stat_rows(int op, int B, int H, int W, int Cin_p, int Cout_p, int dtype, int fused_bn, const clamd_tuning* tune);
@@ -177,16 +177,6 @@ int clamd_conv3x3_winograd24_pre(const float* v, const float* w_wino, const floa
 int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const float* w_wino, const float* bias, float* y, int y_ldc,
                                             float* stats, int stat_rows, int B, int H, int W,
                                             int Cin_p, int Cout_p, int relu, const clamd_tuning* tune, void* stream);
-/* ---- F(4,3) along the image row, the three kernel rows summed directly (wino41.hip): the NARROW 3x3 convolutions of
- * models/unet.py:49-55,66-72 (64 / 128 channels at levels 0-1) and their data gradients on the exact-fp32 path.  4.5 instead of 3
- * multiply-adds per output, but the input transform is shared by the kernel rows and by all waves: done once while staging, the K loop
- * is MFMAs and fragment reads only.  w41: [Cin_p/8][18 = 3 j + ky][Cout_p][8] from clamd_wino41_pack (jobs as clamd_wino_pack; form 18 of
- * clamd_bn_fold_pack).  W a multiple of 32 (clamd_conv3x3_winograd41_ok); relu bits as clamd_conv3x3 (bit 1: border-class bias table);
- * stat_rows = clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD41, ...).  Same results as clamd_conv3x3_winograd24 to fp32 rounding. */
-int clamd_wino41_pack(const void* jobs_dev, int njobs, int total_blocks, void* stream);
-int clamd_conv3x3_winograd41_ok(int B, int H, int W, int Cin_p, int Cout_p);
-int clamd_conv3x3_winograd41(const float* x, int x_ldc, const float* w41, const float* bias, float* y, int y_ldc, float* stats, int stat_rows,
-                             int B, int H, int W, int Cin_p, int Cout_p, int relu, const clamd_tuning* tune, void* stream);
 /* Weight gradient of the same convolution as a batched GEMM over the 24 Winograd planes (K = tiles) on operands transformed
  * once: v = the forward image of the convolution INPUT (clamd_winograd24_transform_input, kept from the forward pass: it is
  * read in place as the x-side operand), yt = caller-provided scratch of clamd_wgrad_winograd24_pre_operand_elems(B,H,W,Rp)

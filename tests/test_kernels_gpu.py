@@ -553,93 +553,6 @@ def test_conv3x3_winograd24_fp32(C, shape):
             np.testing.assert_allclose(stats2.double().sum(0).cpu().numpy(), stats.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
 
 
-W41_SHAPES = [  # B, Cin segs, Cout, H, W   (W a multiple of 32)
-    (2, [(64, 64)], 64, 32, 64),              # whole 16 x 32 tiles, the narrow-layer shape class
-    (1, [(40, 64)], 70, 24, 32),              # ragged height, padded channels on both sides, two output slabs with a ragged last one
-    (3, [(20, 32), (20, 32)], 32, 50, 96),    # concat input, a 32-channel slab (second block absent), more tiles than one round of a slab
-    (1, [(128, 128)], 128, 7, 64),            # image lower than a tile
-]
-
-
-@pytest.mark.parametrize('shape', W41_SHAPES, ids=lambda sh: f'{sh[0]}x{"+".join(str(a) for a, _ in sh[1])}->{sh[2]}@{sh[3]}x{sh[4]}')
-def test_conv3x3_winograd41_fp32(C, shape):
-    """F(4,3) along the row x three kernel rows summed directly (wino41.hip): forward (+bias, ReLU, statistics rows) and data gradient, fp32,
-    against the oracle's direct convolution at the 2e-5 bound of the other fp32 kernels; the border-class bias of a folded BatchNorm against
-    the convolution of the normalised tensor; bit-reproducible statistics rows; other grids give the same activations."""
-    B, segs, cout, H, W = shape
-    rng = np.random.default_rng(41)
-    cin = sum(s[0] for s in segs)
-    x = rnd(rng, B, cin, H, W)
-    w = rnd(rng, cout, cin, 3, 3) * (1.0 / np.sqrt(9 * cin))
-    b = rnd(rng, cout)
-    cin_p, cout_p = sum(s[1] for s in segs), C.ops.cpad(cout)
-    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
-    assert lib.load().clamd_conv3x3_winograd41_ok(B, H, W, cin_p, cout_p) == 1 and lib.load().clamd_conv3x3_winograd41_ok(B, H, 48, cin_p, cout_p) == 0
-    xt = nhwc_with_segs(C, x, segs, 0)
-    wt, bt = dev(w), dev(b)
-    wf = torch.zeros(18 * cout_p * cin_p, device='cuda')
-    wd = torch.zeros(18 * cin_p * cout_p, device='cuda')
-    bp = torch.zeros(cout_p, device='cuda')
-    tab = C.ops.WinoPackTable(18); tab.conv3x3(wt, wf, wd, segs, cout); tab.finalize('cuda').run()
-    pt = C.ops.PackTable(0); pt.vector(bt, bp, cout); pt.finalize('cuda').run(0)
-    y = torch.full((B, H, W, cout_p), 7.0, device='cuda')
-    stats, rows = stat_buf(C, lib.OP_CONV3X3_WINOGRAD41, B, H, W, cin_p, cout_p, 0)
-    lib.call('clamd_conv3x3_winograd41', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), rows, B, H, W, cin_p, cout_p, 1, None, s)
-    gz = rnd(rng, B, cout, H, W)
-    gzt = C.ops.to_nhwc(dev(gz), 0)
-    gx = torch.full((B, H, W, cin_p), 3.0, device='cuda')
-    lib.call('clamd_conv3x3_winograd41', ptr(gzt), cout_p, ptr(wd), None, ptr(gx), cin_p, None, 0, B, H, W, cout_p, cin_p, 0, None, s)
-    sync()
-    ref = O.relu_fwd(O.conv3x3_fwd(x, w, b))
-    assert rel_l2(C.ops.from_nhwc(y, cout, 0).cpu().numpy(), ref) < TOL[0]
-    st = stats.double().sum(0).cpu().numpy()
-    np.testing.assert_allclose(st[0, :cout], ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
-    np.testing.assert_allclose(st[1, :cout], (ref ** 2).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
-    assert float(y[..., cout:].abs().max()) == 0.0 if cout < cout_p else True
-    rgx = O.conv3x3_bwd(x, w, gz)[0]
-    pm = phys_map(segs)
-    got_gx = gx.cpu().numpy().transpose(0, 3, 1, 2)
-    assert rel_l2(got_gx[:, [p_ for p_, l in enumerate(pm) if l >= 0]], rgx) < TOL[0]
-    pad = [p_ for p_, l in enumerate(pm) if l < 0]
-    assert not pad or float(np.abs(got_gx[:, pad]).max()) == 0.0
-    # without ReLU / statistics (and against the F(2x4) kernel where that one applies: the same sums in another order)
-    y_lin = torch.full((B, H, W, cout_p), 7.0, device='cuda')
-    lib.call('clamd_conv3x3_winograd41', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y_lin), cout_p, None, 0, B, H, W, cin_p, cout_p, 0, None, s)
-    sync()
-    assert rel_l2(C.ops.from_nhwc(y_lin, cout, 0).cpu().numpy(), O.conv3x3_fwd(x, w, b)) < TOL[0]
-    # reproducible rows; another grid (fewer CUs): same activations, same totals
-    stats2 = torch.full_like(stats, float('nan'))
-    y2 = torch.full_like(y, 9.0)
-    lib.call('clamd_conv3x3_winograd41', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y2), cout_p, ptr(stats2), rows, B, H, W, cin_p, cout_p, 1, None, s)
-    tn = lib.Tuning(cu_reserve=101)
-    stats3, rows3 = stat_buf(C, lib.OP_CONV3X3_WINOGRAD41, B, H, W, cin_p, cout_p, 0, tuning=tn)
-    y3 = torch.full_like(y, 9.0)
-    lib.call('clamd_conv3x3_winograd41', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y3), cout_p, ptr(stats3), rows3, B, H, W, cin_p, cout_p, 1, tn.ref(), s)
-    sync()
-    assert torch.equal(stats, stats2) and torch.equal(y, y2) and torch.equal(y, y3)
-    np.testing.assert_allclose(stats3.double().sum(0).cpu().numpy(), stats.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
-    with pytest.raises(RuntimeError, match='stat_rows'):
-        lib.call('clamd_conv3x3_winograd41', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y2), cout_p, ptr(stats2), rows + 1, B, H, W, cin_p, cout_p, 1, None, s)
-    # BatchNorm of the producer folded in: filters x scale (form 18 of clamd_bn_fold_pack) + border-class bias table, against the fp64
-    # convolution of the normalised tensor (zero padding AFTER the affine, as nn.Conv2d pads)
-    if len(segs) == 1 and H >= 2:
-        scale = (rng.uniform(0.5, 1.5, cin) * np.where(rng.random(cin) < 0.3, -1, 1)).astype(np.float32)
-        shift = rnd(rng, cin)
-        sc_p, sh_p = torch.zeros(cin_p, device='cuda'), torch.zeros(cin_p, device='cuda')
-        sc_p[:cin], sh_p[:cin] = dev(scale), dev(shift)
-        ft = C.ops.WinoPackTable(18); ft.conv3x3(wt, wf, None, segs, cout, kscale=sc_p); ft.finalize('cuda')
-        table = torch.zeros(9, cout_p, device='cuda')
-        lib.call('clamd_bn_fold_pack', 18, ptr(ft.dev_table), len(ft.jobs), ft.nblocks, 0, ptr(wt), 9, ptr(sh_p), ptr(bt), ptr(table), cout, cin, cout_p, s)
-        yf = torch.full_like(y, 5.0)
-        statsf = torch.full_like(stats, float('nan'))
-        lib.call('clamd_conv3x3_winograd41', ptr(xt), cin_p, ptr(wf), ptr(table), ptr(yf), cout_p, ptr(statsf), rows, B, H, W, cin_p, cout_p, 3, None, s)
-        sync()
-        xn = x.astype(np.float64) * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
-        reff = O.relu_fwd(O.conv3x3_fwd(xn, w.astype(np.float64), b.astype(np.float64)))
-        assert rel_l2(C.ops.from_nhwc(yf, cout, 0).cpu().numpy(), reff) < 3e-5
-        np.testing.assert_allclose(statsf.double().sum(0).cpu().numpy()[0, :cout], reff.sum((0, 2, 3)), rtol=2e-4, atol=2e-3)
-
-
 FOLD_SHAPES = [  # B, Cin, Cout, H, W
     (2, 64, 64, 24, 40),       # 8x32 tiles ragged along x: every tile touches the border
     (1, 128, 128, 16, 16),     # one 16x16 tile per image: all nine border classes inside one tile
