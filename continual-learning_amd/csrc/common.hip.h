@@ -179,7 +179,7 @@ __device__ inline uint4 buf_ld16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsig
 // The data registers of a 16-byte store must not be rewritten by the very next vector instructions: the store reads them dword by dword
 // after it has issued.  hipcc inserts the wait state only for stores WITHOUT an SGPR offset (GCNHazardRecognizer: "no hazard if soffset is
 // a register"); on gfx950 a packed fma that rewrote dwords 2-3 one instruction behind such a store corrupted them in lanes 12-15 / 28-31 of
-// each half-wave (wino41.hip, round 4: wrong .w components, found by a kernel parity test).  The asm keeps the four registers alive -- tied
+// each half-wave (the 1-D Winograd experiment of round 4, in the git history: wrong .w components, found by its kernel parity test).  The asm keeps the four registers alive -- tied
 // in and out -- until two wait states behind the store.
 __device__ inline void buf_st16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const uint4& v) {
     u32x4 d; d.x = v.x; d.y = v.y; d.z = v.z; d.w = v.w;

@@ -43,10 +43,49 @@ def init_rccl(device, max_channels=RCCL_MAX_CHANNELS, **kw):
     return rccl_settings()
 
 
+_HW_QUEUES = {}
+
+
+def hw_queues(device, upto=8):
+    """Hardware queues this process's HIP streams are multiplexed onto, MEASURED (GPU_MAX_HW_QUEUES is read by the runtime when it starts: a
+    value exported later, or by a caller that initialised HIP first, is not what runs).  `upto` fresh streams each get one spin kernel of the
+    same length; kernels that share a hardware queue run one after the other, so wall time / single-kernel time = streams per queue.
+    ~1 ms, once per device and process."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key in _HW_QUEUES:
+        return _HW_QUEUES[key]
+    with torch.cuda.device(key):
+        cycles = 400_000
+        streams = [torch.cuda.Stream(device=device) for _ in range(upto)]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(streams[0]):      # one kernel alone: the unit
+            torch.cuda._sleep(cycles); torch.cuda._sleep(cycles)      # (the first launch of the kernel includes its load)
+            e0.record(); torch.cuda._sleep(cycles); e1.record()
+        torch.cuda.synchronize()
+        unit = e0.elapsed_time(e1)
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cur = torch.cuda.current_stream()
+        b0.record(cur)
+        for st in streams:
+            st.wait_event(b0)
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(cycles)
+        for st in streams:
+            cur.wait_stream(st)
+        b1.record(cur)
+        torch.cuda.synchronize()
+        per_queue = max(1, round(b0.elapsed_time(b1) / max(unit, 1e-6)))      # streams that shared the busiest queue
+        n = max(1, min(upto, -(-upto // per_queue)))
+    _HW_QUEUES[key] = n
+    return n
+
+
 def rccl_settings():
     return {'backend': dist.get_backend() if dist.is_initialized() else None,
             'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS'), 'NCCL_MIN_NCHANNELS': os.environ.get('NCCL_MIN_NCHANNELS'),
-            'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES')}
+            'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES'),
+            'hw_queues_measured': (hw_queues(torch.device('cuda', torch.cuda.current_device())) if torch.cuda.is_available() and torch.cuda.is_initialized() else None)}
 
 
 class GradSync:
@@ -93,6 +132,17 @@ class GradSync:
             cu_reserve = int(os.environ['CLAMD_CU_RESERVE'])
         if cu_reserve is not None:          # otherwise whatever the user set on model.tuning stays
             model.tuning.cu_reserve = max(0, min(128, int(cu_reserve)))
+        # a rank uses five streams (default, the engine's second and third, this object's, RCCL's own): with fewer hardware queues some
+        # share one, and a kernel waits behind whatever shares its queue -- measured, not read from the environment
+        self.hw_queues = None
+        p0 = next(iter(model.parameters()), None)
+        if p0 is not None and p0.is_cuda:
+            self.hw_queues = hw_queues(p0.device)
+            if self.hw_queues < 5 and self.world > 1:
+                import warnings
+                warnings.warn(f'continual-learning_amd.ddp: the HIP runtime multiplexes streams onto {self.hw_queues} hardware queues; the gradient '
+                              'all-reduce will share a queue with a compute stream and serialise behind it.  Export GPU_MAX_HW_QUEUES=8 BEFORE the '
+                              'process makes its first HIP call (ddp.init_rccl does when it can; bench.py does at import time).')
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
             optimizer.pre_step_hooks.append(self.wait)

@@ -1026,16 +1026,15 @@ class _Engine:
         return [gf[o:o + k].view(self.gshape[n]) for n, (o, k) in ((n, self.goffset[n]) for n in self.param_names)]
 
     def _x3_allowed(self):
-        """The third stream only where it cannot end up on a hardware queue with RCCL's kernels: HIP multiplexes streams onto
-        GPU_MAX_HW_QUEUES queues (4 by default) and a kernel waits behind whatever shares its queue.  A data-parallel rank has the default
-        stream, the second and third streams, GradSync's stream and RCCL's: five -- so under ddp.GradSync the third stream needs the 8 queues
-        bench.py / ddp.init_rccl set before the runtime starts."""
+        """The third stream only where it cannot end up on a hardware queue with RCCL's kernels: HIP multiplexes streams onto a fixed number of
+        hardware queues in creation order and a kernel waits behind whatever shares its queue.  A data-parallel rank has the default stream,
+        the second and third streams, GradSync's stream and RCCL's: five -- so under ddp.GradSync the third stream needs at least eight queues
+        (two rounds of the assignment apart).  The count is MEASURED (ddp.hw_queues: spin kernels on eight streams), not read from
+        GPU_MAX_HW_QUEUES -- the runtime reads that variable once, when it starts."""
         if self.model.grad_sync is None:
             return True
-        try:
-            return int(os.environ.get('GPU_MAX_HW_QUEUES', '4')) >= 8
-        except ValueError:
-            return False
+        from . import ddp
+        return ddp.hw_queues(self.dev) >= 8
 
     def _fuse_sums(self, b):
         """Does the data-gradient launch of conv `b` (3x3, K = b.cout_p gradient channels) also reduce the BN-backward sums

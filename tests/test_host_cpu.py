@@ -4,6 +4,7 @@ packing tables are consistent.  No kernel is launched here (there is no GPU in t
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -294,3 +295,16 @@ def test_no_test_function_is_shadowed():
         names = re.findall(r'^def (test_\w+)\(', open(f).read(), flags=re.M)
         dup = [n for n, c in collections.Counter(names).items() if c > 1]
         assert not dup, f'{os.path.basename(f)}: defined more than once: {dup}'
+
+
+def test_bench_step_traffic_reads_the_committed_profile():
+    """bench.py's driver line carries HBM bytes per step (committed PMC profile of the same workload) beside SURVEY §8d's algorithmic bytes."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for dtype, e in (('fp32', 4), ('bf16', 2), ('bf16x3', 4)):
+        t = bench.step_traffic(dtype, 256, 16, 64)
+        assert t is not None and os.path.exists(os.path.join(ROOT, t['traffic_source']))
+        assert t['algorithmic_bytes_per_step'] == int(16 * 250e6 * e + 31_044_821 * 28 + 3 * 31_044_821 * e)
+        assert abs(t['hbm_over_algorithmic'] - t['hbm_bytes_per_step'] / t['algorithmic_bytes_per_step']) < 1e-3
+        assert 1.0 < t['hbm_over_algorithmic'] < 6.0
+    assert bench.step_traffic('fp32', 128, 16, 64) is None          # no profile of that workload: nothing invented

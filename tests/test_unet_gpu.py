@@ -68,9 +68,10 @@ def test_train_steps_vs_reference_golden(C, golden, fixture, nc, cd, size, dtype
         if s == 0:
             lg = out.detach().cpu().numpy()
             assert lg.shape == (2, nc, size, size)
-            tol = 1e-3 if fp32 else 0.15
+            # bf16: measured 2.35e-2 / 1.98e-2 rel L2 and 3.9e-2 / 2.8e-2 max rel on the two fixtures (round 4, -s prints them): bounds <= 2x
+            tol, tolm = (1e-3, 1e-3) if fp32 else (4.5e-2, 7.5e-2)
             print(f'measured[{fixture} {dtype}]: logits rel L2 {rel_l2(lg, g["logits"]):.3e}, max rel {maxrel(lg, g["logits"]):.3e}')
-            assert rel_l2(lg, g['logits']) < tol and maxrel(lg, g['logits']) < tol * (1 if fp32 else 2)
+            assert rel_l2(lg, g['logits']) < tol and maxrel(lg, g['logits']) < tolm, (rel_l2(lg, g['logits']), maxrel(lg, g['logits']))
             gn = np.array([float(p.grad.double().norm()) for p in model.parameters()])
             # These toy models normalise over as few as 8 samples at the deepest level (2x2 spatial, batch 2), which
             # amplifies rounding differences by ~10^2-10^3; the full-size test below holds every tensor to 5e-3.
@@ -133,9 +134,10 @@ def test_config1_exact_vs_reference_golden(C, golden, dtype):
         out = model(x); opt.zero_grad(); loss = crit(out, y); loss.backward()
         if s == 0:
             lg = out.detach().cpu().numpy()
-            tol = 1e-3 if fp32 else 6e-2
+            # bf16: measured 2.27e-2 rel L2, 2.84e-2 max rel (round 4): bounds <= 2x
+            tol, tolm = (1e-3, 1e-3) if fp32 else (4.5e-2, 5.5e-2)
             print(f'measured[config1 {dtype}]: logits rel L2 {rel_l2(lg, g["logits"]):.3e}, max rel {maxrel(lg, g["logits"]):.3e}')
-            assert rel_l2(lg, g['logits']) < tol and maxrel(lg, g['logits']) < tol * (1 if fp32 else 2)
+            assert rel_l2(lg, g['logits']) < tol and maxrel(lg, g['logits']) < tolm, (rel_l2(lg, g['logits']), maxrel(lg, g['logits']))
             gn = np.array([float(p.grad.double().norm()) for p in model.parameters()])
             big = g['grad_norms'] > 1e-4 * g['grad_norms'].max()
             np.testing.assert_allclose(gn[big], g['grad_norms'][big], rtol={'fp32': 1e-2, 'bf16x3': 3e-2, 'bf16': 0.4}[dtype])
