@@ -44,40 +44,36 @@ def init_rccl(device, max_channels=RCCL_MAX_CHANNELS, **kw):
 
 
 _HW_QUEUES = {}
+_HW_PROBE = {}        # device -> (wall us of the eight-stream probe, us of one kernel): what hw_queues() decided from
 
 
 def hw_queues(device, upto=8):
     """Hardware queues this process's HIP streams are multiplexed onto, MEASURED (GPU_MAX_HW_QUEUES is read by the runtime when it starts: a
     value exported later, or by a caller that initialised HIP first, is not what runs).  `upto` fresh streams each get one spin kernel of the
-    same length; kernels that share a hardware queue run one after the other, so wall time / single-kernel time = streams per queue.
-    ~1 ms, once per device and process."""
+    same length (clamd_debug_hold_cus: one workgroup spinning on the wall clock); kernels that share a hardware queue run one after the other,
+    so wall time / kernel time = streams per queue.  ~4 ms, once per device and process."""
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key in _HW_QUEUES:
         return _HW_QUEUES[key]
+    import time
+    from . import _lib
+    hold_us = 400
     with torch.cuda.device(key):
-        cycles = 400_000
         streams = [torch.cuda.Stream(device=device) for _ in range(upto)]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        with torch.cuda.stream(streams[0]):      # one kernel alone: the unit
-            torch.cuda._sleep(cycles); torch.cuda._sleep(cycles)      # (the first launch of the kernel includes its load)
-            e0.record(); torch.cuda._sleep(cycles); e1.record()
-        torch.cuda.synchronize()
-        unit = e0.elapsed_time(e1)
-        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        cur = torch.cuda.current_stream()
-        b0.record(cur)
-        for st in streams:
-            st.wait_event(b0)
-            with torch.cuda.stream(st):
-                torch.cuda._sleep(cycles)
-        for st in streams:
-            cur.wait_stream(st)
-        b1.record(cur)
-        torch.cuda.synchronize()
-        per_queue = max(1, round(b0.elapsed_time(b1) / max(unit, 1e-6)))      # streams that shared the busiest queue
+        _lib.call('clamd_debug_hold_cus', 1, 10, streams[0].cuda_stream)       # loads the kernel
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for st in streams:                   # one workgroup each, spinning on the wall clock for hold_us: nothing to contend for but the queue
+                _lib.call('clamd_debug_hold_cus', 1, hold_us, st.cuda_stream)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) * 1e6
+            best = dt if best is None else min(best, dt)
+        per_queue = max(1, min(upto, int(best / hold_us + 0.35)))      # streams behind one another on the busiest queue (launch + sync overhead: < 0.3 of a kernel)
         n = max(1, min(upto, -(-upto // per_queue)))
     _HW_QUEUES[key] = n
+    _HW_PROBE[key] = (round(best, 1), hold_us)
     return n
 
 

@@ -109,12 +109,14 @@ def test_hardware_queue_count_is_measured():
     engine's third stream and GradSync's warning depend on it; GPU_MAX_HW_QUEUES is only read when the runtime starts).  Two processes, the
     variable set to 2 and to 8 before HIP starts: the measurement follows."""
     code = ("import torch, continual_learning_amd as C; from continual_learning_amd import ddp; "
-            "print('Q', ddp.hw_queues(torch.device('cuda', 0)))")
+            "print('Q', ddp.hw_queues(torch.device('cuda', 0)), ddp._HW_PROBE)")
     got = {}
     for q in ('2', '8'):
         env = dict(os.environ, GPU_MAX_HW_QUEUES=q)
         out = subprocess.run([sys.executable, '-c', code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
-        got[q] = int([l for l in out.stdout.splitlines() if l.startswith('Q ')][-1].split()[1])
+        line = [l for l in out.stdout.splitlines() if l.startswith('Q ')][-1]
+        print(q, line)
+        got[q] = int(line.split()[1])
     print(got)
     assert got['2'] <= 2 < got['8'], got

@@ -41,7 +41,7 @@ for dt in fp32 bf16; do
   timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${tag}_gaps_$dt -o g -- python3 bench.py --steps 4 --warmup 1 --dtype $dt --no-cpu-baseline --no-parity --also "" --no-kernel-timing > gpurun_out/${tag}_gaps_$dt.json 2> gpurun_out/${tag}_gaps_$dt.err || exit 6
   python tools/trace_gaps.py gpurun_out/${tag}_gaps_$dt/g_kernel_trace.csv 2 24 > gpurun_out/${tag}_trace_gaps_$dt.txt
 done
-for a in "bf16 8" "fp32 8" "bf16x3 8"; do GPU_MAX_HW_QUEUES=8 timeout -k 10 200 python tools/cu_steal.py $a 2>/dev/null | grep '^{' >> gpurun_out/${tag}_cu_steal.jsonl || exit 5; done
+for a in "bf16 8" "fp32 8" "bf16x3 8" "bf16 16" "fp32 16"; do GPU_MAX_HW_QUEUES=8 timeout -k 10 200 python tools/cu_steal.py $a 2>/dev/null | grep '^{' >> gpurun_out/${tag}_cu_steal.jsonl || exit 5; done
 python tools/layer_table.py fp32 > gpurun_out/${tag}_layers_fp32.txt 2>/dev/null
 python tools/layer_table.py bf16 > gpurun_out/${tag}_layers_bf16.txt 2>/dev/null
 python tools/layer_table.py bf16x3 > gpurun_out/${tag}_layers_bf16x3.txt 2>/dev/null
