@@ -19,6 +19,11 @@
 #ifndef PWS_EPW
 #define PWS_EPW 68
 #endif
+#if defined(PWS_ABLATE_EPI) && PWS_ABLATE_EPI == 3     // timing ablation (wrong results): no statistics in the channels-in-the-lane epilogue
+#define PWS_ABLATE_STATS true
+#else
+#define PWS_ABLATE_STATS false
+#endif
 namespace clamd {
 
 #ifdef CLAMD_DIAG
@@ -326,6 +331,13 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             d2 = PWD_T();
 
             // ---- epilogue: a lane owns the pixel of its column; registers 8q .. 8q+7 of block nt are 16 bytes of the output
+#if defined(PWS_ABLATE_EPI) && PWS_ABLATE_EPI == 1     // timing ablation (tools/pws_epi_ablate.sh, wrong results): no epilogue at all
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(acc[i][j]));
+            continue;
+#endif
             const __amdgpu_buffer_rsrc_t yrs = make_rsrc((const char*)p.y + (size_t)b * y_img, y_img);
             const unsigned y_so = (unsigned)((y0 * p.W + x0) * p.y_ldc) * 2u;
             bool border = false;
@@ -357,7 +369,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                     float v[16];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) v[e] = CLM == 2 ? vmax_f32(acc[mt][nt][e], relu_lo) : acc[mt][nt][e];
-                    if constexpr (CLM == 2) {
+                    if constexpr (CLM == 2 && !PWS_ABLATE_STATS) {
                         if (p.stats) {                     // wave-uniform
 #pragma unroll
                             for (int e = 0; e < 16; ++e) {
@@ -382,10 +394,20 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                         }
                     }
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        buf_st16(yrs, vo + (unsigned)(64 * nt + 32 * q), y_so,
-                                 make_uint4(pack2bf(v[8 * q + 0], v[8 * q + 1]), pack2bf(v[8 * q + 2], v[8 * q + 3]),
-                                            pack2bf(v[8 * q + 4], v[8 * q + 5]), pack2bf(v[8 * q + 6], v[8 * q + 7])));
+                    for (int q = 0; q < 2; ++q) {
+                        const uint4 o_ = make_uint4(pack2bf(v[8 * q + 0], v[8 * q + 1]), pack2bf(v[8 * q + 2], v[8 * q + 3]),
+                                                    pack2bf(v[8 * q + 4], v[8 * q + 5]), pack2bf(v[8 * q + 6], v[8 * q + 7]));
+#if defined(PWS_ABLATE_EPI) && PWS_ABLATE_EPI == 2     // timing ablation (wrong results): everything but the global stores
+                        asm volatile("" :: "v"(o_.x), "v"(o_.y), "v"(o_.z), "v"(o_.w));
+#elif defined(PWS_ABLATE_EPI) && PWS_ABLATE_EPI == 4   // timing ablation (wrong results): the store PATTERN of an exchanged epilogue (8 full 128-byte lines per instruction)
+                        {
+                            const int m4_ = 32 * MT * cw + 32 * mt + (lane >> 3) + 8 * (2 * nt + q);
+                            buf_st16(yrs, (unsigned)(((m4_ / TW) * p.W + m4_ % TW) * p.y_ldc + n0 + 8 * (lane & 7)) * 2u, y_so, o_);
+                        }
+#else
+                        buf_st16(yrs, vo + (unsigned)(64 * nt + 32 * q), y_so, o_);
+#endif
+                    }
                 }
             }
             de += PWD_T() - d2;
