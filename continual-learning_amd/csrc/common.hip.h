@@ -111,21 +111,9 @@ template <> struct Vec8<split_t> {
     }
 };
 
-#ifdef MFMA16_ABLATE
-// TIMING ABLATION (wrong results, never shipped): the same FLOP issued as two v_mfma_f32_16x16x32_bf16 on the same operand registers.  On
-// real data the chip is power-limited and the 16x16x32 form sustains a higher clock (tools/ubench/mfma_shapes.hip: 1.96 vs 1.74 PFLOP/s).
-typedef float f32x4_ __attribute__((ext_vector_type(4)));
-__device__ inline void mma_bf16(const uint4& a, const uint4& b, f32x16& acc) {
-    f32x4_ q0 = {acc[0], acc[1], acc[2], acc[3]}, q1 = {acc[4], acc[5], acc[6], acc[7]};
-    q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), q0, 0, 0, 0);
-    q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), q1, 0, 0, 0);
-    acc[0] = q0[0]; acc[1] = q0[1]; acc[2] = q0[2]; acc[3] = q0[3]; acc[4] = q1[0]; acc[5] = q1[1]; acc[6] = q1[2]; acc[7] = q1[3];
-}
-#else
 __device__ inline void mma_bf16(const uint4& a, const uint4& b, f32x16& acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
-#endif
 
 template <typename T> __device__ inline float ld1(const T* p);
 template <> __device__ inline float ld1<float>(const float* p) { return *p; }
@@ -223,12 +211,6 @@ __device__ inline float vmax_f32(float a, float b) {
 
 // Row of accumulator register `reg` (0..15) for lane half h in a 32x32 MFMA tile; column = lane & 31.
 __device__ inline int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
-// v_mfma_f32_16x16x32_bf16 fragments read with ds_read_b128 from a [16-byte plane][row] LDS image (lane = row x + 16 * plane): the position,
-// inside its block of 16, that logical MFMA row / column x stands for.  x in 4..11 -> the even positions, the others -> the odd ones: every
-// 16-lane group the hardware serves a ds_read_b128 in ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...) then takes the odd positions of one
-// plane and the even positions of the next -- 16 different 16-byte slots of the 256-byte bank row whenever the plane pitch is even.
-__device__ inline int pi16(int x) { return (x >= 4 && x < 12) ? 2 * (x - 4) : (x < 4 ? 2 * x + 1 : 2 * (x - 12) + 9); }
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- XCD-aware block remap (8 XCDs, blocks dealt round-robin): give each XCD a contiguous id range so
 // neighbouring tiles share that XCD's L2.  Bijective for any grid size.  Speed only, never correctness.

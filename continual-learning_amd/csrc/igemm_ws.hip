@@ -59,18 +59,6 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    // bf16 (M16): the same wave block as 16x16 MFMA tiles -- acc4[i][j] = pixels 16 i + pi16(4 rg + e) x channel 16 j + pi16(c16) in lane
-    // (c16 = lane & 15, rg = lane >> 4); see the consumer loop
-    constexpr bool M16 = __is_same(T, bf16_t);
-    constexpr int NI = 2 * MT;
-    f32x4 acc4[M16 ? NI : 1][4];
-#pragma unroll
-    for (int i = 0; i < (M16 ? NI : 1); ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc4[i][j][e] = 0.f;
-    const int c16 = lane & 15, rg = lane >> 4;
 
     if (producer) {
         // ------------------------------------------------------------------ producers: global -> registers -> LDS
@@ -196,15 +184,6 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
             const int m = 32 * MT * cw + 32 * mt + r;
             apix[mt] = (m / TW) * HW_ + (m % TW);
         }
-        int apix4[M16 ? NI : 1];                           // M16: LDS pixel slot behind MFMA row c16 of the wave's i-th 16-pixel block
-        const int wrow = pi16(c16);                        //      filter row (inside a block of 16) behind MFMA column c16
-        if constexpr (M16) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int m = 32 * MT * cw + 16 * i + pi16(c16);
-                apix4[i] = (m / TW) * HW_ + (m % TW);
-            }
-        }
         unsigned long long c0, c1, d_cmp = 0, d_cbar = 0;
         c0 = DIAG_T();
         __syncthreads();                                   // stage 0 is ready
@@ -212,53 +191,7 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
         for (int ks = 0; ks < nk; ++ks) {
             c0 = DIAG_T();
             const uint4* sm = smem + (ks & 1) * STAGE;
-            if constexpr (M16) {
-                // v_mfma_f32_16x16x32_bf16: one MFMA contracts the WHOLE 32-channel K-step (the four 16-byte planes of the LDS image: lane
-                // (c16, kg = lane >> 4) reads plane kg) for a 16-pixel x 16-channel block.  On real data the chip is power-limited and this
-                // form sustains a higher clock than 32x32x16 (tools/ubench/mfma_shapes.hip: 1.96-2.13 against 1.74-1.91 PFLOP/s in bare
-                // loops; this kernel 8-10 % faster).  Logical MFMA row / column x stands for pixel / filter row pi16(x) of its block of 16:
-                // the four 16-lane groups a ds_read_b128 is served in then hit 16 different 16-byte bank slots (odd positions in one plane,
-                // even ones in the next; the plane pitches are even), as the (r, h) fragments of the 32x32 form do.
-                // Per tap: NI pixel fragments + 4 filter fragments for 4 NI MFMAs.  The filter fragments are double-buffered per tap, the
-                // pixel fragments a ring of four, fetched two 16-pixel blocks ahead.
-                constexpr int Q = NT * NI;                       // 16-pixel blocks x taps of this K-step
-#ifndef WS_M16_DIST
-#define WS_M16_DIST 2
-#endif
-                constexpr int DIST = WS_M16_DIST, RING = DIST <= 3 ? 4 : 8;
-                uint4 fa[RING], fb[2][4];
-#define WS_PIXF(q_) sm[(((q_) / NI) / 3) * HW_ + (((q_) / NI) % 3) + rg * NPIXP + apix4[(q_) % NI]]
-#define WS_FILF(t_, j_) sm[G::IN_SLOTS + ((t_) * 4 + rg) * G::WG + 16 * (j_) + wrow]
-#pragma unroll
-                for (int j = 0; j < 4; ++j) fb[0][j] = WS_FILF(0, j);
-#pragma unroll
-                for (int q = 0; q < DIST; ++q) fa[q] = WS_PIXF(q);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4 + DIST, 0);
-#pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    const int t = q / NI, i = q % NI;
-                    int nr = 0;
-                    if (q + DIST < Q) { fa[(q + DIST) & (RING - 1)] = WS_PIXF(q + DIST); ++nr; }
-                    if (t + 1 < NT) {                         // the next tap's filter fragments, spread over this tap's blocks
-                        constexpr int PER = (4 + NI - 1) / NI;
-#pragma unroll
-                        for (int jj = 0; jj < PER; ++jj) {
-                            const int j = i * PER + jj;
-                            if (j < 4) { fb[(t + 1) & 1][j] = WS_FILF(t + 1, j); ++nr; }
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[q & (RING - 1)]), __builtin_bit_cast(bf16x8, fb[t & 1][j]),
-                                                                             acc4[i][j], 0, 0, 0);
-                    if (nr == 3) sched_mfma_reads<4, 3>();
-                    else if (nr == 2) sched_mfma_reads<4, 2>();
-                    else if (nr == 1) sched_mfma_reads<4, 1>();
-                    else __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                }
-#undef WS_PIXF
-#undef WS_FILF
-            } else if constexpr (SPLIT) {
+            if constexpr (SPLIT) {
                 uint4 f[2][2 * MT + 4];      // [buffer][a_hi[mt], a_lo[mt] ..., bh0, bl0, bh1, bl1]
 #define WS_FRAG_S(t_, d_)                                                                                         \
     do {                                                                                                          \
@@ -334,33 +267,6 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
         bcol[nt] = (p.bias && n < p.Np) ? p.bias[n] : 0.f;
     }
     unsigned long long vmask = 0;
-    if constexpr (M16) {
-        // the same steps on the 16x16 accumulators: lane (c16, rg) holds, for block (i, j), pixels 16 i + pi16(4 rg + e) of the wave's rows and
-        // channel 16 j + pi16(c16) of the slab
-        float bc4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + 16 * j + pi16(c16);
-            bc4[j] = (p.bias && n < p.Np) ? p.bias[n] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = 32 * MT * cw + 16 * i + pi16(4 * rg + e);
-                if (y0 + m / TW < p.H && x0 + m % TW < p.W) vmask |= 1ull << (i * 4 + e);
-            }
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc4[i][j][e] + bc4[j];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    acc4[i][j][e] = v;
-                }
-    } else {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -378,37 +284,10 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
                 if (p.relu) v = fmaxf(v, 0.f);
                 acc[mt][nt][e] = v;
             }
-    }
     float* ebuf = reinterpret_cast<float*>(smem);     // the last loop barrier released both stages
     if (p.stats) {
         float* sbuf = ebuf + 4 * 32 * 68;
-        if constexpr (M16) {
-            if (cons) {
-                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float v = (vmask >> (i * 4 + e)) & 1 ? acc4[i][j][e] : 0.f;
-                            s1[j] += v;
-                            s2[j] += v * v;
-                        }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s1[j] += __shfl_xor(s1[j], 16); s1[j] += __shfl_xor(s1[j], 32);
-                    s2[j] += __shfl_xor(s2[j], 16); s2[j] += __shfl_xor(s2[j], 32);
-                }
-                if (rg == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        sbuf[(cw * 2 + 0) * 64 + 16 * j + pi16(c16)] = s1[j];
-                        sbuf[(cw * 2 + 1) * 64 + 16 * j + pi16(c16)] = s2[j];
-                    }
-                }
-            }
-        } else if (cons) {
+        if (cons) {
             float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -453,19 +332,10 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
     for (int mt = 0; mt < MT; ++mt) {
         __syncthreads();
         if (cons) {
-            if constexpr (M16) {
-#pragma unroll
-                for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) wbuf[(16 * i2 + pi16(4 * rg + e)) * 68 + 16 * j + pi16(c16)] = acc4[M16 ? 2 * mt + i2 : 0][j][e];
-            } else {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) wbuf[acc_row(e, h) * 68 + 32 * nt + r] = acc[mt][nt][e];
-            }
         }
         __syncthreads();
         if (cons) {
