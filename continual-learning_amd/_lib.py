@@ -122,7 +122,7 @@ SIGNATURES = {
 }
 
 # include/clamd_debug.h: measurement scaffolding (tools/cu_steal.py), bound when present, never part of the product header
-DEBUG_SIGNATURES = {'clamd_debug_hold_cus': (_I, [_I, _I, _P])}
+DEBUG_SIGNATURES = {'clamd_debug_hold_cus': (_I, [_I, _I, _P]), 'clamd_debug_mfma_rate': (_LL, [_I, _I, _P, _P])}
 
 _lib = None
 

@@ -572,6 +572,53 @@ __global__ void __launch_bounds__(256) hold_cus_kernel(unsigned long long ticks,
     if (ticks == ~0ull && sink) sink[0] = pad[threadIdx.x];       // never true: keeps the LDS allocation alive
 }
 
+// Calibration loop for bench.py: the rate the matrix pipes SUSTAIN on pseudo-random operands (registers only, one wave per SIMD, every CU).
+// bf16 MFMA loops on real data are power-limited on MI355X -- 1.7-1.9 PFLOP/s against the 2.5 PFLOP/s the clock-times-width peak promises
+// (tools/ubench/mfma_shapes.hip) -- so a kernel's fraction of the nominal peak understates how close to the attainable rate it runs.
+__device__ inline unsigned mix32(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+template <bool BF16>
+__global__ void __launch_bounds__(256) mfma_rate_kernel(float* sink, int iters) {
+    uint4 a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned hsh = mix32(threadIdx.x * 64u + j * 8u + e + blockIdx.x * 7919u);
+            const float v = ((int)(hsh & 0xffffu) - 32768) * (1.f / 32768.f);
+            w[e] = BF16 ? (unsigned)f2bf(v) | ((unsigned)f2bf(-v * 0.37f) << 16) : __float_as_uint(v);
+        }
+        a[j] = make_uint4(w[0], w[1], w[2], w[3]);
+        b[j] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)              // 32 MFMAs per iteration and wave
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (BF16) mma_bf16(a[(i + u) & 3], b[(j + 2 + u) & 3], acc[i][j]);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[(i + u) & 3].x), __uint_as_float(b[(j + 2 + u) & 3].y), acc[i][j], 0, 0, 0);
+                }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+    sink[blockIdx.x * 256 + threadIdx.x] = t;
+}
+
 // gradient exchange in bf16 (ddp.GradSync(grad_dtype='bf16'), BASELINE.json configs[2]/[4] "bf16 DDP"): a bucket of the flat
 // fp32 gradient buffer is rounded to bf16 (rne) for the all-reduce and widened back afterwards.  A bucket starts at an
 // arbitrary element of the flat buffer: `head` leading elements are converted one by one, the aligned body 8 per thread and
@@ -776,6 +823,14 @@ int clamd_scale_by_device_scalar(float* p, long long n, const float* scale_dev, 
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(scale_by_dev_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p, n, scale_dev);
     return clamd_check_launch("scale_by_device_scalar");
+}
+
+long long clamd_debug_mfma_rate(int dtype, int iters, float* sink_65536, void* stream) {
+    if (iters < 1 || iters > (1 << 20) || !sink_65536) { clamd_fail("debug_mfma_rate: 1..2^20 iterations and a sink of 65536 floats"); return -1; }
+    if (dtype == CLAMD_F32) hipLaunchKernelGGL(mfma_rate_kernel<false>, dim3(256), dim3(256), 0, (hipStream_t)stream, sink_65536, iters);
+    else hipLaunchKernelGGL(mfma_rate_kernel<true>, dim3(256), dim3(256), 0, (hipStream_t)stream, sink_65536, iters);
+    if (clamd_check_launch("debug_mfma_rate")) return -1;
+    return 256ll * 4 * iters * 32 * (dtype == CLAMD_F32 ? 4096 : 32768);      // FLOP of the launch
 }
 
 int clamd_debug_hold_cus(int ncus, int usec, void* stream) {
