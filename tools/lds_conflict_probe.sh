@@ -1,6 +1,8 @@
+# LDS bank conflicts of the conv3x3 kernel by counters: rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS on tools/conv_ab.py (one
+# deep layer), default build against a variant build (second argument of the loop below); per-kernel sums.   bash tools/lds_conflict_probe.sh
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export CONV_LAYERS='1024,512,32'
-for v in default m16; do
+for v in default ${1:-diag}; do
   if [ $v != default ]; then export CLAMD_LIB=build/$v/libclamd.so; fi
   timeout -k 10 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d gpurun_out/ldsconf_$v -o pmc -- python3 tools/conv_ab.py bf16 0 > gpurun_out/ldsconf_$v.log 2>&1
   echo "rc=$?"

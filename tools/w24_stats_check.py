@@ -1,5 +1,7 @@
+"""Statistics rows of the F(2x4,3x3) kernels (clamd_conv3x3_winograd24 and its pre-transformed / direct-filter forms) against sums taken from the
+activations they wrote: one layer shape, fp32.   python tools/w24_stats_check.py"""
 import sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import continual_learning_amd as C
 from continual_learning_amd._lib import call, ptr
 L = C._lib; s = L.stream_ptr()
