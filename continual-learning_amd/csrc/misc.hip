@@ -57,6 +57,9 @@ struct PackJob {
                                  // (the 3x3 kernels read whole [tap][n] slabs of one K-chunk: contiguous 128-B lines)
     const float* kscale;         // optional [Kp]: every element is multiplied by kscale[physical k] (a BatchNorm folded into the
                                  // filters of the convolution behind it, bnfold.hip)
+    void* dst_t;                 // optional second destination (kc > 0 only): the tap-flipped TRANSPOSED layout of the same tile, element
+                                 // (T-1-t, n' = k, k' = n) K-chunk-major over n with the same kc -- the data-gradient filters of a 3x3
+                                 // convolution from the one read of the source (kscale is NOT applied to it)
 };
 
 __device__ inline int phys2log(int p, int seg0, int seg0p, int L) {
@@ -88,6 +91,98 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackJob* __restrict__ j
     const int n0 = (local / tiles_k) * PACK_TILE, k0 = (local % tiles_k) * PACK_TILE;
     const bool along_n = j.sn < j.sk;    // source-contiguous logical dimension gets the lanes
     const int tid = threadIdx.x;
+#ifndef PACK_NO_RUN_PATH      // -DPACK_NO_RUN_PATH: A/B builds of the generic path alone
+    if constexpr (!__is_same(T, float)) {
+        // 3x3 filters into the K-chunk-major layouts (96 % of the bytes of a step's pack): [Cout][Cin][3][3] has 32 channels x 9 taps = 288
+        // CONTIGUOUS floats per row of the tile -- rows = n for the forward layout (sk == 9), rows = k for the transposed data-gradient layout
+        // (sn == 9) -- so the tile is read as whole 1152-byte runs (16-byte loads when the runs are aligned) and written as 16-byte pieces of
+        // the destination's contiguous 2-KB (tap, 32 n) blocks.  The generic path below reads with a 36-byte lane stride and writes 2 bytes
+        // per lane: 1.4 TB/s; the same bits.
+        const bool rows_n = j.sk == 9, rows_k = j.sn == 9;
+        constexpr int KCT = __is_same(T, bf16_t) ? 32 : 16;
+        if (j.T == 9 && j.st == 1 && j.kc == KCT && !j.dst_f32 && rows_n != rows_k && j.Np % 8 == 0 && j.Kp % 8 == 0 && (!j.dst_t || rows_n)) {
+            float (*tf)[289] = reinterpret_cast<float (*)[289]>(&tile[0][0][0]);      // 32 rows x 288 (+1) floats
+            const int c0 = rows_n ? k0 : n0, r0 = rows_n ? n0 : k0;                     // contiguous / row dimension: first physical index
+            const int cs0 = rows_n ? j.k_seg0 : j.n_seg0, cs0p = rows_n ? j.k_seg0p : j.n_seg0p, cL = rows_n ? j.K : j.N;
+            const int rs0 = rows_n ? j.n_seg0 : j.k_seg0, rs0p = rows_n ? j.n_seg0p : j.k_seg0p, rL = rows_n ? j.N : j.K;
+            // a 32-aligned tile never straddles the two segments (their physical sizes are multiples of 32): its logical channels are one run
+            const int l0 = c0 < cs0p ? c0 : cs0 + (c0 - cs0p);
+            const int lim = c0 < cs0p ? cs0 : cL;
+            int nv = lim - l0;
+            nv = nv < 0 ? 0 : (nv > PACK_TILE ? PACK_TILE : nv);
+            const int run = nv * 9;
+            const long long srow = rows_n ? j.sn : j.sk;
+            const float* base = j.src + (long long)l0 * 9;
+            const bool vec = nv == PACK_TILE && (srow & 3) == 0 && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+            if (vec) {
+                for (int idx = tid; idx < PACK_TILE * 72; idx += 256) {
+                    const int row = idx / 72, e4 = idx - row * 72;
+                    const int lr = phys2log(r0 + row, rs0, rs0p, rL);
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (lr >= 0) v = *reinterpret_cast<const float4*>(base + lr * srow + 4 * e4);
+                    tf[row][4 * e4] = v.x; tf[row][4 * e4 + 1] = v.y; tf[row][4 * e4 + 2] = v.z; tf[row][4 * e4 + 3] = v.w;
+                }
+            } else {
+                for (int idx = tid; idx < PACK_TILE * 288; idx += 256) {
+                    const int row = idx / 288, e = idx - row * 288;
+                    const int lr = phys2log(r0 + row, rs0, rs0p, rL);
+                    tf[row][e] = (lr >= 0 && e < run) ? base[lr * srow + e] : 0.f;
+                }
+            }
+            __syncthreads();
+            for (int item = tid; item < 9 * 128; item += 256) {
+                const int t = item >> 7, nn = (item & 127) >> 2, k8 = item & 3;
+                const int ts = j.flip ? 8 - t : t;
+                const int n = n0 + nn, k = k0 + 8 * k8;
+                if (n >= j.Np || k >= j.Kp) continue;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float x = rows_n ? tf[nn][(8 * k8 + i) * 9 + ts] : tf[8 * k8 + i][nn * 9 + ts];
+                    v[i] = j.kscale ? x * j.kscale[k + i] : x;
+                }
+                const long long d = (((long long)(k / KCT) * 9 + t) * j.Np + n) * KCT + (k % KCT);      // element offset of (t, n, k)
+                if constexpr (__is_same(T, bf16_t)) {
+                    *reinterpret_cast<uint4*>((uint16_t*)j.dst + d) =
+                        make_uint4((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16),
+                                   (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16), (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16));
+                } else {
+                    // 4 bytes per element: every 16-channel group is [16 x bf16 hi][16 x bf16 lo]; this item is 8 channels of one group
+                    unsigned hi[8], lo[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { hi[i] = f2bf(v[i]); lo[i] = f2bf(v[i] - bf2f((uint16_t)hi[i])); }
+                    uint16_t* grp = (uint16_t*)j.dst + 2 * (d - (k & 15));
+                    *reinterpret_cast<uint4*>(grp + (k & 15)) = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+                    *reinterpret_cast<uint4*>(grp + 16 + (k & 15)) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+                }
+            }
+            if (j.dst_t && rows_n) {      // the transposed, tap-flipped layout from the same tile: n' = k (this tile's columns), k' = n (its rows)
+                for (int item = tid; item < 9 * 128; item += 256) {
+                    const int t = item >> 7, nn = (item & 127) >> 2, k8 = item & 3;
+                    const int n = k0 + nn, k = n0 + 8 * k8;
+                    if (n >= j.Kp || k >= j.Np) continue;
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = tf[8 * k8 + i][nn * 9 + (8 - t)];
+                    const long long d = (((long long)(k / KCT) * 9 + t) * j.Kp + n) * KCT + (k % KCT);
+                    if constexpr (__is_same(T, bf16_t)) {
+                        *reinterpret_cast<uint4*>((uint16_t*)j.dst_t + d) =
+                            make_uint4((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16), (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16),
+                                       (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16), (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16));
+                    } else {
+                        unsigned hi[8], lo[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { hi[i] = f2bf(v[i]); lo[i] = f2bf(v[i] - bf2f((uint16_t)hi[i])); }
+                        uint16_t* grp = (uint16_t*)j.dst_t + 2 * (d - (k & 15));
+                        *reinterpret_cast<uint4*>(grp + (k & 15)) = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+                        *reinterpret_cast<uint4*>(grp + 16 + (k & 15)) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+                    }
+                }
+            }
+            return;
+        }
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < PACK_TILE * PACK_TILE / 256; ++i) {
         const int idx = tid + 256 * i, a = idx & (PACK_TILE - 1), b = idx / PACK_TILE;
@@ -100,8 +195,7 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackJob* __restrict__ j
         }
         const bool ok = nl >= 0 && kl >= 0;
         const float* src = j.src + (ok ? nl * j.sn + kl * j.sk : 0);
-        const float ks = (ok && j.kscale) ? j.kscale[k] : 1.f;
-        for (int t = 0; t < j.T; ++t) tile[t][nn][kk] = ok ? src[(j.flip ? j.T - 1 - t : t) * j.st] * ks : 0.f;
+        for (int t = 0; t < j.T; ++t) tile[t][nn][kk] = ok ? src[(j.flip ? j.T - 1 - t : t) * j.st] : 0.f;      // unscaled: dst_t takes these
     }
     __syncthreads();
 #pragma unroll
@@ -109,19 +203,39 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackJob* __restrict__ j
         const int idx = tid + 256 * i, kk = idx & (PACK_TILE - 1), nn = idx / PACK_TILE;
         const int n = n0 + nn, k = k0 + kk;
         if (n < j.Np && k < j.Kp) {
+            const float ks = j.kscale ? j.kscale[k] : 1.f;
             for (int t = 0; t < j.T; ++t) {
                 // element offset of (t, n, k) with k rounded down to its 16-channel group `kg` (+ k%16 added below)
                 const long long d = j.kc > 0 ? (((long long)(k / j.kc) * j.T + t) * j.Np + n) * j.kc + (k % j.kc)
                                              : t * j.dt + n * j.dn + k * j.dk;
-                if (j.dst_f32) ((float*)j.dst)[d] = tile[t][nn][kk];
+                if (j.dst_f32) ((float*)j.dst)[d] = tile[t][nn][kk] * ks;
                 else if constexpr (__is_same(T, split_t)) {
                     // 4 bytes per element: every 16-channel group is stored as [16 x bf16 hi][16 x bf16 lo]
-                    const float x = tile[t][nn][kk];
+                    const float x = tile[t][nn][kk] * ks;
                     const uint16_t hi = f2bf(x);
                     uint16_t* grp = (uint16_t*)j.dst + 2 * (d - (k & 15));
                     grp[k & 15] = hi;
                     grp[16 + (k & 15)] = f2bf(x - bf2f(hi));
-                } else st1<T>((T*)j.dst + d, tile[t][nn][kk]);
+                } else st1<T>((T*)j.dst + d, tile[t][nn][kk] * ks);
+            }
+        }
+    }
+    if (j.dst_t && j.kc > 0) {      // transposed, tap-flipped second layout: lanes along n, the destination's contiguous index
+#pragma unroll
+        for (int i = 0; i < PACK_TILE * PACK_TILE / 256; ++i) {
+            const int idx = tid + 256 * i, nn = idx & (PACK_TILE - 1), kk = idx / PACK_TILE;
+            const int n = n0 + nn, k = k0 + kk;
+            if (n < j.Np && k < j.Kp) {
+                for (int t = 0; t < j.T; ++t) {
+                    const long long d = (((long long)(n / j.kc) * j.T + (j.T - 1 - t)) * j.Kp + k) * j.kc + (n % j.kc);
+                    const float x = tile[t][nn][kk];
+                    if constexpr (__is_same(T, split_t)) {
+                        const uint16_t hi = f2bf(x);
+                        uint16_t* grp = (uint16_t*)j.dst_t + 2 * (d - (n & 15));
+                        grp[n & 15] = hi;
+                        grp[16 + (n & 15)] = f2bf(x - bf2f(hi));
+                    } else st1<T>((T*)j.dst_t + d, x);
+                }
             }
         }
     }

@@ -11,11 +11,11 @@ from ._lib import call, ptr
 TORCH_DT = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.SPLIT: torch.float32}
 
 _PACK_DT = np.dtype({'names': ['src', 'dst', 'T', 'Np', 'Kp', 'N', 'K', 'st', 'sn', 'sk', 'dt', 'dn', 'dk',
-                               'n_seg0', 'n_seg0p', 'k_seg0', 'k_seg0p', 'flip', 'dst_f32', 'block0', 'kc', 'kscale'],
+                               'n_seg0', 'n_seg0p', 'k_seg0', 'k_seg0p', 'flip', 'dst_f32', 'block0', 'kc', 'kscale', 'dst_t'],
                      'formats': ['u8', 'u8', 'i4', 'i4', 'i4', 'i4', 'i4', 'i8', 'i8', 'i8', 'i8', 'i8', 'i8',
-                                 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'u8'],
-                     'offsets': [0, 8, 16, 20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 88, 92, 96, 100, 104, 108, 112, 116, 120],
-                     'itemsize': 128})
+                                 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'i4', 'u8', 'u8'],
+                     'offsets': [0, 8, 16, 20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 88, 92, 96, 100, 104, 108, 112, 116, 120, 128],
+                     'itemsize': 136})
 
 
 def cpad(c):
@@ -34,11 +34,12 @@ class PackTable:
         self.dcode = dcode
         self.kc = self.KC[dcode]
 
-    def add(self, src, dst, T, Np, Kp, N, K, st, sn, sk, dt, dn, dk, nseg=None, kseg=None, flip=0, f32=0, kc=0, kscale=None):
+    def add(self, src, dst, T, Np, Kp, N, K, st, sn, sk, dt, dn, dk, nseg=None, kseg=None, flip=0, f32=0, kc=0, kscale=None, dst_t=None):
         nseg = nseg or (N, Np)
         kseg = kseg or (K, Kp)
         self.jobs.append((src.data_ptr(), dst.data_ptr(), T, Np, Kp, N, K, st, sn, sk, dt, dn, dk,
-                          nseg[0], nseg[1], kseg[0], kseg[1], flip, f32, 0, kc, kscale.data_ptr() if kscale is not None else 0))
+                          nseg[0], nseg[1], kseg[0], kseg[1], flip, f32, 0, kc, kscale.data_ptr() if kscale is not None else 0,
+                          dst_t.data_ptr() if dst_t is not None else 0))
 
     # ---- the layouts of include/clamd.h ----
     def conv3x3(self, w, wf, wd, cin_segs, cout, kscale=None):
@@ -50,9 +51,9 @@ class PackTable:
         cin_p = sum(s[1] for s in cin_segs)
         cout_p = cpad(cout)
         seg = (cin_segs[0][0], cin_segs[0][1]) if len(cin_segs) == 2 else None
-        if wf is not None:
-            self.add(w, wf, 9, cout_p, cin_p, cout, cin, 1, cin * 9, 9, cout_p * cin_p, cin_p, 1, kseg=seg, kc=self.kc, kscale=kscale)
-        if wd is not None:
+        if wf is not None:      # both layouts from ONE read of the source tile (PackJob::dst_t)
+            self.add(w, wf, 9, cout_p, cin_p, cout, cin, 1, cin * 9, 9, cout_p * cin_p, cin_p, 1, kseg=seg, kc=self.kc, kscale=kscale, dst_t=wd)
+        elif wd is not None:
             self.add(w, wd, 9, cin_p, cout_p, cin, cout, 1, 9, cin * 9, cin_p * cout_p, cout_p, 1, nseg=seg, flip=1,
                      kc=self.kc)
 

@@ -34,7 +34,7 @@ def test_abi_library_exports_every_declared_symbol(C):
     assert sorted(C._lib.SIGNATURES) == names, 'ctypes signature table and header disagree'
     l = C._lib.load()
     assert l.clamd_version() >= 100
-    assert l.clamd_sizeof_pack_job() == 128 and l.clamd_sizeof_adam_tensor() == 48
+    assert l.clamd_sizeof_pack_job() == 136 and l.clamd_sizeof_adam_tensor() == 48
     assert l.clamd_bn_bwd_nsums() == 5
     assert l.clamd_sizeof_tuning() == ctypes.sizeof(C._lib.Tuning)
 
@@ -168,12 +168,17 @@ def test_engine_geometry_and_pack_table(C):
     assert [u.name for u in pooled] == ['enc3.block.4'] and pooled[0].y is e.cat[2] and pooled[0].y_ldc == 64
     assert sorted(u.name for u in fold if not hasattr(u.fold_a, 'name')) == ['dec3.block.0', 'enc4.block.1']
     assert len(fold) == 11 and all(u.fold_a.apply_in_filters and len(u.fold_table.jobs) == 1 and len(u.plain_table.jobs) == 1 for u in fold)
-    assert all(u.fold_table.jobs[0][-1] == u.fold_a.vec[0].data_ptr() and u.plain_table.jobs[0][-1] == 0 for u in fold)
+    ks = lambda u, t: t.jobs[0][-1 if u.wino else -2]       # kscale: the last field of a Winograd pack job, the one before dst_t of a plain one
+    assert all(ks(u, u.fold_table) == u.fold_a.vec[0].data_ptr() and ks(u, u.plain_table) == 0 for u in fold)
     assert sum(len(t.jobs) for t in e.wino_early) == sum(2 - (u.fold_a is not None) for u in wino_units if not u.pack_late)
     assert nw == 2 * len(wino_units) - sum(1 for u in fold if u.wino)
     head = e.stages[-1]['tail']
     assert head.kind == 'head' and head.fold_b is e.convs[-1] and len(head.fold_table.jobs) == 1      # the 1x1 head folds the last BatchNorm
-    assert len(jobs) + nw + len(fold) + 1 == 18 * 3 - 1 + 5 * 3
+    # a plain (non-Winograd) 3x3 unit whose forward AND data-gradient filters come from the table is ONE job (PackJob::dst_t: both layouts from one
+    # read of the source tile)
+    merged = [j for j in jobs if j[2] == 9 and j[-1] != 0]
+    assert len(merged) == sum(1 for u in e.convs if not u.wino and not u.im2col and u.fold_a is None and u.wd is not None)
+    assert len(jobs) + len(merged) + nw + len(fold) + 1 == 18 * 3 - 1 + 5 * 3
     assert e.pack_table.nblocks + e.pack_late.nblocks == sum(((j[3] + 31) // 32) * ((j[4] + 31) // 32) for j in jobs)
     assert C.cpad(3) == 32 and C.cpad(21) == 32 and C.cpad(1024) == 1024
 

@@ -94,6 +94,53 @@ def test_layout_roundtrip(C, name, dcode):
     assert float(nf(C, t, dcode)[..., 5:].abs().max()) == 0.0        # padded channels are zero
 
 
+@pytest.mark.parametrize('name,dcode', [d for d in DT if d[1] != 0])
+@pytest.mark.parametrize('cout,segs,scaled', [(128, [(64, 64)], False), (96, [(64, 64), (40, 64)], False), (64, [(128, 128)], True), (21, [(72, 96)], True)])
+def test_pack_3x3_whole_run_path(C, name, dcode, cout, segs, scaled):
+    """3x3 filters into the K-chunk-major layouts: the pack kernel's whole-run path (288 contiguous floats per row of a tile, 16-byte loads
+    when aligned, 16-byte stores) against the layout written out in numpy -- full tiles, a second segment that ends inside a tile, padded
+    output channels, the folded BatchNorm scale; forward and (tap-flipped, transposed) data-gradient layouts, bf16 and hi/lo pair storage."""
+    rng = np.random.default_rng(5)
+    T = C.ops.TORCH_DT[dcode]
+    cin, cin_p, cout_p = sum(a for a, _ in segs), sum(b for _, b in segs), C.ops.cpad(cout)
+    w = rnd(rng, cout, cin, 3, 3)
+    ks = (rnd(rng, cin_p) if scaled else None)
+    wt, kst = dev(w), (dev(ks) if scaled else None)
+    esz = 2 if dcode == 2 else 1                              # hi/lo pairs: 4 bytes per element = two bf16
+    wf = torch.zeros(9 * cout_p * cin_p * esz, dtype=torch.bfloat16, device='cuda')
+    wd = torch.zeros(9 * cin_p * cout_p * esz, dtype=torch.bfloat16, device='cuda')
+    tab = C.ops.PackTable(dcode)
+    tab.conv3x3(wt, wf.view(T) if dcode != 2 else wf, None, segs, cout, kscale=kst)
+    tab.conv3x3(wt, None, wd.view(T) if dcode != 2 else wd, segs, cout)
+    wf2, wd2 = torch.zeros_like(wf), torch.zeros_like(wd)      # both layouts from ONE job (PackJob::dst_t): the same bits, the scale on the forward one only
+    tab.conv3x3(wt, wf2.view(T) if dcode != 2 else wf2, wd2.view(T) if dcode != 2 else wd2, segs, cout, kscale=kst)
+    assert len(tab.jobs) == 3
+    tab.finalize('cuda').run(dcode)
+    sync()
+    assert torch.equal(wf2.view(torch.int16), wf.view(torch.int16)) and torch.equal(wd2.view(torch.int16), wd.view(torch.int16))
+    pm = phys_map(segs)
+    exp_f = np.zeros((9, cout_p, cin_p), np.float32); exp_d = np.zeros((9, cin_p, cout_p), np.float32)
+    for t in range(9):
+        ky, kx = divmod(t, 3)
+        for kp, kl in enumerate(pm):
+            if kl >= 0:
+                exp_f[t, :cout, kp] = w[:, kl, ky, kx] * (ks[kp] if scaled else np.float32(1))
+                exp_d[t, kp, :cout] = w[:, kl, 2 - ky, 2 - kx]
+    kc = tab.kc
+
+    def chunked(buf, n, k):       # [K/kc][tap][n][kc] -> [tap][n][k]
+        if dcode == 2:
+            raw = buf.view(torch.int16).cpu().numpy().view(np.uint16).reshape(k // 16, 9, n, 2, 16)
+            f = (raw.astype(np.uint32) << 16).view(np.float32)
+            return [a.transpose(1, 2, 0, 3).reshape(9, n, k) for a in (f[..., 0, :], f[..., 0, :] + f[..., 1, :])]
+        return [buf.float().cpu().numpy().reshape(k // kc, 9, n, kc).transpose(1, 2, 0, 3).reshape(9, n, k)] * 2
+    for buf, exp, n, k in ((wf, exp_f, cout_p, cin_p), (wd, exp_d, cin_p, cout_p)):
+        hi, full = chunked(buf, n, k)
+        assert np.array_equal(hi, rb(exp, 1))
+        if dcode == 2:
+            assert np.abs(full - exp).max() <= 2.0 ** -16 * np.abs(exp).max()
+
+
 @pytest.mark.parametrize('name,dcode', DT)
 def test_pack_layouts(C, name, dcode):
     rng = np.random.default_rng(1)
