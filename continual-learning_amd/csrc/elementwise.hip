@@ -540,7 +540,15 @@ template <typename T>
 __global__ void __launch_bounds__(256) nchw_im2col3x4_kernel(const float* __restrict__ src, T* dst, int ldc, int B, int C, int H, int W) {
     const long long hw = (long long)H * W, nq = (long long)B * hw / 4;
     const int wq = W / 4;
-    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
+    // bf16, pitch 32: a lane owns 4 pixels x 64 bytes; its 16 pieces go through LDS (piece P = 16 lane + 4 j + cg at slot P ^ (lane & 7), undone
+    // by the reader with (P >> 4) & 7 -- the ce4_kernel exchange, misc.hip) so that one store instruction writes 1 KB of contiguous output
+    constexpr bool XCH = __is_same(T, bf16_t);
+    __shared__ uint4 xbuf[XCH ? 4 : 1][XCH ? 1024 : 1];
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < nq; base += (long long)gridDim.x * blockDim.x) {
+        const long long qi = base + threadIdx.x;
+        const bool live = qi < nq;                          // block-uniform trip count: the exchange has barriers
+        if (!(XCH && ldc == 32) && !live) continue;
+        const long long q = live ? qi : nq - 1;
         const int x = (int)(q % wq) * 4;
         const long long row = q / wq;
         const int y = (int)(row % H);
@@ -559,6 +567,7 @@ __global__ void __launch_bounds__(256) nchw_im2col3x4_kernel(const float* __rest
                 a[c][ky][5] = (ok && x + 4 < W) ? r[4] : 0.f;
             }
         const long long pix = (b * H + y) * W + x;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -569,8 +578,54 @@ __global__ void __launch_bounds__(256) nchw_im2col3x4_kernel(const float* __rest
                     const int k = cg * 8 + k8, c = k / 9, t = k - c * 9;        // compile-time after unrolling
                     o[k8] = k < 27 ? a[c < 3 ? c : 0][t / 3][j + t % 3] : 0.f;
                 }
+                if constexpr (XCH) {
+                    if (ldc == 32) {
+                        const int P = 16 * lane + 4 * j + cg;
+                        xbuf[wv][P ^ (lane & 7)] = make_uint4((unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16), (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16),
+                                                              (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16), (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16));
+                        continue;
+                    }
+                }
                 Vec8<T>::store(dst + (pix + j) * ldc + cg * 8, o);
             }
+        if constexpr (XCH) {
+            if (ldc == 32) {
+                __syncthreads();
+                const long long wave_pix = 4 * (base + 64 * wv);      // first pixel of this wave's 256 (pixels are linear over (b, y, x): W % 4 == 0)
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int P = 64 * it + lane;
+                    const long long px = wave_pix + (P >> 2);
+                    if (px < 4 * nq) *reinterpret_cast<uint4*>((uint16_t*)dst + px * 32 + (P & 3) * 8) = xbuf[wv][P ^ ((P >> 4) & 7)];
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// The same tensor with one thread per 8-channel PIECE of a pixel (4 lanes per pixel): every store instruction of a wave writes 16 pixels x 64
+// bytes (bf16) = 1 KB of contiguous output, where the four-pixels-per-thread kernel above writes 16 bytes every 256 (64 partial lines per
+// instruction: 1.7 TB/s).  The eight values of a piece are gathered with scalar loads -- the input is 12 MB, read nine times, L1/L2-resident.
+template <typename T>
+__global__ void __launch_bounds__(256) nchw_im2col3p_kernel(const float* __restrict__ src, T* dst, int ldc, int B, int C, int H, int W) {
+    const long long hw = (long long)H * W, npiece = (long long)B * hw * 4;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < npiece; it += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(it & 3);
+        const long long pix = it >> 2;
+        const int x = (int)(pix % W);
+        const long long row = pix / W;
+        const int y = (int)(row % H);
+        const long long b = row / H;
+        float o[8];
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const int k = cg * 8 + k8, c = k / 9, t = k - c * 9, ky = t / 3, kx = t - ky * 3;
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            const bool ok = k < 27 && c < C && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            o[k8] = ok ? src[(b * C + c) * hw + (long long)yy * W + xx] : 0.f;
+        }
+        Vec8<T>::store(dst + pix * ldc + cg * 8, o);
     }
 }
 
@@ -830,6 +885,20 @@ int clamd_nchw_im2col3(const float* src, void* dst, int ldc, int B, int C, int H
     const long long nitem = (long long)B * H * W;
     dim3 g(ew_grid(nitem, 8192)), b(256);
     hipStream_t s = (hipStream_t)stream;
+#ifndef IM2COL_FOUR_PIXELS      // -DIM2COL_FOUR_PIXELS: A/B builds of the four-pixels-per-thread kernel
+    // 4-byte storage: the piece kernel (fp32 60 -> 35 us, bf16x3 47 -> 38 us at 16 x 256 x 256); bf16: the four-pixel kernel with its LDS
+    // exchange (the piece kernel's 8 scalar gathers per 16 bytes of output cost more than they save there: 42 us against 36)
+    if (C <= 3 && Cp == 32 && (dtype != CLAMD_BF16 || W % 4 || ((size_t)src % 16))) {
+        const dim3 gp(ew_grid(nitem * 4, 16384));
+#define LAUNCHP(T) hipLaunchKernelGGL(nchw_im2col3p_kernel<T>, gp, b, 0, s, src, (T*)dst, ldc, B, C, H, W)
+        if (dtype == CLAMD_BF16) LAUNCHP(bf16_t);
+        else if (dtype == CLAMD_F32) LAUNCHP(float);
+        else if (dtype == CLAMD_SPLIT) LAUNCHP(split_t);
+        else return clamd_fail("nchw_im2col3: bad dtype");
+#undef LAUNCHP
+        return clamd_check_launch("nchw_im2col3");
+    }
+#endif
     if (C <= 3 && Cp == 32 && W % 4 == 0 && ((size_t)src % 16) == 0) {
         const dim3 g4(ew_grid(nitem / 4, 8192));
 #define LAUNCH4(T) hipLaunchKernelGGL(nchw_im2col3x4_kernel<T>, g4, b, 0, s, src, (T*)dst, ldc, B, C, H, W)

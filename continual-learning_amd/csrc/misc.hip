@@ -390,6 +390,11 @@ __global__ void __launch_bounds__(256) ce_kernel(const float* __restrict__ logit
 // head's data gradient reads, so the backward pass needs no NCHW -> NHWC conversion (88 + 67 MB at config 2 in bf16): a thread's four
 // pixels are consecutive there too (4 x 64 bytes in bf16).
 struct ce_no_nhwc {};
+#ifdef CE_NO_EXCHANGE      // A/B builds of the NHWC copy stored straight from the registers
+#define CE_EXCHANGE false
+#else
+#define CE_EXCHANGE true
+#endif
 template <int KMAX, typename NT = ce_no_nhwc>
 __global__ void __launch_bounds__(256) ce4_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                   float* __restrict__ dlogits, float* __restrict__ partial,
@@ -402,8 +407,13 @@ __global__ void __launch_bounds__(256) ce4_kernel(const float* __restrict__ logi
     const unsigned int nv = count_rows ? ce_count_total(count_rows, 0, cnt_tmp) : *nvalid;
     const float gs = grad_scale / (float)max(nv, 1u);
     float ce_sum = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (long long)gridDim.x * blockDim.x) {
-        const long long pix = 4 * i, b = pix / HW, p = pix - b * HW;
+    constexpr bool XCH = __is_same(NT, bf16_t) && CE_EXCHANGE;      // NHWC copy through LDS: whole KBs per store instruction
+    __shared__ uint4 xbuf[XCH ? 4 : 1][XCH ? 1024 : 1];
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < nq; base += (long long)gridDim.x * blockDim.x) {
+        const long long i = base + threadIdx.x;
+        const bool live = i < nq;                                    // the trip count is block-uniform (the exchange below has barriers)
+        if (!XCH && !live) continue;
+        const long long pix = 4 * (live ? i : nq - 1), b = pix / HW, p = pix - b * HW;
         const float* z = logits + b * K * HW + p;
         float4 v[KMAX];
         float4 mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
@@ -426,10 +436,12 @@ __global__ void __launch_bounds__(256) ce4_kernel(const float* __restrict__ logi
             }
         const bool ok[4] = {lab[0] != ignore_index && lab[0] >= 0 && lab[0] < K, lab[1] != ignore_index && lab[1] >= 0 && lab[1] < K,
                             lab[2] != ignore_index && lab[2] >= 0 && lab[2] < K, lab[3] != ignore_index && lab[3] >= 0 && lab[3] < K};
-        if (ok[0]) ce_sum += mx.x + logf(se.x) - picked.x;
-        if (ok[1]) ce_sum += mx.y + logf(se.y) - picked.y;
-        if (ok[2]) ce_sum += mx.z + logf(se.z) - picked.z;
-        if (ok[3]) ce_sum += mx.w + logf(se.w) - picked.w;
+        if (live) {
+            if (ok[0]) ce_sum += mx.x + logf(se.x) - picked.x;
+            if (ok[1]) ce_sum += mx.y + logf(se.y) - picked.y;
+            if (ok[2]) ce_sum += mx.z + logf(se.z) - picked.z;
+            if (ok[3]) ce_sum += mx.w + logf(se.w) - picked.w;
+        }
         const float4 r = make_float4(ok[0] ? gs / se.x : 0.f, ok[1] ? gs / se.y : 0.f, ok[2] ? gs / se.z : 0.f, ok[3] ? gs / se.w : 0.f);
         const float4 h = make_float4(ok[0] ? gs : 0.f, ok[1] ? gs : 0.f, ok[2] ? gs : 0.f, ok[3] ? gs : 0.f);
         float* d = dlogits + b * K * HW + p;
@@ -439,10 +451,46 @@ __global__ void __launch_bounds__(256) ce4_kernel(const float* __restrict__ logi
                 float4 g;
                 g.x = v[k].x * r.x - (lab[0] == k ? h.x : 0.f); g.y = v[k].y * r.y - (lab[1] == k ? h.y : 0.f);
                 g.z = v[k].z * r.z - (lab[2] == k ? h.z : 0.f); g.w = v[k].w * r.w - (lab[3] == k ? h.w : 0.f);
-                *reinterpret_cast<float4*>(d + k * HW) = g;
+                if (live) *reinterpret_cast<float4*>(d + k * HW) = g;
                 if constexpr (!__is_same(NT, ce_no_nhwc)) v[k] = g;
             }
-        if constexpr (!__is_same(NT, ce_no_nhwc)) {
+        if constexpr (XCH) {
+            // A lane owns 4 pixels x 64 bytes; stored straight from its registers every instruction would write 16 bytes every 256 (64 partial
+            // lines).  Instead the wave's 1024 16-byte pieces go through LDS (piece P = 16 lane + 4 q + cg at slot P ^ (lane & 7): the eight
+            // lanes a ds_write_b128 is served in hit eight different bank groups; the reader undoes it with (P >> 4) & 7) and leave in pixel
+            // order: one store instruction = 16 pixels x 64 bytes = 1 KB of contiguous output.
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) {
+                    unsigned w[4];
+#pragma unroll
+                    for (int j2 = 0; j2 < 4; ++j2) {
+                        float e[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int k = cg * 8 + 2 * j2 + u;
+                            float t = 0.f;
+                            if (k < KMAX) { if (k < K) t = q == 0 ? v[k < KMAX ? k : 0].x : q == 1 ? v[k < KMAX ? k : 0].y : q == 2 ? v[k < KMAX ? k : 0].z : v[k < KMAX ? k : 0].w; }
+                            e[u] = t;
+                        }
+                        w[j2] = (unsigned)f2bf(e[0]) | ((unsigned)f2bf(e[1]) << 16);
+                    }
+                    const int P = 16 * lane + 4 * q + cg;
+                    xbuf[wv][P ^ (lane & 7)] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            __syncthreads();
+            const long long wave_pix = 4 * (base + 64 * wv);          // first pixel of this wave's 256
+            const long long npix = 4 * nq;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int P = 64 * it + lane;
+                const long long px = wave_pix + (P >> 2);
+                if (px < npix) *reinterpret_cast<uint4*>((uint16_t*)dl_nhwc + px * dl_ldc + (P & 3) * 8) = xbuf[wv][P ^ ((P >> 4) & 7)];
+            }
+            __syncthreads();
+        } else if constexpr (!__is_same(NT, ce_no_nhwc)) {
             NT* o = dl_nhwc + pix * dl_ldc;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
