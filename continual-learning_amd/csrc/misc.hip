@@ -139,7 +139,9 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackJob* __restrict__ j
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float x = rows_n ? tf[nn][(8 * k8 + i) * 9 + ts] : tf[8 * k8 + i][nn * 9 + ts];
-                    v[i] = j.kscale ? x * j.kscale[k + i] : x;
+                    // the scale of a padded channel is never read (the caller may leave it uninitialised): its filter entries are zeros
+                    const bool kreal = rows_n ? 8 * k8 + i < nv : phys2log(k + i, rs0, rs0p, rL) >= 0;
+                    v[i] = (j.kscale && kreal) ? x * j.kscale[k + i] : x;
                 }
                 const long long d = (((long long)(k / KCT) * 9 + t) * j.Np + n) * KCT + (k % KCT);      // element offset of (t, n, k)
                 if constexpr (__is_same(T, bf16_t)) {
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(256) pack_kernel(const PackJob* __restrict__ j
         const int idx = tid + 256 * i, kk = idx & (PACK_TILE - 1), nn = idx / PACK_TILE;
         const int n = n0 + nn, k = k0 + kk;
         if (n < j.Np && k < j.Kp) {
-            const float ks = j.kscale ? j.kscale[k] : 1.f;
+            const float ks = (j.kscale && phys2log(k, j.k_seg0, j.k_seg0p, j.K) >= 0) ? j.kscale[k] : 1.f;      // never a padded channel's entry
             for (int t = 0; t < j.T; ++t) {
                 // element offset of (t, n, k) with k rounded down to its 16-channel group `kg` (+ k%16 added below)
                 const long long d = j.kc > 0 ? (((long long)(k / j.kc) * j.T + t) * j.Np + n) * j.kc + (k % j.kc)

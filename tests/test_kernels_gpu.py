@@ -106,6 +106,9 @@ def test_pack_3x3_whole_run_path(C, name, dcode, cout, segs, scaled):
     w = rnd(rng, cout, cin, 3, 3)
     ks = (rnd(rng, cin_p) if scaled else None)
     wt, kst = dev(w), (dev(ks) if scaled else None)
+    if scaled:
+        pm_ = phys_map(segs)
+        kst[torch.tensor([i for i, l in enumerate(pm_) if l < 0], dtype=torch.long, device='cuda')] = float('nan')      # padded entries must never matter
     esz = 2 if dcode == 2 else 1                              # hi/lo pairs: 4 bytes per element = two bf16
     wf = torch.zeros(9 * cout_p * cin_p * esz, dtype=torch.bfloat16, device='cuda')
     wd = torch.zeros(9 * cin_p * cout_p * esz, dtype=torch.bfloat16, device='cuda')
