@@ -40,25 +40,6 @@ class Tuning(ctypes.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != 'reserved'}
 
 
-class BnTail(ctypes.Structure):
-    """Mirror of `clamd_bn_tail` (include/clamd.h): the BatchNorm finalize of the rows a clamd_conv3x3_tail launch writes, run inside the launch
-    by the workgroup that finishes last.  Pointers are raw device addresses (tensor.data_ptr()); the owner keeps the tensors alive."""
-    _fields_ = [('ticket', c_void_p), ('kind', c_int), ('C', c_int), ('gamma', c_void_p), ('beta', c_void_p), ('running_mean', c_void_p),
-                ('running_var', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('save_mean', c_void_p), ('save_istd', c_void_p),
-                ('num_batches_tracked', c_void_p), ('k012', c_void_p), ('dgamma', c_void_p), ('dbeta', c_void_p), ('dbias', c_void_p),
-                ('count', c_double), ('momentum', c_double), ('eps', c_double)]
-
-    def __init__(self, **kw):
-        super().__init__()
-        for k, v in kw.items():
-            if k not in dict(self._fields_):
-                raise KeyError(f'unknown clamd_bn_tail field {k!r}')
-            setattr(self, k, v.data_ptr() if hasattr(v, 'data_ptr') else v)
-
-    def ref(self):
-        return ctypes.addressof(self)
-
-
 def tune_ptr(t):
     """`const clamd_tuning*` argument for a Tuning object (None -> NULL = library defaults)."""
     return None if t is None else t.ref()
@@ -77,8 +58,6 @@ SIGNATURES = {
     'clamd_tuning_init': (None, [_P]),
     'clamd_stat_rows': (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'clamd_conv3x3': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    'clamd_sizeof_bn_tail': (_I, []),
-    'clamd_conv3x3_tail': (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     'clamd_conv3x3_border_bias_ok': (_I, [_I, _I, _I, _I, _I, _I, _P]),
     'clamd_conv3x3_bn_sums': (_I, [_I, _I, _I, _I, _I, _I, _P]),
     'clamd_bn_fold_bias': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -5,7 +5,6 @@
 // concat buffer; every thread moves 8 channels (16 B bf16 / 32 B f32) per pixel, lanes along channels first.
 #include "common.hip.h"
 #include "clamd_internal.h"
-#include "bn_tail.hip.h"
 
 namespace clamd {
 
@@ -15,15 +14,26 @@ namespace clamd {
 // is left of a CU or it waits for a weight-gradient workgroup to retire -- the 1024-thread form of round 3 (4 waves x 40 registers per
 // SIMD) did, for 35-95 us per launch on 8 launches of a bf16 step (kernel trace, round 4).  256 threads = one 40-register wave per SIMD;
 // FIN_CH channels per workgroup (more, smaller workgroups instead of more threads).
-// (FIN_THREADS, FIN_CH and the arithmetic live in bn_tail.hip.h: the in-launch tail of the convolution kernels produces the same bits)
+constexpr int FIN_THREADS = 256, FIN_CH = 2;
 // Fixed-order sum of partial rows [row][NK][Cp] for the FIN_CH channels c0.. of this block: thread (row lane, column) adds its rows in
-// ascending order into four interleaved fp64 chains (fin_lane_sum), the row lanes are then added in ascending order.  The result depends only on
+// ascending order into four interleaved fp64 chains, the row lanes are then added in ascending order.  The result depends only on
 // (nrows, data): two runs are bit-identical (no float atomics anywhere).
 template <int NK>
 __device__ inline void sum_partial_rows(const float* __restrict__ rows, int nrows, int Cp, int c0, double* red, double* out) {
     constexpr int COLS = NK * FIN_CH, RL = FIN_THREADS / COLS;
     const int t = threadIdx.x, col = t % COLS, rl = t / COLS;
-    if (rl < RL) red[rl * COLS + col] = fin_lane_sum<NK>(rows + (size_t)(col / FIN_CH) * Cp + c0 + (col % FIN_CH), (size_t)NK * Cp, nrows, rl);
+    if (rl < RL) {
+        const float* p = rows + (size_t)(col / FIN_CH) * Cp + c0 + (col % FIN_CH);
+        const size_t rs = (size_t)NK * Cp;
+        double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+        int r = rl;
+        for (; r + 3 * RL < nrows; r += 4 * RL) {
+            a0 += (double)p[(size_t)r * rs]; a1 += (double)p[(size_t)(r + RL) * rs];
+            a2 += (double)p[(size_t)(r + 2 * RL) * rs]; a3 += (double)p[(size_t)(r + 3 * RL) * rs];
+        }
+        for (; r < nrows; r += RL) a0 += (double)p[(size_t)r * rs];
+        red[rl * COLS + col] = (a0 + a1) + (a2 + a3);
+    }
     __syncthreads();
     if (t < COLS) {      // out[k * FIN_CH + channel]
         double v = 0.;
@@ -46,8 +56,27 @@ __global__ void __launch_bounds__(FIN_THREADS) bn_finalize_kernel(const float* _
     if (threadIdx.x >= FIN_CH) return;
     if (num_batches_tracked && stats && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;      // nn.BatchNorm2d's counter (train mode)
     const int c = c0 + threadIdx.x;
-    bn_finalize_channel(c, C, stats != nullptr, stats ? tot[threadIdx.x] : 0., stats ? tot[FIN_CH + threadIdx.x] : 0., gamma, beta, running_mean,
-                        running_var, scale, shift, save_mean, save_istd, count, momentum, eps);
+    double mean, var;
+    if (stats) {
+        mean = tot[threadIdx.x] / count;
+        var = tot[FIN_CH + threadIdx.x] / count - mean * mean;
+        var = var > 0. ? var : 0.;
+    } else {   // eval mode (trainer.py:271): normalise with the running statistics, update nothing
+        mean = c < C ? (double)running_mean[c] : 0.;
+        var = c < C ? (double)running_var[c] : 1.;
+    }
+    const double istd = 1.0 / sqrt(var + eps);
+    const double g = c < C ? (double)gamma[c] : 0., b = c < C ? (double)beta[c] : 0.;
+    const float sc = (float)(g * istd);
+    scale[c] = sc;
+    shift[c] = (float)(b - mean * (g * istd));
+    save_mean[c] = (float)mean;
+    save_istd[c] = (float)istd;
+    if (c < C && running_mean && stats) {
+        const double unb = count > 1. ? var * (count / (count - 1.)) : var;
+        running_mean[c] = (float)((1. - momentum) * (double)running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1. - momentum) * (double)running_var[c] + momentum * unb);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -176,6 +205,7 @@ __device__ inline void load_gu(const T* ga, int ga_ldc, const T* gp, int gp_ldc,
         for (int j = 0; j < 8; ++j) g[q][j] += (arg[j] == q) ? gpv[j] : 0.f;
 }
 
+constexpr int NSUM = 5;
 
 template <typename T, bool POOL>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ ga, int ga_ldc,
@@ -271,7 +301,19 @@ __global__ void __launch_bounds__(FIN_THREADS) bn_bwd_finalize_kernel(const floa
     double s[NSUM];
 #pragma unroll
     for (int k = 0; k < NSUM; ++k) s[k] = tot[k * FIN_CH + threadIdx.x];
-    bn_bwd_finalize_channel(c, C, Cp, s, gamma, save_mean, save_istd, k012, dgamma, dbeta, dbias, count);
+    const double mu = save_mean[c], istd = save_istd[c];
+    const double g = c < C ? (double)gamma[c] : 0.;
+    const double inv_n = 1. / count;
+    const double k0 = g * istd;
+    const double c2 = istd * istd * (s[1] * inv_n - mu * s[0] * inv_n);
+    const double k1 = -k0 * c2;
+    const double k2 = k0 * (mu * c2 - s[0] * inv_n);
+    k012[c] = (float)k0; k012[Cp + c] = (float)k1; k012[2 * Cp + c] = (float)k2;
+    if (c < C) {
+        dgamma[c] = (float)(istd * (s[1] - mu * s[0]));
+        dbeta[c] = (float)s[0];
+        if (dbias) dbias[c] = (float)(k0 * s[2] + k1 * s[4] + k2 * s[3]);
+    }
 }
 
 // g_z = k0 g + k1 y + k2 where the ReLU was active: ONE expression (two fused multiply-adds) for every apply kernel, so the variants

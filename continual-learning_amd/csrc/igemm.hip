@@ -568,49 +568,6 @@ int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* b
     return launch<MODE_CONV3, EPI_NHWC>(p, dtype, (hipStream_t)stream, tn.igemm_variant);
 }
 
-int clamd_sizeof_bn_tail(void) { return (int)sizeof(clamd_bn_tail); }
-
-int clamd_conv3x3_tail(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
-                       float* stats, const void* bn_y, float* bn_sums, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p,
-                       int relu, int m_fastest, int dtype, const clamd_tuning* tune, const clamd_bn_tail* tail, void* stream) {
-    if (!tail) return clamd_conv3x3(x, x_ldc, w_packed, bias, y, y_ldc, stats, bn_y, bn_sums, stat_rows, B, H, W, Cin_p, Cout_p, relu, m_fastest, dtype, tune, stream);
-    if (!tail->ticket || (tail->kind != 1 && tail->kind != 2)) return clamd_fail("conv3x3_tail: needs a ticket counter and kind 1 (statistics) or 2 (backward sums)");
-    if (tail->kind == 1 && !stats) return clamd_fail("conv3x3_tail: kind 1 finalizes the statistics rows of this launch: stats must be given");
-    if (tail->kind == 2 && !bn_sums) return clamd_fail("conv3x3_tail: kind 2 finalizes the backward sums of this launch: bn_y / bn_sums must be given");
-    if (tail->kind == 1 && (!tail->gamma || !tail->beta || !tail->scale || !tail->shift || !tail->save_mean || !tail->save_istd))
-        return clamd_fail("conv3x3_tail: kind 1 needs gamma, beta and the four output vectors");
-    if (tail->kind == 2 && (!tail->gamma || !tail->save_mean || !tail->save_istd || !tail->k012 || !tail->dgamma || !tail->dbeta))
-        return clamd_fail("conv3x3_tail: kind 2 needs gamma, the saved mean / inverse deviation and k012, dgamma, dbeta");
-    if (tail->C > Cout_p || tail->count <= 0) return clamd_fail("conv3x3_tail: bad channel count or element count");
-    if (relu & ~3) return clamd_fail("conv3x3: bad relu flags");
-    if (int e = clamd_check_tuning(tune)) return e;
-    const clamd_tuning& tn = clamd_tune(tune);
-    IgemmParams p{x, x_ldc, w_packed, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu & 1, 0, m_fastest, bn_y, bn_sums};
-    const Conv3Plan pl = plan_conv3x3(p, dtype, tn);
-    // the two-sum rows of the persistent bf16 kernel carry zeros in rows 2-4: kind 2 must not ask for the conv-bias gradient there
-    const bool two = bn_sums && dtype == CLAMD_BF16 && pl.kind == 2;
-    if (tail->kind == 2 && two && tail->dbias) return clamd_fail("conv3x3_tail: this launch takes two of the five sums (clamd_conv3x3_bn_sums): dbias must be NULL");
-    const bool in_launch = (pl.kind == 1 || pl.kind == 2) && Cout_p <= BN_TAIL_MAX_CHANNELS;
-    if (in_launch) {
-        p.bias_classes = (relu & CLAMD_BIAS_BORDER_CLASSES) ? 1 : 0;
-        if (int e = check_common(p, "conv3x3", dtype)) return e;
-        if ((bn_y == nullptr) != (bn_sums == nullptr)) return clamd_fail("conv3x3: bn_y and bn_sums go together");
-        if (pl.rows <= 0) return clamd_fail("conv3x3: grid out of range");
-        if (p.bias_classes && (pl.kind != 2 || !bias || H < 2 || W < 2))
-            return clamd_fail("conv3x3: the border-class bias table needs the persistent kernel (ask clamd_conv3x3_border_bias_ok), a table and H, W >= 2");
-        if (int e = check_rows(p, stat_rows, pl.rows, "conv3x3")) return e;
-        p.tail = *tail;
-        if (pl.kind == 2) return launch_igemm_pws(p, dtype, (hipStream_t)stream, tn);
-        return launch_igemm_ws(p, dtype, (hipStream_t)stream, pl.mt);
-    }
-    if (int e = clamd_conv3x3(x, x_ldc, w_packed, bias, y, y_ldc, stats, bn_y, bn_sums, stat_rows, B, H, W, Cin_p, Cout_p, relu, m_fastest, dtype, tune, stream)) return e;
-    if (tail->kind == 1)
-        return clamd_bn_finalize(stats, stat_rows, tail->gamma, tail->beta, tail->running_mean, tail->running_var, tail->scale, tail->shift,
-                                 tail->save_mean, tail->save_istd, Cout_p, tail->C, tail->count, tail->momentum, tail->eps, tail->num_batches_tracked, stream);
-    return clamd_bn_bwd_finalize(bn_sums, stat_rows, tail->gamma, tail->save_mean, tail->save_istd, tail->k012, tail->dgamma, tail->dbeta, tail->dbias,
-                                 Cout_p, tail->C, tail->count, stream);
-}
-
 int clamd_conv3x3_border_bias_ok(int B, int H, int W, int Cin_p, int Cout_p, int dtype, const clamd_tuning* tune) {
     if (B <= 0 || H < 2 || W < 2 || clamd_check_tuning(tune)) return 0;
     IgemmParams p{nullptr, Cin_p, nullptr, nullptr, nullptr, Cout_p, nullptr, B, H, W, Cin_p, Cout_p, 1, 0, 0, nullptr, nullptr};

@@ -2,7 +2,6 @@
 // wave-specialised structure for the 3x3 convolutions).
 #pragma once
 #include "common.hip.h"
-#include "bn_tail.hip.h"
 #include "clamd_internal.h"
 
 namespace clamd {
@@ -31,8 +30,6 @@ struct IgemmParams {
     long long* pred;
     // MODE_CONV3 forward launches behind a folded BatchNorm (bnfold.hip): bias is a [9][Np] table indexed by the border class of the pixel
     int bias_classes;
-    // igemm_pws / igemm_ws: the last workgroup to finish runs the BatchNorm finalize on the rows of this launch (bn_tail.hip.h); ticket == null: off
-    BnTail tail;
 };
 
 #ifndef IGEMM_PW_NT

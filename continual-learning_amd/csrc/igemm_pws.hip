@@ -70,7 +70,6 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
     static_assert((2 * STAGE + EPI_SLOTS) * 16 <= 160 * 1024, "two LDS stages + the epilogue region must fit one CU");
     __shared__ uint4 smem[2 * STAGE + EPI_SLOTS];
     static_assert(!CL || 2 * STAGE * 16 >= 2 * 64 * 4 * 33 * 4, "the final hand-over of the running sums reuses the two stages");
-    static_assert(2 * STAGE * 16 >= 16 + bn_tail_scratch_doubles(BN_TAIL_MAX_CHANNELS, 512) * 8, "the in-launch BatchNorm finalize reuses the two stages");
     // CLS: this workgroup's 64 columns of the [9][Np] border-class bias table (a folded BatchNorm, bnfold.hip), filled by the consumers while
     // they wait for the first stage: a border tile then takes its biases from LDS, not through two dependent global round trips per row tile
     __shared__ float cls_tab[CLS ? 9 * 64 : 1];
@@ -695,17 +694,11 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             t += __shfl_xor(t, 2);
             const int k = kc >> 6, c = kc & 63;
             if ((tid & 3) == 0 && n0 + c < p.Np) {
-                if constexpr (CLM == 2) st_row(p.stats + ((size_t)mg * 2 + k) * p.Np + n0 + c, t);
-                else st_row(p.bn_sums + ((size_t)mg * 5 + k) * p.Np + n0 + c, t);
+                if constexpr (CLM == 2) p.stats[((size_t)mg * 2 + k) * p.Np + n0 + c] = t;
+                else p.bn_sums[((size_t)mg * 5 + k) * p.Np + n0 + c] = t;
             }
             if constexpr (CLM == 3) {      // rows 2-4 of the five-sum layout: not taken here (the conv-bias gradient comes from clamd_bn_bwd_apply)
-                if (tid < 192 && n0 + (tid & 63) < p.Np) st_row(p.bn_sums + ((size_t)mg * 5 + 2 + (tid >> 6)) * p.Np + n0 + (tid & 63), 0.f);
-            }
-            if (p.tail.ticket) {           // the BatchNorm finalize of these rows, by the workgroup that finishes last (bn_tail.hip.h)
-                if (bn_tail_last(p.tail.ticket, reinterpret_cast<int*>(smem))) {
-                    if constexpr (CLM == 2) bn_tail_finalize<2, 2, 512>(p.tail, p.stats, gm, p.Np, reinterpret_cast<double*>(smem + 1));
-                    else bn_tail_finalize<2, NSUM, 512>(p.tail, p.bn_sums, gm, p.Np, reinterpret_cast<double*>(smem + 1));      // two-sum rows
-                }
+                if (tid < 192 && n0 + (tid & 63) < p.Np) p.bn_sums[((size_t)mg * 5 + 2 + (tid >> 6)) * p.Np + n0 + (tid & 63)] = 0.f;
             }
         }
         return;
@@ -732,11 +725,7 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
             const int k = tid >> 6, c = tid & 63;
             const float t = sbuf[(0 * 2 + k) * 64 + c] + sbuf[(1 * 2 + k) * 64 + c] + sbuf[(2 * 2 + k) * 64 + c] +
                             sbuf[(3 * 2 + k) * 64 + c];
-            if (n0 + c < p.Np) st_row(p.stats + ((size_t)mg * 2 + k) * p.Np + n0 + c, t);
-        }
-        if (p.tail.ticket) {
-            if (bn_tail_last(p.tail.ticket, reinterpret_cast<int*>(smem)))
-                bn_tail_finalize<2, 2, 512>(p.tail, p.stats, gm, p.Np, reinterpret_cast<double*>(smem + 1));
+            if (n0 + c < p.Np) p.stats[((size_t)mg * 2 + k) * p.Np + n0 + c] = t;
         }
     }
 }

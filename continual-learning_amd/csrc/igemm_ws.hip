@@ -35,7 +35,6 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
     constexpr bool SPLIT = __is_same(T, split_t);
     constexpr int STAGE = G::IN_SLOTS + G::WT_SLOTS;
     static_assert(2 * STAGE * 16 <= 160 * 1024, "two LDS stages must fit one CU");
-    static_assert(2 * STAGE * 16 >= 16 + bn_tail_scratch_doubles(BN_TAIL_MAX_CHANNELS, 512) * 8, "the in-launch BatchNorm finalize reuses the two stages");
     __shared__ uint4 smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -318,7 +317,7 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
             const int k = tid >> 6, c = tid & 63;
             const float t = sbuf[(0 * 2 + k) * 64 + c] + sbuf[(1 * 2 + k) * 64 + c] + sbuf[(2 * 2 + k) * 64 + c] +
                             sbuf[(3 * 2 + k) * 64 + c];
-            if (n0 + c < p.Np) st_row(p.stats + ((size_t)tm * 2 + k) * p.Np + n0 + c, t);      // partial row of this pixel tile
+            if (n0 + c < p.Np) p.stats[((size_t)tm * 2 + k) * p.Np + n0 + c] = t;      // partial row of this pixel tile
         }
     }
     T* out = (T*)p.y;
@@ -390,13 +389,7 @@ __global__ void __launch_bounds__(512, 2) igemm_ws_kernel(const IgemmParams p) {
             const int k = i >> 6, c = i & 63;
             const float t = ebuf[(0 * 5 + k) * 64 + c] + ebuf[(1 * 5 + k) * 64 + c] + ebuf[(2 * 5 + k) * 64 + c] +
                             ebuf[(3 * 5 + k) * 64 + c];
-            if (n0 + c < p.Np) st_row(p.bn_sums + ((size_t)tm * 5 + k) * p.Np + n0 + c, t);
-        }
-    }
-    if (p.tail.ticket) {       // the BatchNorm finalize of this launch's rows (one per pixel tile), by the workgroup that finishes last (bn_tail.hip.h)
-        if (bn_tail_last(p.tail.ticket, reinterpret_cast<int*>(smem))) {
-            if (p.tail.kind == 1) bn_tail_finalize<2, 2, 512>(p.tail, p.stats, ntm, p.Np, reinterpret_cast<double*>(smem + 1));
-            else bn_tail_finalize<NSUM, NSUM, 512>(p.tail, p.bn_sums, ntm, p.Np, reinterpret_cast<double*>(smem + 1));
+            if (n0 + c < p.Np) p.bn_sums[((size_t)tm * 5 + k) * p.Np + n0 + c] = t;
         }
     }
     if (wave == 0) DIAG_ADD(6, DIAG_T() - e0);             // [6] epilogue (one wave per workgroup)

@@ -65,10 +65,6 @@ FOLD_FILTERS_MAX_CHANNELS = int(os.environ.get('CLAMD_FOLD_FILTERS_MAX_CHANNELS'
 # max(s x + t) = s min(x) + t), and the two readers take scale / shift in their filters and bias tables.  The pooled bn_apply pass of enc1
 # (603 MB, the largest elementwise pass of the step) becomes a 335 MB pooling pass.
 FOLD_POOLED = os.environ.get('CLAMD_FOLD_POOLED', '1') != '0'
-# BatchNorm finalize inside the convolution launch that wrote the rows (clamd_conv3x3_tail: the workgroup that finishes last adds them) instead
-# of a launch of its own on the critical chain conv -> finalize -> apply / fold-pack -> conv.  The implicit-GEMM kernels only (bf16 / bf16x3
-# storage and the fp32 fall-back shapes); the same bits either way.  =0: A/B measurements
-TAIL_FINALIZE = os.environ.get('CLAMD_TAIL_FINALIZE', '1') != '0'
 # fp32 path, pre-transformed weight gradients: the gradient-side transform (HBM-bound) on a THIRD stream, so that it runs beside the
 # weight-gradient GEMM of the unit before (which leaves 188 registers per SIMD free) instead of in front of its own GEMM on the second
 # stream, and that GEMM can start the moment the data gradient of its unit has finished.
@@ -351,7 +347,6 @@ class _Engine:
         self.dcode, self.tdtype = _DTYPES[model.compute_dtype]
         self.wino = bool(WINOGRAD) and self.dcode == _lib.F32
         self.pack_late_stream, self.pack_late_at = bool(PACK_LATE_STREAM), int(PACK_LATE_AT)
-        self.tail_finalize = bool(TAIL_FINALIZE)
         self.tuning = model.tuning
         self.NS = lib.clamd_bn_bwd_nsums()
         self.generation = 0
@@ -514,10 +509,6 @@ class _Engine:
             tail.bias_p = torch.zeros(tail.cout_p, dtype=torch.float32, device=dev)
             self.stages.append(dict(kind='dec', convs=(a, b), tail=tail))
         self.convs = convs
-        for i, u in enumerate(convs):
-            u.index, u.fwd_fin_in_launch, u.bwd_fin_in_launch = i, False, False
-        # ticket counters of the in-launch BatchNorm finalize (clamd_conv3x3_tail): one per unit and direction, zero between launches
-        self.tickets = torch.zeros(2 * len(convs), dtype=torch.int32, device=dev)
         for u in convs:
             u.apply_folded, u.fold_src = False, None
         for st in self.stages:
@@ -922,23 +913,12 @@ class _Engine:
                 name = ('clamd_conv3x3_winograd24_direct_filters' if u.direct_f else 'clamd_conv3x3_winograd24') if u.w24 else 'clamd_conv3x3_winograd'
                 _timed('igemm_conv3x3', flops, nbytes, name, ptr(xin), xin_ldc, ptr(u.wf), ptr(bias), ptr(y), u.y_ldc, ptr(st), rows,
                        Bl, u.h, u.w_, u.cin_p, u.cout_p, relu, tp, s)
-        elif st is not None and self.tail_finalize:
-            v = u.vec
-            tail = _lib.BnTail(ticket=self.tickets[u.index:], kind=1, C=u.cout, gamma=u.gamma, beta=u.beta, running_mean=u.rm, running_var=u.rv,
-                               scale=v[0], shift=v[1], save_mean=v[2], save_istd=v[3], num_batches_tracked=u.nbt,
-                               count=float(self.B * u.h * u.w_), momentum=BN_MOMENTUM, eps=BN_EPS)
-            _timed('igemm_conv3x3', flops, nbytes, 'clamd_conv3x3_tail', ptr(xin), xin_ldc, ptr(u.wf), ptr(bias), ptr(y), u.cout_p,
-                   ptr(st), None, None, rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, relu, u.m_fastest, dc, tp, tail.ref(), s)
-            u.fwd_fin_in_launch = True
         else:
             _timed('igemm_conv3x3', flops, nbytes, 'clamd_conv3x3', ptr(xin), xin_ldc, ptr(u.wf), ptr(bias), ptr(y), u.cout_p,
                    ptr(st), None, None, rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, relu, u.m_fastest, dc, tp, s)
 
     def _fwd_finalize(self, u, training, s):
         v = u.vec
-        if u.fwd_fin_in_launch:      # done by the convolution launch itself (clamd_conv3x3_tail)
-            u.fwd_fin_in_launch = False
-            return
         call('clamd_bn_finalize', ptr(u.stats) if training else None, u.stat_rows, ptr(u.gamma), ptr(u.beta), ptr(u.rm), ptr(u.rv),
              ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(v[3]), u.cout_p, u.cout, float(self.B * u.h * u.w_), BN_MOMENTUM, BN_EPS,
              ptr(u.nbt) if training else None, s)      # num_batches_tracked += 1 inside the launch (was a torch._foreach_add_ on the critical chain)
@@ -1075,11 +1055,8 @@ class _Engine:
             call('clamd_bn_bwd_reduce', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.y_ldc,
                  ptr(v[0]), ptr(v[1]), ptr(u.sums), u.sum_rows, B, u.h, u.w_, u.cout_p, dc, tp, s)
         two = u.fused_reduce and u.gz_nrows > 0      # the producing launch took sum g and sum g y only: d conv-bias = sum g_z, from the apply pass
-        if u.bwd_fin_in_launch:      # the data-gradient launch that wrote the sums ran the finalize in its last workgroup (clamd_conv3x3_tail)
-            u.bwd_fin_in_launch = False
-        else:
-            call('clamd_bn_bwd_finalize', ptr(u.sums), u.sum_rows, ptr(u.gamma), ptr(v[2]), ptr(v[3]), ptr(v[4]), g[u.keys[2]],
-                 g[u.keys[3]], None if two else g[u.keys[1]], u.cout_p, u.cout, count, s)
+        call('clamd_bn_bwd_finalize', ptr(u.sums), u.sum_rows, ptr(u.gamma), ptr(v[2]), ptr(v[3]), ptr(v[4]), g[u.keys[2]],
+             g[u.keys[3]], None if two else g[u.keys[1]], u.cout_p, u.cout, count, s)
         if two:
             assert gp is None
             call('clamd_bn_bwd_apply_sums', ptr(ga), ga_ldc, ptr(u.y), u.y_ldc, ptr(v[4]), ptr(u.gz), u.cout_p, ptr(u.gz_rows), u.gz_nrows,
@@ -1118,18 +1095,6 @@ class _Engine:
                 name = 'clamd_conv3x3_winograd24_direct_filters' if u.direct_d else ('clamd_conv3x3_winograd24' if u.w24d else 'clamd_conv3x3_winograd')
                 _timed('igemm_conv3x3', flops, self._conv_bytes(u), name, ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
                        B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
-            elif u.g_in is not None and u.consumer is not None and self.tail_finalize:
-                a = u.consumer      # this launch writes the BatchNorm-backward sums of unit a AND (last workgroup) finalizes them
-                gp_ = self._gp
-                two_a = a.fused_reduce and a.gz_nrows > 0
-                tail = _lib.BnTail(ticket=self.tickets[len(self.convs) + a.index:], kind=2, C=a.cout, gamma=a.gamma, save_mean=a.vec[2],
-                                   save_istd=a.vec[3], k012=a.vec[4], dgamma=gp_[a.keys[2]], dbeta=gp_[a.keys[3]],
-                                   dbias=None if two_a else gp_[a.keys[1]], count=float(B * a.h * a.w_))
-                _timed('igemm_conv3x3', flops, self._conv_bytes(u),
-                       'clamd_conv3x3_tail', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,
-                       ptr(a.y), ptr(a.sums), a.sum_rows,
-                       B, u.h, u.w_, u.cout_p, u.cin_p, 0, 1 if 9 * u.cin_p > B * u.h * u.w_ else 0, dc, tp, tail.ref(), s)
-                a.bwd_fin_in_launch = True
             elif u.g_in is not None:
                 _timed('igemm_conv3x3', flops, self._conv_bytes(u),
                        'clamd_conv3x3', ptr(u.gz), u.cout_p, ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None,

@@ -99,38 +99,6 @@ enum { CLAMD_RELU = 1, CLAMD_BIAS_BORDER_CLASSES = 2 };
 int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
                   float* stats, const void* bn_y, float* bn_sums, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p,
                   int relu, int m_fastest, int dtype, const clamd_tuning* tune, void* stream);
-
-/* clamd_conv3x3 followed, on the same stream, by the BatchNorm finalize of the rows it wrote -- clamd_bn_finalize on `stats` (kind 1: the
- * nn.BatchNorm2d behind the convolution, models/unet.py:15,18) or clamd_bn_bwd_finalize on `bn_sums` (kind 2: the unit whose gradient this
- * data-gradient launch produces).  Where the kernel structure allows (the persistent and the producer/consumer kernels, <= 1024 output
- * channels), the finalize runs INSIDE the launch: the rows are stored write-through, the workgroup that finishes last (a ticket counter; one
- * agent-scope acquire; nobody waits) adds them in a fixed fp64 order of its own -- deterministic, equal to the stand-alone finalize to fp64
- * rounding of the sums -- which takes the 5-7 us finalize launch off the chain conv -> finalize -> apply -> conv; elsewhere the library
- * enqueues the finalize kernel itself.  `ticket`: one device unsigned int, ZERO before the first
- * launch (the launch leaves it zero); one counter per concurrently running launch.  Fields of the other kind are ignored. */
-typedef struct clamd_bn_tail {
-    unsigned int* ticket;
-    int kind;                        /* 1 forward statistics, 2 backward sums */
-    int C;                           /* logical channels (Cout_p padded ones are finalized with gamma = beta = 0) */
-    const float* gamma;
-    const float* beta;               /* kind 1 */
-    float* running_mean;             /* kind 1, may be NULL */
-    float* running_var;
-    float* scale;                    /* kind 1 outputs [Cout_p] */
-    float* shift;
-    float* save_mean;                /* kind 1 output, kind 2 input */
-    float* save_istd;
-    long long* num_batches_tracked;  /* kind 1, may be NULL */
-    float* k012;                     /* kind 2 outputs: [3][Cout_p], [C], [C], [C] (dbias may be NULL) */
-    float* dgamma;
-    float* dbeta;
-    float* dbias;
-    double count, momentum, eps;     /* elements per channel; nn.BatchNorm2d momentum and eps (kind 1) */
-} clamd_bn_tail;
-int clamd_sizeof_bn_tail(void);
-int clamd_conv3x3_tail(const void* x, int x_ldc, const void* w_packed, const float* bias, void* y, int y_ldc,
-                       float* stats, const void* bn_y, float* bn_sums, int stat_rows, int B, int H, int W, int Cin_p, int Cout_p,
-                       int relu, int m_fastest, int dtype, const clamd_tuning* tune, const clamd_bn_tail* tail, void* stream);
 int clamd_conv3x3_border_bias_ok(int B, int H, int W, int Cin_p, int Cout_p, int dtype, const clamd_tuning* tune);
 /* How many of the five sums a PLAIN (no bias, ReLU, statistics) clamd_conv3x3 launch with bn_y / bn_sums takes: 5, or 2 where the
  * persistent bf16 kernel runs it (channels-in-the-lane epilogue: sum g and sum g y as running sums per accumulator register; rows

@@ -381,95 +381,6 @@ def test_conv3x3_kernel_structures_agree(C, name, dcode, shape):
 
 
 @pytest.mark.parametrize('name,dcode', DT)
-@pytest.mark.parametrize('shape', VARIANT_SHAPES)
-def test_conv3x3_tail_finalizes_in_the_launch(C, name, dcode, shape):
-    """clamd_conv3x3_tail = clamd_conv3x3 + clamd_bn_finalize (kind 1) / clamd_bn_bwd_finalize (kind 2) with the finalize run inside the
-    launch by the workgroup that finishes last (persistent and producer/consumer kernels; the baseline kernel gets the finalize launch
-    from the library): the activations and the batch counter bit for bit; every output vector and the running statistics to an ulp or two
-    (the in-launch finalize adds the rows in its own fixed fp64 order, so the sums agree to fp64 rounding and two launches of it bit for bit);
-    three launches in a row on the same ticket counter (it must come back to zero), for every kernel structure and dtype."""
-    B, cin, cout, H, W = shape
-    rng = np.random.default_rng(31)
-    segs = [(cin, C.ops.cpad(cin))]
-    x, w, b, xt, wf, wd, bp, cin_p, cout_p = _conv_case(C, rng, B, segs, cout, H, W, dcode)
-    lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()
-    T = C.ops.TORCH_DT[dcode]
-    gamma, beta = dev(rnd(rng, cout)), dev(rnd(rng, cout))
-    count = float(B * H * W)
-    ticket = torch.zeros(1, dtype=torch.int32, device='cuda')
-    for k1, v1, k2, v2 in CONV_VARIANTS:
-        tn = lib.Tuning(**{k1: v1, k2: v2})
-        stats, rows = stat_buf(C, lib.OP_CONV3X3, B, H, W, cin_p, cout_p, dcode, tuning=tn)
-        y = torch.empty(B, H, W, cout_p, dtype=T, device='cuda')
-
-        def fresh():
-            return (torch.full((4, cout_p), float('nan'), device='cuda'), dev(rnd(np.random.default_rng(5), cout)),
-                    dev(np.abs(rnd(np.random.default_rng(6), cout)) + 0.5), torch.full((1,), 3, dtype=torch.int64, device='cuda'))
-        va, rma, rva, nba = fresh()
-        vb, rmb, rvb, nbb = fresh()
-        for rep in range(3):
-            lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, rows, B, H, W, cin_p, cout_p,
-                     1, 0, dcode, tn.ref(), s)
-            lib.call('clamd_bn_finalize', ptr(stats), rows, ptr(gamma), ptr(beta), ptr(rma), ptr(rva), ptr(va[0]), ptr(va[1]), ptr(va[2]), ptr(va[3]),
-                     cout_p, cout, count, 0.1, 1e-5, ptr(nba), s)
-            ya = y.clone()
-            y.fill_(7.0); stats.fill_(float('nan'))
-            tail = lib.BnTail(ticket=ticket, kind=1, C=cout, gamma=gamma, beta=beta, running_mean=rmb, running_var=rvb, scale=vb[0], shift=vb[1],
-                              save_mean=vb[2], save_istd=vb[3], num_batches_tracked=nbb, count=count, momentum=0.1, eps=1e-5)
-            lib.call('clamd_conv3x3_tail', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, rows, B, H, W, cin_p, cout_p,
-                     1, 0, dcode, tn.ref(), tail.ref(), s)
-            sync()
-            assert int(ticket) == 0, (k1, v1, k2, v2, rep)
-            assert torch.equal(ya, y)
-            close = lambda a_, b_: bool(((a_ - b_).abs() <= 4e-7 * (a_.abs() + b_.abs()) + 1e-30).all())      # a few ulp of fp32
-            assert close(va, vb) and close(rma, rmb) and close(rva, rvb) and int(nba) == int(nbb) == 4 + rep, (k1, v1, k2, v2, rep)
-            if rep == 0:
-                vfirst = vb.clone()
-        assert bool(torch.isfinite(va).all())
-        # the in-launch finalize is deterministic: a fresh run of the same three launches reproduces its vectors bit for bit
-        vc, rmc, rvc, nbc = fresh()
-        tail = lib.BnTail(ticket=ticket, kind=1, C=cout, gamma=gamma, beta=beta, running_mean=rmc, running_var=rvc, scale=vc[0], shift=vc[1],
-                          save_mean=vc[2], save_istd=vc[3], num_batches_tracked=nbc, count=count, momentum=0.1, eps=1e-5)
-        lib.call('clamd_conv3x3_tail', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, rows, B, H, W, cin_p, cout_p,
-                 1, 0, dcode, tn.ref(), tail.ref(), s)
-        sync()
-        assert torch.equal(vc, vfirst)
-    # kind 2: a data-gradient launch that carries the BatchNorm-backward sums of the unit in front of it
-    tn = lib.Tuning()
-    nk = lib.load().clamd_bn_bwd_nsums()
-    two = lib.load().clamd_conv3x3_bn_sums(B, H, W, cin_p, cout_p, dcode, tn.ref()) == 2
-    rows = lib.stat_rows(lib.OP_CONV3X3, B, H, W, cin_p, cout_p, dcode, fused_bn=1, tuning=tn)
-    sums = torch.full((rows, nk, cout_p), float('nan'), device='cuda')
-    ysave = C.ops.to_nhwc(dev(np.maximum(rb(rnd(rng, B, cout, H, W), dcode), 0)), dcode)
-    mean, istd = dev(rnd(rng, cout_p)), dev(np.abs(rnd(rng, cout_p)) + 0.5)
-    gfull = torch.zeros(cout_p, device='cuda'); gfull[:cout] = gamma
-    g = torch.empty(B, H, W, cout_p, dtype=T, device='cuda')
-
-    def outs():
-        return [torch.full((3, cout_p), float('nan'), device='cuda')] + [torch.full((cout,), float('nan'), device='cuda') for _ in range(3)]
-    oa, ob = outs(), outs()
-    for rep in range(2):
-        lib.call('clamd_conv3x3', ptr(xt), cin_p, ptr(wf), None, ptr(g), cout_p, None, ptr(ysave), ptr(sums), rows, B, H, W, cin_p, cout_p,
-                 0, 0, dcode, tn.ref(), s)
-        lib.call('clamd_bn_bwd_finalize', ptr(sums), rows, ptr(gfull), ptr(mean), ptr(istd), ptr(oa[0]), ptr(oa[1]), ptr(oa[2]),
-                 None if two else ptr(oa[3]), cout_p, cout, count, s)
-        sums.fill_(float('nan'))
-        tail = lib.BnTail(ticket=ticket, kind=2, C=cout, gamma=gfull, save_mean=mean, save_istd=istd, k012=ob[0], dgamma=ob[1], dbeta=ob[2],
-                          dbias=None if two else ob[3], count=count)
-        lib.call('clamd_conv3x3_tail', ptr(xt), cin_p, ptr(wf), None, ptr(g), cout_p, None, ptr(ysave), ptr(sums), rows, B, H, W, cin_p, cout_p,
-                 0, 0, dcode, tn.ref(), tail.ref(), s)
-        sync()
-        assert int(ticket) == 0
-        for a_, b_ in list(zip(oa, ob))[:3 if two else 4]:
-            assert bool(((a_ - b_).abs() <= 2e-6 * (a_.abs() + b_.abs()) + 1e-6 * float(a_.abs().max())).all())
-    bad = lib.BnTail(kind=1)                                   # (kept alive: .ref() is the address of the Python-owned struct)
-    stats, rows = stat_buf(C, lib.OP_CONV3X3, B, H, W, cin_p, cout_p, dcode, tuning=tn)
-    with pytest.raises(RuntimeError, match='ticket'):
-        lib.call('clamd_conv3x3_tail', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y), cout_p, ptr(stats), None, None, rows, B, H, W, cin_p, cout_p,
-                 1, 0, dcode, tn.ref(), bad.ref(), s)
-
-
-@pytest.mark.parametrize('name,dcode', DT)
 @pytest.mark.parametrize('shape', [(2, 64, 64, 40, 64), (1, 256, 96, 16, 16), (5, 40, 130, 24, 40)])
 def test_wgrad_kernel_structures_agree(C, name, dcode, shape):
     """wgrad: two-workgroups-per-CU vs producer/consumer kernel (different split-K widths: equal up to rounding)."""
