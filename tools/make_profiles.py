@@ -106,5 +106,10 @@ for dt in DT:
         by = v['hbm_read_bytes_per_launch'] + v['hbm_write_bytes_per_launch']
         L.append(f"| `{k}` | {v['hbm_read_bytes_per_launch'] / 1e6:.1f} | {v['hbm_write_bytes_per_launch'] / 1e6:.1f} | {v['avg_launch_us']} | {by / max(v['avg_launch_us'], 1e-9) / 1e3:.0f} |")
     L.append('')
+# side evidence that is not regenerated by profile_round.sh: listed when present
+if os.path.exists(f'{P}/{dst}_wino24g_band.txt'):
+    L.append(f"`{dst}_wino24g_band.txt`: `tools/wino24g_band.sh` — launch time and FETCH_SIZE (x2 corrected) of `wino24g_kernel` under every block order "
+             "(`clamd_tuning::wino_band`) on three wide layer shapes: the traffic model of DESIGN §4 (V·slabs/b + F·tiles/a, a·b = 32) to 1 %, and launch "
+             "times that do not follow it.\n")
 open(f'{P}/README.md', 'w').write('\n'.join(L) + '\n')
 print('\n'.join(L[:30]))
