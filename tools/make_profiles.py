@@ -111,5 +111,9 @@ if os.path.exists(f'{P}/{dst}_wino24g_band.txt'):
     L.append(f"`{dst}_wino24g_band.txt`: `tools/wino24g_band.sh` — launch time and FETCH_SIZE (x2 corrected) of `wino24g_kernel` under every block order "
              "(`clamd_tuning::wino_band`) on three wide layer shapes: the traffic model of DESIGN §4 (V·slabs/b + F·tiles/a, a·b = 32) to 1 %, and launch "
              "times that do not follow it.\n")
+if os.path.exists(f'{P}/{dst}_mfma_second_wave.txt'):
+    L.append(f"`{dst}_mfma_second_wave.txt`: `tools/ubench/mfma_lds_power.hip` — clock of a power-limited bf16 MFMA loop (one wave per SIMD, random operands) with a "
+             "second wave per SIMD that exits / sleeps / runs VALU / reads or writes LDS / waits at a barrier: 1.82-1.90 GHz alone or beside a barrier-waiting wave, "
+             "1.51-1.66 GHz beside a wave that issues anything, at unchanged cycles per MFMA.\n")
 open(f'{P}/README.md', 'w').write('\n'.join(L) + '\n')
 print('\n'.join(L[:30]))
