@@ -996,7 +996,7 @@ def test_head_fwd_bwd(C, name, dcode, shape):
 
 
 @pytest.mark.parametrize('name,dcode', DT)
-@pytest.mark.parametrize('shape', [(2, 3, 64, 16, 48), (1, 1, 5, 32, 32), (2, 3, 7, 8, 12)])
+@pytest.mark.parametrize('shape', [(2, 3, 64, 16, 48), (1, 1, 5, 32, 32), (2, 3, 7, 8, 12), (1, 3, 8, 6, 10), (3, 2, 40, 40, 72)])      # (widths that are not a multiple of 4 take the piece-per-thread kernel in bf16 too; 3 x 40 x 72 / 4 quads end inside a workgroup)
 def test_first_layer_im2col_path(C, name, dcode, shape):
     """enc1.0 (Cin = 3, models/unet.py:50) as im2col + pointwise GEMM: forward (+ReLU, BN stats) and weight gradient
     against the oracle's 3x3 conv."""
