@@ -115,5 +115,9 @@ if os.path.exists(f'{P}/{dst}_mfma_second_wave.txt'):
     L.append(f"`{dst}_mfma_second_wave.txt`: `tools/ubench/mfma_lds_power.hip` — clock of a power-limited bf16 MFMA loop (one wave per SIMD, random operands) with a "
              "second wave per SIMD that exits / sleeps / runs VALU / reads or writes LDS / waits at a barrier: 1.82-1.90 GHz alone or beside a barrier-waiting wave, "
              "1.51-1.66 GHz beside a wave that issues anything, at unchanged cycles per MFMA.\n")
+if os.path.exists(f'{P}/{dst}_bench_gloo4_rehearsal.jsonl'):
+    L.append(f"`{dst}_bench_gloo4_rehearsal.jsonl`: `CLAMD_BENCH_BACKEND=gloo python bench.py --gpus 4 --steps 5 --warmup 2 [--dtype bf16]` on ONE card (four rank "
+             "processes sharing it, gradients through gloo on the host: the times mean nothing) — the N = 4 code path of the driver's scaling run end to end: "
+             "rank spawn, six bucketed collectives per step in launch order, bf16 exchange for the bf16 model, the `comm` record.\n")
 open(f'{P}/README.md', 'w').write('\n'.join(L) + '\n')
 print('\n'.join(L[:30]))
