@@ -54,3 +54,14 @@ med = lambda v: sorted(v)[len(v) // 2]
 names = ['forward', 'zero_grad', 'loss', 'backward', 'adam']
 print(f'{dtype}: enqueue {med(host) * 1e3:.3f} ms per step (median; ' + ', '.join(f'{n} {med([p[i] for p in parts]) * 1e3:.3f}' for i, n in enumerate(names)) +
       f'); step from an idle GPU {med(total) * 1e3:.3f} ms; free-running {free * 1e3:.3f} ms per step')
+
+# free-running: where does the host spend a step when nothing synchronises explicitly?  (a part that takes as long as the GPU step is where
+# the runtime throttles the host -- the GPU then starts that part's kernels late)
+parts = []
+torch.cuda.synchronize()
+for _ in range(steps):
+    step(parts)
+torch.cuda.synchronize()
+tail = parts[len(parts) // 2:]
+print(f'{dtype}: free-running host time per step ' + ', '.join(f'{n} {med([p[i] for p in tail]) * 1e3:.3f}' for i, n in enumerate(names)) +
+      f'; sum {sum(med([p[i] for p in tail]) for i in range(5)) * 1e3:.3f} ms')
