@@ -122,5 +122,8 @@ if os.path.exists(f'{P}/{dst}_bench_gloo4_rehearsal.jsonl'):
 if os.path.exists(f'{P}/{dst}_mfma_shapes.txt'):
     L.append(f"`{dst}_mfma_shapes.txt`: `tools/ubench/mfma_shapes.hip` — sustained rate of bare MFMA loops on pseudo-random and on zero operands: bf16 32x32x16 "
              "1.9 PFLOP/s (1.83 GHz) and 16x16x32 2.13 PFLOP/s on random data against 2.47 PFLOP/s (2.37 GHz) on zeros — a power limit; fp32 32x32x2 155 TFLOP/s either way.\n")
+if os.path.exists(f'{P}/{dst}_partial_line_pmc.txt'):
+    L.append(f"`{dst}_partial_line_pmc.txt`: `tools/partial_line_pmc.sh` — texture-addresser busy cycles and write requests per launch of the loss kernel's NHWC copy "
+             "and of the filter pack, shipped against the predecessors (a variant build): the counters behind DESIGN's \"partial lines cost what full lines cost\".\n")
 open(f'{P}/README.md', 'w').write('\n'.join(L) + '\n')
 print('\n'.join(L[:30]))
