@@ -125,5 +125,7 @@ if os.path.exists(f'{P}/{dst}_mfma_shapes.txt'):
 if os.path.exists(f'{P}/{dst}_partial_line_pmc.txt'):
     L.append(f"`{dst}_partial_line_pmc.txt`: `tools/partial_line_pmc.sh` — texture-addresser busy cycles and write requests per launch of the loss kernel's NHWC copy "
              "and of the filter pack, shipped against the predecessors (a variant build): the counters behind DESIGN's \"partial lines cost what full lines cost\".\n")
+if os.path.exists(f'{P}/{dst}_layers_bf16_config5.txt'):
+    L.append(f"`{dst}_layers_bf16_config5.txt`: `python tools/layer_table.py bf16 512 32` — the per-layer table at BASELINE configs[4]'s per-GPU workload (512x512, bs32, bf16).\n")
 open(f'{P}/README.md', 'w').write('\n'.join(L) + '\n')
 print('\n'.join(L[:30]))
