@@ -120,3 +120,25 @@ def test_hardware_queue_count_is_measured():
         got[q] = int(line.split()[1])
     print(got)
     assert got['2'] <= 2 < got['8'], got
+
+
+def test_bench_single_gpu_line_carries_calibration_and_traffic_fields():
+    """The one-GPU driver line: `roofline` with the sustained-MFMA calibration measured in the same process, the traffic ratio fields (null for a
+    workload no PMC profile was committed for), an `also` entry per further dtype -- on a small workload so that the test stays short."""
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'CLAMD_BENCH_BACKEND', 'CLAMD_BENCH_FORCE_DIST'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--size', '128', '--batch', '4',
+                          '--no-cpu-baseline', '--also', 'bf16'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['dtype'] == 'f32' and d['unit'] == 'images/sec' and d['vs_baseline'] is None
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['peak'] == 157.3 and 0 < r['frac'] < 1
+    assert 100 < r['sustained_mfma_tflops_measured'] < 160 and abs(r['frac_of_sustained'] - r['achieved'] / r['sustained_mfma_tflops_measured']) < 2e-3
+    # 128 x 128 bs4 has no committed PMC profile: the traffic fields are there and empty, nothing is invented
+    assert d['hbm_bytes_per_step'] is None and d['algorithmic_bytes_per_step'] is None and d['hbm_over_algorithmic'] is None
+    (a,) = d['also']
+    assert a['dtype'] == 'bf16' and 1000 < a['mfma_sustained_tflops_measured'] < 2600 and 0 < a['conv3x3_igemm_frac_of_sustained'] < 1.2
