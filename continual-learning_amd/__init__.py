@@ -10,7 +10,6 @@ from .optim import FusedAdam  # noqa: F401
 from .metrics import argmax_confusion, eval_metrics, metrics_from_confusion  # noqa: F401
 from .trainer import Trainer, default_config  # noqa: F401
 from . import data, ddp  # noqa: F401
-from .graph import GraphedStep  # noqa: F401
 
-__all__ = ['GraphedStep', 'UNet', 'CrossEntropyLoss', 'DistillationCrossEntropy', 'FusedAdam', 'Trainer', 'default_config',
+__all__ = ['UNet', 'CrossEntropyLoss', 'DistillationCrossEntropy', 'FusedAdam', 'Trainer', 'default_config',
            'argmax_confusion', 'eval_metrics', 'metrics_from_confusion', 'data', 'ddp', 'synth']

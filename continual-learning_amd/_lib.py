@@ -115,6 +115,7 @@ SIGNATURES = {
     'clamd_voc_prepare': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_label_to_rgb': (_I, [_P, _P, _LL, _LL, _P]),
     'clamd_fill_f32': (_I, [_P, _LL, _D, _P]),
+    'clamd_hold_cus': (_I, [_I, _I, _P]),
     'clamd_f32_to_bf16': (_I, [_P, _P, _LL, _P]),
     'clamd_bf16_to_f32': (_I, [_P, _P, _LL, _P]),
     'clamd_scale_by_device_scalar': (_I, [_P, _LL, _P, _P]),

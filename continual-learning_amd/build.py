@@ -53,6 +53,11 @@ def build(force=False, verbose=True, diag=False, variant=None, extra_flags=()):
         return out
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
+    # objects of sources that have left the library (an experiment removed again) must not travel to the GPU box with the snapshot
+    keep = {src.replace('.hip', '.o') for src in SOURCES}
+    for f in os.listdir(objdir):
+        if f.endswith('.o') and f not in keep:
+            os.remove(os.path.join(objdir, f))
 
     def cc(src):
         obj = os.path.join(objdir, src.replace('.hip', '.o'))

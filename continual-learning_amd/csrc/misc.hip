@@ -997,11 +997,12 @@ long long clamd_debug_mfma_rate(int dtype, int iters, float* sink_65536, void* s
     return 256ll * 4 * iters * 32 * (dtype == CLAMD_F32 ? 4096 : 32768);      // FLOP of the launch
 }
 
-int clamd_debug_hold_cus(int ncus, int usec, void* stream) {
-    if (ncus < 1 || ncus > 256 || usec < 1 || usec > 2000000) return clamd_fail("debug_hold_cus: 1..256 CUs for 1..2000000 us");
+int clamd_hold_cus(int ncus, int usec, void* stream) {
+    if (ncus < 1 || ncus > 256 || usec < 1 || usec > 2000000) return clamd_fail("hold_cus: 1..256 CUs for 1..2000000 us");
     hipLaunchKernelGGL(hold_cus_kernel, dim3(ncus), dim3(256), 0, (hipStream_t)stream, (unsigned long long)usec * 100ull, (unsigned int*)nullptr);
-    return clamd_check_launch("debug_hold_cus");
+    return clamd_check_launch("hold_cus");
 }
+int clamd_debug_hold_cus(int ncus, int usec, void* stream) { return clamd_hold_cus(ncus, usec, stream); }
 
 int clamd_fill_f32(float* p, long long n, double v, void* stream) {
     int g = (int)((n + 255) / 256);

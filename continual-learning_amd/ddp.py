@@ -44,36 +44,55 @@ def init_rccl(device, max_channels=RCCL_MAX_CHANNELS, **kw):
 
 
 _HW_QUEUES = {}
-_HW_PROBE = {}        # device -> (wall us of the eight-stream probe, us of one kernel): what hw_queues() decided from
+_HW_PROBE = {}        # device -> {'wall_us': three tries, 'kernel_us', 'measured': bool}: what hw_queues() decided from
+
+
+def _queues_from_env():
+    try:
+        return max(1, min(8, int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))))      # the runtime's default is 4
+    except ValueError:
+        return 4
 
 
 def hw_queues(device, upto=8):
     """Hardware queues this process's HIP streams are multiplexed onto, MEASURED (GPU_MAX_HW_QUEUES is read by the runtime when it starts: a
     value exported later, or by a caller that initialised HIP first, is not what runs).  `upto` fresh streams each get one spin kernel of the
-    same length (clamd_debug_hold_cus: one workgroup spinning on the wall clock); kernels that share a hardware queue run one after the other,
-    so wall time / kernel time = streams per queue.  ~4 ms, once per device and process."""
+    same length (clamd_hold_cus: one workgroup spinning on the wall clock for 2 ms); kernels that share a hardware queue run one after the
+    other, so wall time / kernel time = streams per queue.  The ratio has to land within 0.25 of a whole number in two of three tries -- a
+    loaded host, a profiler or other processes on the card stretch the wall time by fractions of a kernel -- otherwise the count is UNKNOWN
+    and the runtime's own setting (GPU_MAX_HW_QUEUES, default 4) is reported instead, with `_HW_PROBE[dev]['measured'] = False`.  ~20 ms, once
+    per device and process; never during a stream capture (the probe synchronises: the engine calls it when it is built)."""
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key in _HW_QUEUES:
         return _HW_QUEUES[key]
+    if torch.cuda.is_current_stream_capturing():
+        return _queues_from_env()              # not cached: the next call outside the capture measures
     import time
     from . import _lib
-    hold_us = 400
+    hold_us = 2000
     with torch.cuda.device(key):
         streams = [torch.cuda.Stream(device=device) for _ in range(upto)]
-        _lib.call('clamd_debug_hold_cus', 1, 10, streams[0].cuda_stream)       # loads the kernel
-        best = None
+        _lib.call('clamd_hold_cus', 1, 10, streams[0].cuda_stream)       # loads the kernel
+        votes, walls = [], []
         for _ in range(3):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for st in streams:                   # one workgroup each, spinning on the wall clock for hold_us: nothing to contend for but the queue
-                _lib.call('clamd_debug_hold_cus', 1, hold_us, st.cuda_stream)
+                _lib.call('clamd_hold_cus', 1, hold_us, st.cuda_stream)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) * 1e6
-            best = dt if best is None else min(best, dt)
-        per_queue = max(1, min(upto, int(best / hold_us + 0.35)))      # streams behind one another on the busiest queue (launch + sync overhead: < 0.3 of a kernel)
-        n = max(1, min(upto, -(-upto // per_queue)))
+            walls.append(round(dt, 1))
+            ratio = dt / hold_us                 # launch + sync overhead adds < 0.15 of a 2-ms kernel on an idle host
+            per_queue = int(ratio + 0.35)
+            if 1 <= per_queue <= upto and -0.1 <= ratio - per_queue <= 0.25:
+                votes.append(per_queue)
+        agreed = [v for v in set(votes) if votes.count(v) >= 2]
+        if agreed:
+            n, measured = max(1, min(upto, -(-upto // agreed[0]))), True
+        else:
+            n, measured = _queues_from_env(), False
     _HW_QUEUES[key] = n
-    _HW_PROBE[key] = (round(best, 1), hold_us)
+    _HW_PROBE[key] = {'wall_us': walls, 'kernel_us': hold_us, 'measured': measured}
     return n
 
 

@@ -47,7 +47,9 @@ class _CEFn(torch.autograd.Function):
             if old_logits.shape[0] != B or tuple(old_logits.shape[2:]) != (H, W):
                 raise ValueError('old_logits must be [B, K_old, H, W]')
         ctx.sink = None
-        if old_logits is None and (H * W) % 4 == 0:
+        # the four-pixel kernels read 16 bytes of logits / 32 bytes of labels per lane: an odd storage offset takes the scalar kernel
+        aligned = logits.data_ptr() % 16 == 0 and dl.data_ptr() % 16 == 0 and labels.data_ptr() % 32 == 0
+        if old_logits is None and (H * W) % 4 == 0 and aligned:
             # the training-step form: the count of valid pixels as partial rows (no memset, no atomics), and, when the logits come from this
             # package's UNet, d logits written a second time in the layout (and dtype) its 1x1 head's data gradient reads -- the backward
             # pass then starts without a conversion pass (unet._Engine.backward)
@@ -59,7 +61,9 @@ class _CEFn(torch.autograd.Function):
                  int(ignore_index), 1.0, _lib.stream_ptr())
             if eng is not None:
                 ctx.sink = eng
-                eng.dl_src = (dl.data_ptr(), dl._version, eng.generation)
+                # a STRONG reference: while the engine waits for this gradient its storage cannot be freed and handed to another
+                # tensor of the same shape (a second loss on the same logits would otherwise pass for this one by address)
+                eng.dl_src = (dl, dl.data_ptr(), dl._version, eng.generation)
         else:
             call('clamd_ce_fwd_bwd', ptr(logits), ptr(labels), ptr(old_logits), kold, int(c_old), float(temperature),
                  float(lam), ptr(dl), ptr(out3), ptr(ws), wsb, B, K, H, W, int(ignore_index), 1.0, _lib.stream_ptr())
@@ -78,7 +82,7 @@ class _CEFn(torch.autograd.Function):
         # touches d logits only when it is not 1 -- no host sync, no 176-MB multiply-by-one pass per step
         g = g.contiguous().float()
         eng = ctx.sink
-        if eng is not None and eng.dl_src is not None and eng.dl_src[0] == dl.data_ptr():      # the NHWC copy follows: both in one launch
+        if eng is not None and eng.dl_src is not None and eng.dl_src[1] == dl.data_ptr():      # the NHWC copy follows: both in one launch
             call('clamd_scale_by_device_scalar_nhwc', ptr(eng.dl), eng.dl.numel(), eng.dcode, ptr(g), ptr(dl), dl.numel(), _lib.stream_ptr())
         else:
             call('clamd_scale_by_device_scalar', ptr(dl), dl.numel(), ptr(g), _lib.stream_ptr())

@@ -99,7 +99,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def sync_hyper(self):
         """Upload lr / betas / eps / gradient scale / L2 weight to device memory if they changed on the host (LambdaLR
-        writes param_groups[0]['lr']).  step() calls this; a replayed HIP graph of the step (graph.GraphedStep) calls it
+        writes param_groups[0]['lr']).  step() calls this; a replayed HIP graph of the step (tools/graphed_step.py) calls it
         before every replay, because the captured Adam kernel reads the values from that device buffer."""
         group = self.param_groups[0]
         hyper = (float(group['lr']), float(group['betas'][0]), float(group['betas'][1]), float(group['eps']),

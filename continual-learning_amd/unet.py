@@ -984,7 +984,7 @@ class _Engine:
                 h, w = H >> t.level, W >> t.level
                 if t.kind == 'head':
                     src = self.dl_src
-                    if not (src is not None and src == (gout.data_ptr(), gout._version, self.generation)):
+                    if not (src is not None and src[1:] == (gout.data_ptr(), gout._version, self.generation)):
                         # not the tensor this package's loss wrote beside its NHWC copy (another loss, a hook, a sum of gradients): convert
                         call('clamd_nchw_to_nhwc', ptr(gout), ptr(self.dl), self.Kp, B, self.K, H, W, self.Kp, 1.0, dc, s)
                     self.dl_src = None

@@ -326,6 +326,11 @@ int clamd_voc_prepare(const unsigned char* img_rgb, const unsigned char* mask_rg
 /* voc.to_rgb (datasets/voc.py:74-89): labels int64 [N,H,W] -> palette colours [N,3,H,W] (0..255 as float). */
 int clamd_label_to_rgb(const long long* labels, float* rgb, long long n_img, long long hw, void* stream);
 int clamd_fill_f32(float* p, long long n, double v, void* stream);
+/* `ncus` workgroups (1..256) that each keep one whole CU (96 KB of LDS) for `usec` microseconds of wall clock and touch no memory:
+ * what an RCCL channel workgroup does to the one-workgroup-per-CU kernels of this library during a collective (trainer.py:120-122
+ * becomes one process per GPU, ddp.py).  The data-parallel host code uses it with ncus = 1 to MEASURE how many hardware queues the
+ * runtime multiplexes its streams onto (ddp.hw_queues); tools/cu_steal.py rehearses held CUs with it. */
+int clamd_hold_cus(int ncus, int usec, void* stream);
 /* Gradient exchange in bf16 (replaces the reduce of nn.DataParallel, trainer.py:120-122, for BASELINE.json configs[2]/[4]
  * "bf16 DDP"): a bucket of the flat fp32 gradient buffer rounded to bf16 (rne) for the RCCL all-reduce and widened back.
  * A bucket may start at any element: the bf16 buffer must sit at the same element phase, (address / element size) % 8. */

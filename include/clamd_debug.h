@@ -1,6 +1,6 @@
 /* clamd_debug.h -- test and measurement scaffolding exported by libclamd.so.  NOT part of the product ABI: include/clamd.h
  * does not include this file, nothing in continual-learning_amd/ calls these on the train-step path, and a maintainer binding
- * the reference never needs them.  Used by tools/, by bench.py's calibration line and by ddp.hw_queues' one-time probe.
+ * the reference never needs them.  Used by tools/ and by bench.py's calibration line.
  */
 #ifndef CLAMD_DEBUG_H
 #define CLAMD_DEBUG_H
@@ -9,9 +9,7 @@
 extern "C" {
 #endif
 
-/* Rehearsal aid for data parallelism on a one-GPU box: `ncus` workgroups that each hold a whole CU for `usec` microseconds
- * and do nothing else -- what an RCCL channel workgroup does to the one-workgroup-per-CU MFMA kernels during a collective
- * (tools/cu_steal.py measures the step with and without clamd_tuning::cu_reserve). */
+/* Older name of clamd_hold_cus (include/clamd.h), kept for the tools of earlier rounds. */
 int clamd_debug_hold_cus(int ncus, int usec, void* stream);
 
 /* Calibration for bench.py: a bare MFMA loop (v_mfma_f32_32x32x16_bf16 for CLAMD_BF16 / CLAMD_SPLIT, v_mfma_f32_32x32x2_f32 for

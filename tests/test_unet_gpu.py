@@ -6,12 +6,15 @@ reported against the tolerance it can reach (bf16 storage of 23 stacked conv lay
 mIoU within +-0.1 of the reference.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
 import torch
 
 from conftest import rel_l2
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from oracle import np_unet as O
 from oracle import torch_cpu as TC
 
@@ -486,6 +489,29 @@ def test_loss_hands_d_logits_to_the_backward_pass(C, dtype):
     assert taken_b and (torch.equal(gb, 2.0 * ga) if dtype != 'bf16x3' else float((gb - 2.0 * ga).norm() / ga.norm()) < 1e-3)
     gc, _, _ = run(lambda out: crit(out, y) + 0.0 * out.sum())                 # two gradients summed by autograd: a new tensor -> converted
     assert float((gc - ga).norm() / ga.norm()) < (1e-6 if dtype != 'bf16' else 1e-2)
+    # (d) the package loss evaluated for logging and DROPPED, then another loss backpropagated through the same logits: its gradient tensor
+    # has the shape and dtype of the one the dropped loss wrote and would get that tensor's address back from the caching allocator if the
+    # engine did not hold it -- the stale NHWC copy (gradient w.r.t. y) must not pass for the gradient w.r.t. y2
+    y2 = torch.from_numpy(C.synth.labels(77, 2, 32, 32, 5)).to(dev)
+
+    def dropped_then_other(out):
+        logged = crit(out, y)
+        del logged
+        return F.cross_entropy(out, y2)
+
+    gd, _, _ = run(dropped_then_other)
+    g2, _, _ = run(lambda out: F.cross_entropy(out, y2))
+    assert float((gd - g2).norm() / g2.norm()) < (1e-6 if dtype != 'bf16' else 1e-2)
+    assert float((gd - ga).norm() / ga.norm()) > 1e-2                          # and y2 is a different target
+    # a misaligned view of the logits (odd storage offset) takes the scalar loss kernel instead of failing
+    torch.manual_seed(9)
+    m = C.UNet(5, 3, 8, compute_dtype=dtype).to(dev).train()
+    base = torch.zeros(2 * 5 * 32 * 32 + 1, device=dev)
+    lg = base[1:].view(2, 5, 32, 32)
+    lg.copy_(m(x).detach())
+    lg.requires_grad_(False)
+    la_odd = float(crit(lg, y))
+    assert abs(la_odd - la) < 1e-5 * abs(la)
     # a later forward invalidates the hand-over of an earlier one
     torch.manual_seed(9)
     m = C.UNet(5, 3, 8, compute_dtype=dtype).to(dev).train()
@@ -916,7 +942,9 @@ def test_checkpoint_roundtrip_and_resume(C, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype,cd,size', [('fp32', 8, 64), ('bf16x3', 8, 64), ('fp32', 64, 64)])
 def test_graphed_step_matches_eager(C, dtype, cd, size):
-    """The whole train step captured in ONE HIP graph (graph.GraphedStep) replays the same kernels as the eager loop:
+    """Every entry point of the library only enqueues on the caller's stream, so the whole train step CAN be captured in ONE HIP graph
+    (tools/graphed_step.py: a measurement tool, not part of the package -- the replay is slower than the three-stream eager step) and replays
+    the same kernels as the eager loop:
     the SAME loss sequence, bit for bit (every reduction is a fixed-order sum); the LambdaLR schedule still reaches the
     captured Adam kernel (lr is read from device memory), and the host-side step counter follows the replays."""
     dev = torch.device('cuda', 0)
@@ -940,7 +968,9 @@ def test_graphed_step_matches_eager(C, dtype, cd, size):
         if i == 3:
             s1.step()                                    # halve the learning rate after the 4th step
     m2, o2, s2, c2 = make()
-    step = C.GraphedStep(m2, o2, c2, x, y, warmup=3)     # 3 eager steps, then the capture (not executed)
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from graphed_step import GraphedStep
+    step = GraphedStep(m2, o2, c2, x, y, warmup=3)       # 3 eager steps, then the capture (not executed)
     if cd == 64:
         eng = next(iter(m2._engines.values()))
         assert any(u.pre_f for u in eng.convs) and any(u.pre_w for u in eng.convs) and any(u.apply_folded for u in eng.convs)

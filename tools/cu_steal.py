@@ -2,7 +2,7 @@
 
     python tools/cu_steal.py [dtype=bf16] [held_cus=8] [steps=6]
 
-A dummy kernel (clamd_debug_hold_cus: one workgroup per CU, 96 KB of LDS each, spinning on the wall clock) keeps K CUs
+A dummy kernel (clamd_hold_cus: one workgroup per CU, 96 KB of LDS each, spinning on the wall clock) keeps K CUs
 busy on a side stream for the whole measurement -- the way RCCL's channel workgroups do during an all-reduce.  The step is
 timed (HIP events on the compute stream)
   base      nothing held, default tuning
@@ -49,7 +49,7 @@ def measure(dtype='bf16', held=8, steps=6, size=256, batch=16, conv_dim=64, nc=2
         est_ms = {'fp32': 30, 'bf16x3': 20, 'bf16': 9}[dtype] * (size / 256) ** 2 * batch / 16 * (conv_dim / 64) ** 2
         if hold:
             with torch.cuda.stream(side):
-                C._lib.call('clamd_debug_hold_cus', hold, int(1000 * (3 * est_ms * steps + 50)), side.cuda_stream)
+                C._lib.call('clamd_hold_cus', hold, int(1000 * (3 * est_ms * steps + 50)), side.cuda_stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(steps):

@@ -32,7 +32,8 @@ def eager():
 ref = [float(eager().detach()) for _ in range(6)]
 
 m2, o2, c2 = make()
-step = C.GraphedStep(m2, o2, c2, x, y, warmup=3)
+from graphed_step import GraphedStep  # noqa: E402 (tools/ is sys.path[0])
+step = GraphedStep(m2, o2, c2, x, y, warmup=3)
 got = [float(l) for l in (step.eager_losses + [step().clone() for _ in range(3)])]
 print('eager ', ref)
 print('graph ', got)

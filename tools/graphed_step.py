@@ -1,4 +1,8 @@
-"""One HIP graph for the whole train step (trainer.py:172-176: forward, zero_grad, loss, backward, Adam).
+"""One HIP graph for the whole train step (trainer.py:172-176: forward, zero_grad, loss, backward, Adam) -- a MEASUREMENT tool since round 5,
+no longer part of the package: the eager loop is GPU-bound (the host enqueues a step in 2.7-3.3 ms, tools/host_rate.py), and the replay is
+SLOWER than the eager step (bf16 6.69 vs 6.42 ms, fp32 21.46 vs 20.88 ms) because the shipped three-stream schedule cannot be captured
+(hipStreamEndCapture crashes on it: tools/ubench/capture_three_streams.hip).  What stays a tested property of the library is that every entry
+point only enqueues on the caller's stream, i.e. that the step CAN be captured (tests/test_unet_gpu.py::test_graphed_step_matches_eager).
 
 Every libclamd entry point only enqueues kernels on the caller's stream (no allocation, no host synchronisation), the
 engine's buffers are allocated once per input shape, and FusedAdam keeps its step counter, learning rate and bias

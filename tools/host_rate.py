@@ -1,6 +1,6 @@
 """Host side of the eager train step: how long Python + ctypes + the HIP runtime need to ENQUEUE one step (the GPU idle at the start of
 each step, so nothing blocks on a full queue) against the time the GPU needs to run it.   python tools/host_rate.py [dtype] [steps]
-A step whose enqueue time approaches its GPU time is launch-bound in the eager loop (bench.py's); graph.GraphedStep replays it from a hipGraph."""
+A step whose enqueue time approaches its GPU time is launch-bound in the eager loop (bench.py's); tools/graphed_step.py replays it from a hipGraph."""
 import os
 import sys
 import time
