@@ -516,11 +516,13 @@ static long long w24_tiles(int B, int H, int W) {
 
 // rows of a launch: one per pixel tile (one workgroup per tile), or one per workgroup of the persistent grid
 long long clamd_winograd24_stat_rows(int B, int H, int W, int Cout_p, const clamd_tuning& tn) {
+    if (tn.wino_half) return clamd_winograd24_half_stat_rows(B, H, W, Cout_p, tn);
     const long long tiles = w24_tiles(B, H, W), nblk = tiles * ((Cout_p + 63) / 64);
     return (tn.wino_persist && nblk > clamd_usable_cus(tn)) ? clamd_usable_cus(tn) : tiles;
 }
 
 int launch_wino24(WinoParams p, const clamd_tuning& tn, int stat_rows, hipStream_t stream) {
+    if (tn.wino_half) return launch_wino24_half(p, tn, stat_rows, stream);
     int ph, pw;
     w24_tile(p.W, ph, pw);
     const long long ntn = (p.Np + 63) / 64, tiles = w24_tiles(p.B, p.H, p.W);

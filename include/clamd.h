@@ -57,14 +57,16 @@ int clamd_bn_bwd_nsums(void);
  *   wino_persist   0|1     one workgroup per tile | persistent tile loop
  *   wino_mt        0|1|2   tile height: per-launch choice | 8 | 16 pixels
  *   bn_reduce_blocks / chsum_blocks   0 (per-launch choice) | n: grid cap of the per-channel reductions
- *   cu_reserve     CUs the persistent grids leave free (for RCCL channel workgroups under data parallelism) */
+ *   cu_reserve     CUs the persistent grids leave free (for RCCL channel workgroups under data parallelism)
+ *   wino_half      0|1     clamd_conv3x3_winograd24: 32 tiles x 64 channels, one workgroup per CU | 32 x 32, two per CU (wino24n.hip) */
 typedef struct clamd_tuning {
     int igemm_pws, igemm_ws, igemm_variant, pws_wres;
     int wgrad_ws, wgrad_dma, wgrad_xcd, wgrad_blocks, wgrad_tw16;
     int wino_band, wino_persist, wino_mt;
     int bn_reduce_blocks, chsum_blocks;
     int cu_reserve;
-    int reserved[9];
+    int wino_half;
+    int reserved[8];
 } clamd_tuning;
 int clamd_sizeof_tuning(void);
 void clamd_tuning_init(clamd_tuning* t);

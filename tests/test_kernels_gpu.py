@@ -509,6 +509,7 @@ W24_SHAPES = [  # B, Cin segs, Cout, H, W (H even, W % 4 == 0)
     (1, [(128, 128)], 96, 34, 20),            # ragged in both directions, narrow tile
     (3, [(32, 32)], 64, 64, 96),              # 72 workgroups
     (2, [(256, 256)], 64, 24, 72),            # long K, ragged columns with the wide tile
+    (5, [(32, 32)], 448, 40, 64),             # 50 tiles x 7 slabs: the persistent loops (350 > 256 workgroups; half-width: 700 > 512)
 ]
 
 
@@ -585,8 +586,11 @@ def test_conv3x3_winograd24_fp32(C, shape):
         sync()
         assert torch.equal(gw, gw2)
         assert rel_l2(gw.cpu().numpy(), rgw) < 2e-5
-    for key, val in (('wino_band', 1), ('wino_band', 32), ('wino_persist', 0), ('cu_reserve', 37), ('wino_persist', 1)):
-        tn = lib.Tuning(**{key: val})
+    # ('wino_half', 1): the half-width workgroups of wino24n.hip (32 tiles x 32 channels, two per CU) -- same filters, formulas and MFMA
+    # chains: bit-identical activations; rows per workgroup of ITS grid
+    for key, val in (('wino_band', 1), ('wino_band', 32), ('wino_persist', 0), ('cu_reserve', 37), ('wino_persist', 1), ('wino_half', 1),
+                     ('wino_half', 2)):
+        tn = lib.Tuning(**({key: val} if (key, val) != ('wino_half', 2) else {'wino_half': 1, 'wino_persist': 0}))
         y2 = torch.full((B, H, W, cout_p), 7.0, device='cuda')
         stats2, rows2 = stat_buf(C, lib.OP_CONV3X3_WINOGRAD24, B, H, W, cin_p, cout_p, 0, tuning=tn)
         lib.call('clamd_conv3x3_winograd24', ptr(xt), cin_p, ptr(wf), ptr(bp), ptr(y2), cout_p, ptr(stats2), rows2, B, H, W, cin_p, cout_p, 1,
@@ -597,7 +601,7 @@ def test_conv3x3_winograd24_fp32(C, shape):
         sync()
         assert torch.equal(y, y2), (key, val)
         assert torch.equal(stats2, stats3), f'{key}={val}: statistics rows differ between two identical launches'
-        if rows2 == rows:
+        if rows2 == rows and key != 'wino_half':
             assert torch.equal(stats, stats2), (key, val)
         else:       # other grid: other rows (per workgroup / per tile), same totals
             np.testing.assert_allclose(stats2.double().sum(0).cpu().numpy(), stats.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
@@ -611,7 +615,7 @@ FOLD_SHAPES = [  # B, Cin, Cout, H, W
 ]
 
 
-@pytest.mark.parametrize('kernel,dcode', [('w24', 0), ('w24h', 0), ('pws', 0), ('pws', 1), ('pws', 2)])
+@pytest.mark.parametrize('kernel,dcode', [('w24', 0), ('w24n', 0), ('w24h', 0), ('pws', 0), ('pws', 1), ('pws', 2)])
 @pytest.mark.parametrize('shape', FOLD_SHAPES, ids=lambda sh: 'x'.join(str(a) for a in sh))
 def test_batchnorm_folded_into_conv3x3(C, kernel, dcode, shape):
     """nn.BatchNorm2d folded algebraically into the nn.Conv2d behind it (bnfold.hip; models/unet.py:15-16): filters packed with the
@@ -669,10 +673,11 @@ def test_batchnorm_folded_into_conv3x3(C, kernel, dcode, shape):
     else:
         wf = torch.zeros(24 * cout_p * cin_p, device='cuda')
         tab = C.ops.WinoPackTable(24); tab.conv3x3(wt, wf, None, [(cin, cin_p)], cout, kscale=sc); tab.finalize('cuda').run()
-        stats, rows = stat_buf(C, lib.OP_CONV3X3_WINOGRAD24, B, H, W, cin_p, cout_p, 0)
-        if kernel == 'w24':
+        tnw = lib.Tuning(wino_half=1) if kernel == 'w24n' else None      # w24n: the half-width workgroups (wino24n.hip)
+        stats, rows = stat_buf(C, lib.OP_CONV3X3_WINOGRAD24, B, H, W, cin_p, cout_p, 0, tuning=tnw if kernel == 'w24n' else None)
+        if kernel in ('w24', 'w24n'):
             lib.call('clamd_conv3x3_winograd24', ptr(rt), cin_p, ptr(wf), ptr(table), ptr(y), cout_p, ptr(stats), rows, B, H, W, cin_p, cout_p,
-                     flags, None, s)
+                     flags, tnw.ref() if tnw else None, s)
         else:
             lib.call('clamd_conv3x3_winograd24_direct_filters', ptr(rt), cin_p, ptr(wf), ptr(table), ptr(y), cout_p, ptr(stats), rows,
                      B, H, W, cin_p, cout_p, flags, None, s)
