@@ -15,7 +15,7 @@ F32, BF16, SPLIT = 0, 1, 2      # SPLIT = 'bf16x3': fp32 storage, 3-term split-b
 WGRAD_CONV3, WGRAD_PW, WGRAD_UP2 = 0, 1, 2
 
 _P, _I, _D, _LL, _SZ = c_void_p, c_int, c_double, c_longlong, c_size_t
-OP_CONV3X3, OP_CONV3X3_WINOGRAD, OP_CONV1X1, OP_CONVT2X2_DGRAD, OP_BN_BWD_REDUCE, OP_CONV3X3_WINOGRAD24 = range(6)
+OP_CONV3X3, OP_CONV3X3_WINOGRAD, OP_CONV1X1, OP_CONVT2X2_DGRAD, OP_BN_BWD_REDUCE, OP_CONV3X3_WINOGRAD24, OP_CONV3X3_WINOGRAD44 = range(7)
 
 
 class Tuning(ctypes.Structure):
@@ -105,6 +105,14 @@ SIGNATURES = {
     'clamd_wgrad_winograd24_pre_transform': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     'clamd_wgrad_winograd24_pre_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I]),
     'clamd_wgrad_winograd24_pre': (_I, [_P, _I, _P, _P, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'clamd_wino44_pack': (_I, [_P, _I, _I, _P]),
+    'clamd_winograd44_input_elems': (_SZ, [_I, _I, _I, _I]),
+    'clamd_winograd44_transform_input': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'clamd_conv3x3_winograd44_pre': (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'clamd_wgrad_winograd44_pre_operand_elems': (_SZ, [_I, _I, _I, _I]),
+    'clamd_wgrad_winograd44_pre_transform': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
+    'clamd_wgrad_winograd44_pre_workspace_bytes': (_SZ, [_I, _I, _I, _I, _I]),
+    'clamd_wgrad_winograd44_pre': (_I, [_P, _I, _P, _P, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     'clamd_ce_workspace_bytes': (_SZ, []),
     'clamd_ce_bad_label_count_offset': (_SZ, []),
     'clamd_ce_fwd_bwd': (_I, [_P, _P, _P, _I, _I, _D, _D, _P, _P, _P, _SZ, _I, _I, _I, _I, _LL, _D, _P]),

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libclamd.so')
-SOURCES = ['igemm.hip', 'igemm_ws.hip', 'igemm_pws.hip', 'wgrad.hip', 'wgrad_dma.hip', 'wino.hip', 'wino24.hip', 'wino24n.hip', 'wino24_wgrad.hip', 'wino24g.hip', 'bnfold.hip', 'elementwise.hip', 'misc.hip']
+SOURCES = ['igemm.hip', 'igemm_ws.hip', 'igemm_pws.hip', 'wgrad.hip', 'wgrad_dma.hip', 'wino.hip', 'wino24.hip', 'wino24n.hip', 'wino24_wgrad.hip', 'wino24g.hip', 'wino44g.hip', 'bnfold.hip', 'elementwise.hip', 'misc.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-I' + os.path.join(HERE, '..', 'include')]
 

@@ -530,6 +530,7 @@ int clamd_stat_rows(int op, int B, int H, int W, int Cin_p, int Cout_p, int dtyp
     case CLAMD_OP_CONV3X3: rows = plan_conv3x3(p, dtype, tn).rows; break;
     case CLAMD_OP_CONV3X3_WINOGRAD: rows = clamd_winograd_stat_rows(B, H, W, Cout_p, tn); break;
     case CLAMD_OP_CONV3X3_WINOGRAD24: rows = clamd_winograd24_stat_rows(B, H, W, Cout_p, tn); break;
+    case CLAMD_OP_CONV3X3_WINOGRAD44: rows = clamd_winograd44_stat_rows(B, H, W, Cout_p, tn); break;
     case CLAMD_OP_CONV1X1:
     case CLAMD_OP_CONVT2X2_DGRAD: rows = igemm_tiles(p); break;
     case CLAMD_OP_BN_BWD_REDUCE: rows = clamd_bn_bwd_reduce_rows(B, H, W, Cout_p, Cin_p != 0, tn); break;

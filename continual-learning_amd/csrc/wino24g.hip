@@ -734,8 +734,9 @@ __global__ void __launch_bounds__(256) wino24g_wgrad_xform_kernel(const W24WgXfo
 struct W24WgGemmParams {
     const float* yt;                      // [24][Tp][Rp]
     const float* v;                       // forward image of the convolution input: [Tp/32][Cp/8][24][2][32][4]
-    float* partial;                       // [nsplit][24][Rp][Cp]
+    float* partial;                       // [nsplit][npl][Rp][Cp]
     int Rp, Cp, Tp, nsplit, tiles_per_split;
+    int npl;                              // planes: 24 (F(2x4)) or 36 (F(4x4), wino44g.hip: the same GEMM on its operands)
 };
 
 constexpr int W24G_D = 8;                 // k-steps (of two tiles) the load stream runs ahead
@@ -765,13 +766,13 @@ __global__ void __launch_bounds__(256, 1) wino24g_wgrad_kernel(const W24WgGemmPa
     const int nk = p.Cp >> 3;
     const unsigned a_bytes = (unsigned)p.Tp * (unsigned)p.Rp * 4u;
     const __amdgpu_buffer_rsrc_t ars = make_rsrc((const char*)p.yt + (size_t)pl * a_bytes, a_bytes);
-    const __amdgpu_buffer_rsrc_t brs = make_rsrc(p.v, (unsigned)((size_t)(p.Tp >> 5) * nk * 24 * 1024));
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc(p.v, (unsigned)((size_t)(p.Tp >> 5) * nk * p.npl * 1024));
     const __amdgpu_buffer_rsrc_t ars_dead = make_rsrc(p.yt, 0u), brs_dead = make_rsrc(p.v, 0u);
     const unsigned a_vo = (unsigned)((h * p.Rp + r0 + 4 * i32) * 4);
-    const unsigned b_vo = (unsigned)(((c0 >> 3) + (i32 >> 1)) * 24 * 1024 + (i32 & 1) * 512 + h * 16);
+    const unsigned b_vo = (unsigned)(((c0 >> 3) + (i32 >> 1)) * p.npl * 1024 + (i32 & 1) * 512 + h * 16);
     const unsigned a_step = (unsigned)p.Rp * 8u;                              // two tiles
     const unsigned a_so0 = (unsigned)t_begin * (unsigned)p.Rp * 4u;
-    const unsigned b_blk = (unsigned)nk * 24u * 1024u, b_pl = (unsigned)pl * 1024u;
+    const unsigned b_blk = (unsigned)nk * (unsigned)p.npl * 1024u, b_pl = (unsigned)pl * 1024u;
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -811,7 +812,7 @@ __global__ void __launch_bounds__(256, 1) wino24g_wgrad_kernel(const W24WgGemmPa
     }
 
     // slab [split][plane][Rp][Cp]: MFMA (m, n) holds rows r0 + 4 i + m, columns c0 + 4 j + n; lane j stores its four n
-    float* const out = p.partial + (((size_t)split * 24 + pl) * p.Rp) * (size_t)p.Cp;
+    float* const out = p.partial + (((size_t)split * p.npl + pl) * p.Rp) * (size_t)p.Cp;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -916,9 +917,14 @@ using namespace clamd;
 // workgroup; measured, tools/wino24g_ab.py), the chip runs ceil(workgroups / CUs) rounds of them, and the reduce pass reads
 // every slab once: pick the split count with the smallest modelled time.  Tiles per split: a multiple of 2 W24G_D (whole
 // passes of the prefetch ring).
-static int w24g_wg_plan(long long Tp, int Rp, int Cp, const clamd_tuning& tn, int* per_out) {
+namespace clamd {
+long long w24g_wg_max_split(long long Tp, int Rp, int Cp, int planes) {
+    const long long nb = (long long)planes * (Rp / 256) * (Cp / 256);
+    return std::max<long long>(1, std::min<long long>((3LL * clamd_num_cus()) / nb, Tp / (2 * W24G_D)));
+}
+int w24g_wg_plan_planes(long long Tp, int Rp, int Cp, int planes, const clamd_tuning& tn, int* per_out) {
     const int quant = 2 * W24G_D;
-    const int nb = 24 * (Rp / 256) * (Cp / 256);
+    const int nb = planes * (Rp / 256) * (Cp / 256);
     const int cus = clamd_usable_cus(tn);
     const long long max_split = std::max<long long>(1, std::min<long long>((3LL * clamd_num_cus()) / nb, Tp / quant));
     double best = 0;
@@ -936,6 +942,13 @@ static int w24g_wg_plan(long long Tp, int Rp, int Cp, const clamd_tuning& tn, in
     if (per_out) *per_out = (int)best_per;
     return (int)best_ns;
 }
+int launch_w24g_wgrad_gemm(const float* yt, const float* v, float* partial, int Rp, int Cp, long long Tp, int nsplit, int per, int planes, hipStream_t s) {
+    W24WgGemmParams p{yt, v, partial, Rp, Cp, (int)Tp, nsplit, per, planes};
+    hipLaunchKernelGGL(wino24g_wgrad_kernel, dim3((unsigned)(planes * nsplit * (Rp / 256) * (Cp / 256))), dim3(256), 0, s, p);
+    return clamd_check_launch("wgrad_winograd_pre (plane GEMM)");
+}
+}  // namespace clamd
+static int w24g_wg_plan(long long Tp, int Rp, int Cp, const clamd_tuning& tn, int* per_out) { return clamd::w24g_wg_plan_planes(Tp, Rp, Cp, 24, tn, per_out); }
 
 extern "C" {
 
@@ -1064,9 +1077,7 @@ int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, floa
         else hipLaunchKernelGGL(wino24g_wgrad_xform_kernel<4>, dim3(g), dim3(256), 0, s, pa);
         if (int e = clamd_check_launch("wgrad_winograd24_pre transform")) return e;
     }
-    W24WgGemmParams p{yt, v, workspace, Rp, Cp, (int)Tp, nsplit, per};
-    hipLaunchKernelGGL(wino24g_wgrad_kernel, dim3((unsigned)(24 * nsplit * (Rp / 256) * (Cp / 256))), dim3(256), 0, s, p);
-    if (int e = clamd_check_launch("wgrad_winograd24_pre")) return e;
+    if (int e = launch_w24g_wgrad_gemm(yt, v, workspace, Rp, Cp, Tp, nsplit, per, 24, s)) return e;
     W24GReduceParams rp{workspace, out, nsplit, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p};
     const long long nquad = (long long)Rp * Cp / 4;
 #define W24G_REDUCE(PHS_)                                                                                              \

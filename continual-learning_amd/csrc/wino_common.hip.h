@@ -42,6 +42,8 @@ int wino_band(long long tiles, long long slabs, double x_elems, double f_elems, 
 // wino24.hip
 long long clamd_winograd24_stat_rows(int B, int H, int W, int Cout_p, const clamd_tuning& tn);
 int launch_wino24(WinoParams p, const clamd_tuning& tn, int stat_rows, hipStream_t stream);
+// wino44g.hip
+long long clamd_winograd44_stat_rows(int B, int H, int W, int Cout_p, const clamd_tuning& tn);
 // wino24n.hip: the same launch as half-width workgroups (32 tiles x 32 channels, two per CU; clamd_tuning::wino_half)
 long long clamd_winograd24_half_stat_rows(int B, int H, int W, int Cout_p, const clamd_tuning& tn);
 int launch_wino24_half(WinoParams p, const clamd_tuning& tn, int stat_rows, hipStream_t stream);

@@ -103,10 +103,10 @@ _WINO_DT = np.dtype({'names': ['w', 'dst', 'Np', 'Kp', 'N', 'K', 'n_seg0', 'n_se
 
 class WinoPackTable:
     """Job table for clamd_wino_pack / clamd_wino24_pack: Winograd filter transforms of every 3x3 conv of one form in one
-    launch (fp32 path).  ``planes`` = 16: F(2x2,3x3) (wino.hip); 24: F(2x4,3x3) (wino24.hip)."""
+    launch (fp32 path).  ``planes`` = 16: F(2x2,3x3) (wino.hip); 24: F(2x4,3x3) (wino24.hip); 36: F(4x4,3x3) (wino44g.hip; no kscale)."""
 
     def __init__(self, planes=16):
-        assert planes in (16, 24)
+        assert planes in (16, 24, 36)
         self.jobs = []
         self.planes = planes
 
@@ -137,7 +137,7 @@ class WinoPackTable:
         return self
 
     def run(self, stream=None):
-        call('clamd_wino_pack' if self.planes == 16 else 'clamd_wino24_pack', ptr(self.dev_table), len(self.jobs), self.nblocks,
+        call({16: 'clamd_wino_pack', 24: 'clamd_wino24_pack', 36: 'clamd_wino44_pack'}[self.planes], ptr(self.dev_table), len(self.jobs), self.nblocks,
              stream or _lib.stream_ptr())
 
 

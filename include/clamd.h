@@ -78,7 +78,7 @@ void clamd_tuning_init(clamd_tuning* t);
  * Two runs on the same inputs are bit-identical.  The caller sizes the buffer with clamd_stat_rows() for the SAME
  * arguments it launches with and passes that row count to the launch (checked) and to the finalize call. */
 enum { CLAMD_OP_CONV3X3 = 0, CLAMD_OP_CONV3X3_WINOGRAD = 1, CLAMD_OP_CONV1X1 = 2, CLAMD_OP_CONVT2X2_DGRAD = 3,
-       CLAMD_OP_BN_BWD_REDUCE = 4, CLAMD_OP_CONV3X3_WINOGRAD24 = 5 };
+       CLAMD_OP_BN_BWD_REDUCE = 4, CLAMD_OP_CONV3X3_WINOGRAD24 = 5, CLAMD_OP_CONV3X3_WINOGRAD44 = 6 };
 /* rows a launch of `op` writes: (B,H,W) = pixel grid of the launch, Cin_p/Cout_p as passed to it (BN_BWD_REDUCE: Cout_p = Cp,
  * Cin_p != 0 means the pooled variant), fused_bn != 0 when bn_y/bn_sums are passed.  Negative on error. */
 int clamd_stat_rows(int op, int B, int H, int W, int Cin_p, int Cout_p, int dtype, int fused_bn, const clamd_tuning* tune);
@@ -191,6 +191,32 @@ size_t clamd_wgrad_winograd24_pre_operand_elems(int B, int H, int W, int Rp);
 int clamd_wgrad_winograd24_pre_transform(const float* gz, int gz_ldc, float* yt, int B, int H, int W, int Rp, void* stream);
 size_t clamd_wgrad_winograd24_pre_workspace_bytes(int B, int H, int W, int Rp, int Cp);
 int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, float* yt, float* workspace, size_t ws_bytes, float* out,
+                               int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p,
+                               const clamd_tuning* tune, void* stream);
+/* ---- F(4x4,3x3) with PRE-TRANSFORMED operands (wino44g.hip): the wide 3x3 convolutions at 32x32 and 64x64 of models/unet.py:28-33,
+ * 50-55 (enc3, enc4, dec2, dec3) and their gradients (trainer.py:175).  36 multiply-adds per 4 x 4 outputs = 2.25 per output against 3
+ * (F(2x4)) and 9 (direct); fp32 error vs fp64 2-3.5e-6 relative.  H and W multiples of 4.  The same call structure as the F(2x4) family
+ * above, argument for argument:
+ *   clamd_wino44_pack                   filters G6 g G6^T as [Cin_p/8][36][Cout_p][8] (same job table as clamd_wino_pack)
+ *   clamd_winograd44_transform_input    x [B,H,W,ldc] (optionally x * scale + shift, zero padding after the affine) -> v,
+ *                                       clamd_winograd44_input_elems() floats = 2.25x the activation
+ *   clamd_conv3x3_winograd44_pre        transform-free K loop (per wave 24 MFMAs + 12 buffer loads into the operand registers per
+ *                                       8-channel chunk; 12 waves per workgroup: six Winograd rows x two 32-channel halves), bias, ReLU,
+ *                                       statistics rows (stat_rows = clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD44, ...)); Cout_p % 64 == 0
+ *   clamd_wgrad_winograd44_pre[_transform|_operand_elems|_workspace_bytes]   weight gradient as the batched plane GEMM of
+ *                                       clamd_wgrad_winograd24_pre over 36 planes: v = the kept forward image, yt = A6 dY A6^T scratch,
+ *                                       fixed-order reduce with G6^T . G6 (deterministic); Rp, Cp multiples of 256 */
+int clamd_wino44_pack(const void* jobs_dev, int njobs, int total_blocks, void* stream);
+size_t clamd_winograd44_input_elems(int B, int H, int W, int Cp);
+int clamd_winograd44_transform_input(const float* x, int x_ldc, const float* scale, const float* shift, float* v, int B, int H, int W,
+                                     int Cp, void* stream);
+int clamd_conv3x3_winograd44_pre(const float* v, const float* w_wino, const float* bias, float* y, int y_ldc,
+                                 float* stats, int stat_rows, int B, int H, int W, int Cin_p,
+                                 int Cout_p, int relu, const clamd_tuning* tune, void* stream);
+size_t clamd_wgrad_winograd44_pre_operand_elems(int B, int H, int W, int Rp);
+int clamd_wgrad_winograd44_pre_transform(const float* gz, int gz_ldc, float* yt, int B, int H, int W, int Rp, void* stream);
+size_t clamd_wgrad_winograd44_pre_workspace_bytes(int B, int H, int W, int Rp, int Cp);
+int clamd_wgrad_winograd44_pre(const float* gz, int gz_ldc, const float* v, float* yt, float* workspace, size_t ws_bytes, float* out,
                                int B, int H, int W, int Rp, int Cp, int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p,
                                const clamd_tuning* tune, void* stream);
 /* Weight gradient of the same convolution by Winograd (fp32, H and W even): out [R][C][3][3] = G^T (sum over tiles of
