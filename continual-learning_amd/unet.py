@@ -43,6 +43,12 @@ WINOGRAD24_WGRAD = 'auto'
 # 'auto' = where the transform pass pays for itself (see _Engine.unit); False = never.
 PRETRANSFORM = os.environ.get('CLAMD_PRETRANSFORM', 'auto')
 PRETRANSFORM = {'0': False, 'false': False, '1': True, 'true': True}.get(str(PRETRANSFORM).lower(), 'auto')
+# ... and those pre-transformed layers by the 2-D F(4x4,3x3) (csrc/wino44g.hip: 2.25 instead of 3 multiply-adds per output, a transformed
+# input of 2.25x instead of 3x the activation; error vs fp64 2-3.5e-6) where a launch has a chip's worth of its 512-pixel x 64-channel work
+# items: the 32x32 and 64x64 levels at config 2 (tools/wino44g_ab.py: transform + forward 1.23-1.30x, weight gradient 1.0-1.26x faster
+# there; 0.67-0.70x at 16x16, where 128 work items leave half the chip idle).  'auto' = that rule; True = wherever it applies; False = never.
+WINOGRAD44 = os.environ.get('CLAMD_WINOGRAD44', 'auto')
+WINOGRAD44 = {'0': False, 'false': False, '1': True, 'true': True}.get(str(WINOGRAD44).lower(), 'auto')
 # ... and the BatchNorm in front of such a convolution is applied by the transform kernel on load where nothing else reads the
 # BatchNorm output (the first unit of enc3/enc4/dec1/dec2/dec3): one HBM pass less per unit.  False = always run clamd_bn_apply.
 FOLD_BN_INTO_TRANSFORM = os.environ.get('CLAMD_FOLD_BN', '1') != '0'
@@ -429,13 +435,24 @@ class _Engine:
             u.pre_w = u.pre_w and u.pre_f and lib.clamd_wgrad_winograd24_pre_operand_elems(B, u.h, u.w_, u.cout_p) * 4 // 24 < (1 << 32)
             u.pre_d = bool(pt) and u.w24d and not first_of_net and u.cout_p >= 64 and u.cin_p % 64 == 0 and fits(u.cout_p) and (
                 pt is True or (u.cout_p >= 256 and (2 * u.cin_p > u.cout_p or (2 * u.cin_p == u.cout_p and u.cin_p >= 256))))
-            u.vx = torch.empty(lib.clamd_winograd24_input_elems(B, u.h, u.w_, u.cin_p), dtype=torch.float32, device=dev) if u.pre_f else None
+            # ... by F(4x4,3x3) where the launch fills the chip with (16x32-pixel tile block, 64-channel slab) work items (WINOGRAD44)
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == 'cuda' else 256
+            blocks44 = B * u.h * u.w_ // 512                       # FULL tile blocks (a 16x16 image fills half of a 32x16 block)
+            ok44 = lambda slab_ch, in_ch: (bool(WINOGRAD44) and u.h % 4 == 0 and u.w_ % 4 == 0 and slab_ch % 64 == 0
+                                           and (WINOGRAD44 is True or blocks44 * (slab_ch // 64) >= ncu)
+                                           and lib.clamd_winograd44_input_elems(B, u.h, u.w_, in_ch) * 4 < (1 << 32))
+            u.f44 = u.pre_f and ok44(u.cout_p, u.cin_p)            # forward (and, with pre_w, the weight gradient: it reads the forward image)
+            u.d44 = u.pre_d and ok44(u.cin_p, u.cout_p)            # data gradient
+            if u.f44 and u.pre_w:
+                u.pre_w = lib.clamd_wgrad_winograd44_pre_operand_elems(B, u.h, u.w_, u.cout_p) * 4 // 36 < (1 << 32)
+            u.vx = torch.empty((lib.clamd_winograd44_input_elems if u.f44 else lib.clamd_winograd24_input_elems)(B, u.h, u.w_, u.cin_p),
+                               dtype=torch.float32, device=dev) if u.pre_f else None
             # 64 input channels (8 chunks per tile): the in-kernel-transform kernel with the filters loaded straight into the operand
             # registers (wino24h_kernel) is 4-6 % faster there and 1-4 % slower on longer K loops (tools/wino24h_ab.py)
             u.direct_f = NARROW_DIRECT and u.w24 and not u.pre_f and u.cin_p == 64 and u.cout_p % 64 == 0
             u.direct_d = NARROW_DIRECT and u.w24d and not u.pre_d and not first_of_net and u.cout_p == 64 and u.cin_p % 64 == 0
-            ntap = 1 if u.im2col else ((24 if u.w24 else 16) if u.wino else 9)   # Winograd: [Cin_p/8][16|24][Cout_p][8] transformed filters
-            ntap_d = (24 if u.w24d else 16) if u.wino else ntap
+            ntap = 1 if u.im2col else ((36 if u.f44 else (24 if u.w24 else 16)) if u.wino else 9)   # Winograd: [Cin_p/8][16|24|36][Cout_p][8] transformed filters
+            ntap_d = (36 if u.d44 else (24 if u.w24d else 16)) if u.wino else ntap
             u.wf = torch.zeros(ntap * u.cout_p * u.cin_p, dtype=T, device=dev)
             u.wd = None if first_of_net else torch.zeros(ntap_d * u.cin_p * u.cout_p, dtype=T, device=dev)
             u.bias_p = torch.zeros(u.cout_p, dtype=torch.float32, device=dev)
@@ -581,7 +598,8 @@ class _Engine:
             if u.w24g:
                 ws = max(ws, lib.clamd_wgrad_winograd24_workspace_bytes(u.cout_p, u.cin_p))
             if u.pre_w:
-                ws = max(ws, lib.clamd_wgrad_winograd24_pre_workspace_bytes(B, u.h, u.w_, u.cout_p, u.cin_p))
+                ws = max(ws, (lib.clamd_wgrad_winograd44_pre_workspace_bytes if u.f44 else lib.clamd_wgrad_winograd24_pre_workspace_bytes)(
+                    B, u.h, u.w_, u.cout_p, u.cin_p))
         for s in self.stages:
             t = s.get('tail')
             if t is not None:
@@ -591,8 +609,9 @@ class _Engine:
         self.ws = torch.empty(ws // 4 + 16, dtype=torch.float32, device=dev)
         # scratch of the pre-transformed kernels: the transformed gradient of the data-gradient launch (main stream) and the
         # gradient-side operand of the weight-gradient GEMM (second stream); launches on one stream are serialised, so one each
-        nvg = max([lib.clamd_winograd24_input_elems(B, u.h, u.w_, u.cout_p) for u in convs if u.pre_d] + [0])
-        nyt = max([lib.clamd_wgrad_winograd24_pre_operand_elems(B, u.h, u.w_, u.cout_p) for u in convs if u.pre_w] + [0])
+        nvg = max([(lib.clamd_winograd44_input_elems if u.d44 else lib.clamd_winograd24_input_elems)(B, u.h, u.w_, u.cout_p) for u in convs if u.pre_d] + [0])
+        nyt = max([(lib.clamd_wgrad_winograd44_pre_operand_elems if u.f44 else lib.clamd_wgrad_winograd24_pre_operand_elems)(B, u.h, u.w_, u.cout_p)
+                   for u in convs if u.pre_w] + [0])
         self.vg = torch.empty(nvg, dtype=torch.float32, device=dev) if nvg else None
         self.yt = torch.empty(nyt, dtype=torch.float32, device=dev) if nyt else None
         # third stream + a second operand buffer: the transform of unit u runs while the GEMM of unit u+1 still reads the other buffer
@@ -630,7 +649,8 @@ class _Engine:
             if u.im2col:
                 r = rows(_lib.OP_CONV1X1, B, u.h, u.w_, u.cin_p, u.cout_p, dc)
             elif u.wino:
-                r = rows(_lib.OP_CONV3X3_WINOGRAD24 if u.w24 else _lib.OP_CONV3X3_WINOGRAD, B, u.h, u.w_, u.cin_p, u.cout_p, dc, tuning=tn)
+                r = rows(_lib.OP_CONV3X3_WINOGRAD44 if u.f44 else (_lib.OP_CONV3X3_WINOGRAD24 if u.w24 else _lib.OP_CONV3X3_WINOGRAD),
+                         B, u.h, u.w_, u.cin_p, u.cout_p, dc, tuning=tn)
             else:
                 r = rows(_lib.OP_CONV3X3, B, u.h, u.w_, u.cin_p, u.cout_p, dc, tuning=tn)
             u.stat_rows_launch = r
@@ -669,16 +689,16 @@ class _Engine:
         # Winograd filter transforms in two launches per form: "early" = the first three encoder stages (4 % of the parameters,
         # needed 0.3 ms into the forward pass), "late" = everything else (first needed by enc4, 2 ms in): the forward pass waits for
         # a few microseconds of packing instead of for all of it (see forward())
-        wtab = {(pl, late): WinoPackTable(pl) for pl in (16, 24) for late in (False, True)}
+        wtab = {(pl, late): WinoPackTable(pl) for pl in (16, 24, 36) for late in (False, True)}
         for i, u in enumerate(self.convs):
             u.pack_late = i >= 6                                 # units 0-5 = enc1, enc2, enc3
             if u.im2col:
                 tab.head(u.w, u.wf, None, 9 * u.cin, u.cout)     # [Cout][Cin*9] is already the (c*9 + tap) K order
             elif u.wino:
                 if u.fold_a is None:
-                    wtab[(24 if u.w24 else 16, u.pack_late)].conv3x3(u.w, u.wf, None, u.cin_segs, u.cout)
+                    wtab[(36 if u.f44 else (24 if u.w24 else 16), u.pack_late)].conv3x3(u.w, u.wf, None, u.cin_segs, u.cout)
                 if u.wd is not None:
-                    wtab[(24 if u.w24d else 16, u.pack_late)].conv3x3(u.w, None, u.wd, u.cin_segs, u.cout)
+                    wtab[(36 if u.d44 else (24 if u.w24d else 16), u.pack_late)].conv3x3(u.w, None, u.wd, u.cin_segs, u.cout)
             else:
                 (late if u.pack_late else tab).conv3x3(u.w, None if u.fold_a is not None else u.wf, u.wd, u.cin_segs, u.cout)
             tab.vector(u.b, u.bias_p, u.cout)
@@ -808,6 +828,8 @@ class _Engine:
         """Multiply-adds the kernel executes per algorithmic (direct-convolution) multiply-add of unit u."""
         if not u.wino:
             return 1.0
+        if {'wgrad': u.pre_w and u.f44, 'dgrad': u.d44}.get(direction, u.f44):
+            return 36.0 / 144.0                                   # F(4x4,3x3): 36 per 16 outputs x 9 taps
         return 24.0 / 72.0 if {'wgrad': u.w24g or u.pre_w, 'dgrad': u.w24d}.get(direction, u.w24) else 16.0 / 36.0
 
     def executed_flop_deficit(self):
@@ -832,8 +854,9 @@ class _Engine:
         f = u.fold_src
         xsrc, xldc, fs, fh = (f.y, f.cout_p, f.vec[0], f.vec[1]) if f is not None else (u.xin, u.xin_ldc, None, None)
         _TIMED_UNIT[:] = [u.name + ' fwd', self.executed_fraction(u, 'fwd')]
-        _timed('wino_transform', 0.0, 16 * self.B * u.h * u.w_ * u.cin_p,        # reads the activation once, writes 3x its size
-               'clamd_winograd24_transform_input', ptr(xsrc), xldc, ptr(fs), ptr(fh), ptr(u.vx), self.B, u.h, u.w_, u.cin_p, s)
+        _timed('wino_transform', 0.0, (13 if u.f44 else 16) * self.B * u.h * u.w_ * u.cin_p,   # reads the activation once, writes 3x (F(4x4): 2.25x) its size
+               'clamd_winograd44_transform_input' if u.f44 else 'clamd_winograd24_transform_input', ptr(xsrc), xldc, ptr(fs), ptr(fh), ptr(u.vx),
+               self.B, u.h, u.w_, u.cin_p, s)
 
     def _fwd_fold(self, u, s):
         """Forward filters of a fold candidate (bnfold.hip): packed here, behind the producer's bn_finalize -- with its scale and the
@@ -907,7 +930,8 @@ class _Engine:
                 torch.cuda.current_stream().wait_stream(self.wg_stream)
                 self._pack_pending = 0
             if u.pre_f:
-                _timed('igemm_conv3x3', flops, nbytes, 'clamd_conv3x3_winograd24_pre', ptr(u.vx), ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p,
+                _timed('igemm_conv3x3', flops, nbytes, 'clamd_conv3x3_winograd44_pre' if u.f44 else 'clamd_conv3x3_winograd24_pre',
+                       ptr(u.vx), ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p,
                        ptr(st), rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, tp, s)
             else:
                 name = ('clamd_conv3x3_winograd24_direct_filters' if u.direct_f else 'clamd_conv3x3_winograd24') if u.w24 else 'clamd_conv3x3_winograd'
@@ -1081,15 +1105,17 @@ class _Engine:
             x3.wait_stream(torch.cuda.current_stream())
             if self._yt_ev[self._yt_flip] is not None:      # the GEMM that read this buffer last (two pre-transformed units back)
                 x3.wait_event(self._yt_ev[self._yt_flip])
-            call('clamd_wgrad_winograd24_pre_transform', ptr(u.gz), u.cout_p, ptr(self._x3_buf), B, u.h, u.w_, u.cout_p, x3.cuda_stream)
+            call('clamd_wgrad_winograd44_pre_transform' if u.f44 else 'clamd_wgrad_winograd24_pre_transform', ptr(u.gz), u.cout_p, ptr(self._x3_buf),
+                 B, u.h, u.w_, u.cout_p, x3.cuda_stream)
             self._x3_ev = torch.cuda.Event(); self._x3_ev.record(x3)
         def dgrad():
             _TIMED_UNIT[:] = [u.name + ' dgrad', self.executed_fraction(u, 'dgrad')]
             if u.g_in is not None and u.pre_d:
-                _timed('wino_transform', 0.0, 16 * B * u.h * u.w_ * u.cout_p,      # reads the gradient once, writes 3x its size
-                       'clamd_winograd24_transform_input', ptr(u.gz), u.cout_p, None, None, ptr(self.vg), B, u.h, u.w_, u.cout_p, s)
+                _timed('wino_transform', 0.0, (13 if u.d44 else 16) * B * u.h * u.w_ * u.cout_p,      # reads the gradient once, writes 3x (F(4x4): 2.25x) its size
+                       'clamd_winograd44_transform_input' if u.d44 else 'clamd_winograd24_transform_input', ptr(u.gz), u.cout_p, None, None, ptr(self.vg),
+                       B, u.h, u.w_, u.cout_p, s)
                 _timed('igemm_conv3x3', flops, self._conv_bytes(u),
-                       'clamd_conv3x3_winograd24_pre', ptr(self.vg), ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
+                       'clamd_conv3x3_winograd44_pre' if u.d44 else 'clamd_conv3x3_winograd24_pre', ptr(self.vg), ptr(u.wd), None, ptr(u.g_in), u.g_in.shape[-1], None, 0,
                        B, u.h, u.w_, u.cout_p, u.cin_p, 0, tp, s)
             elif u.g_in is not None and u.wino:
                 name = 'clamd_conv3x3_winograd24_direct_filters' if u.direct_d else ('clamd_conv3x3_winograd24' if u.w24d else 'clamd_conv3x3_winograd')
@@ -1121,14 +1147,14 @@ class _Engine:
         if u.pre_w and self._x3_ev is not None:
             # the gradient-side operand was transformed on the third stream (enqueued when gz became ready, see below)
             self.wg_stream.wait_event(self._x3_ev)
-            call('clamd_wgrad_winograd24_pre', None, u.cout_p, ptr(u.vx), ptr(self._x3_buf), ptr(self.ws), self.ws_bytes,
+            call('clamd_wgrad_winograd44_pre' if u.f44 else 'clamd_wgrad_winograd24_pre', None, u.cout_p, ptr(u.vx), ptr(self._x3_buf), ptr(self.ws), self.ws_bytes,
                  g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, tp, sw)
             ev = torch.cuda.Event(); ev.record(self.wg_stream)
             self._yt_ev[self._yt_flip] = ev
             self._x3_ev = None
         elif u.pre_w:
             _timed('wgrad_conv3x3', flops, self._conv_bytes(u),
-                   'clamd_wgrad_winograd24_pre', ptr(u.gz), u.cout_p, ptr(u.vx), ptr(self.yt), ptr(self.ws), self.ws_bytes,
+                   'clamd_wgrad_winograd44_pre' if u.f44 else 'clamd_wgrad_winograd24_pre', ptr(u.gz), u.cout_p, ptr(u.vx), ptr(self.yt), ptr(self.ws), self.ws_bytes,
                    g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, u.cin, u.cout, u.cout_p, c_seg0, c_seg0p, tp, sw)
         elif u.wino:
             xin, xin_ldc = (u.fold_a.y, u.fold_a.cout_p) if u.fold_on else (u.xin, u.xin_ldc)
