@@ -23,7 +23,7 @@ class Tuning(ctypes.Structure):
     state; an engine owns one of these and passes it to every launch (None = library defaults)."""
     _fields_ = [(n, c_int) for n in ('igemm_pws', 'igemm_ws', 'igemm_variant', 'pws_wres', 'wgrad_ws', 'wgrad_dma',
                                      'wgrad_xcd', 'wgrad_blocks', 'wgrad_tw16', 'wino_band', 'wino_persist', 'wino_mt',
-                                     'bn_reduce_blocks', 'chsum_blocks', 'cu_reserve', 'wino_half')] + [('reserved', c_int * 8)]
+                                     'bn_reduce_blocks', 'chsum_blocks', 'cu_reserve', 'wino_half', 'wgrad_streamk')] + [('reserved', c_int * 7)]
 
     def __init__(self, **kw):
         super().__init__()

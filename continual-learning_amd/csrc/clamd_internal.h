@@ -14,7 +14,7 @@ inline const clamd_tuning& clamd_default_tuning() {
     static const clamd_tuning d = {/*igemm_pws*/ 1, /*igemm_ws*/ 2, /*igemm_variant*/ 0, /*pws_wres*/ 1,
                                    /*wgrad_ws*/ 1, /*wgrad_dma*/ 1, /*wgrad_xcd*/ 1, /*wgrad_blocks*/ 512, /*wgrad_tw16*/ 0,
                                    /*wino_band*/ 0, /*wino_persist*/ 1, /*wino_mt*/ 0,
-                                   /*bn_reduce_blocks*/ 0, /*chsum_blocks*/ 0, /*cu_reserve*/ 0, /*wino_half*/ 0, {0, 0, 0, 0, 0, 0, 0, 0}};
+                                   /*bn_reduce_blocks*/ 0, /*chsum_blocks*/ 0, /*cu_reserve*/ 0, /*wino_half*/ 0, /*wgrad_streamk*/ 1, {0, 0, 0, 0, 0, 0, 0}};
     return d;
 }
 inline const clamd_tuning& clamd_tune(const clamd_tuning* t) { return t ? *t : clamd_default_tuning(); }

@@ -900,6 +900,171 @@ __global__ void __launch_bounds__(256) wino24g_wgrad_reduce_kernel(const W24GRed
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same plane GEMM with the k-steps of ALL (plane, 256 x 256 block) items dealt evenly to the workgroups ("stream-K", round 5).
+// The split-K plan above launches items x splits workgroups in whole rounds of the chip: 36 planes x 8 blocks = 288 items on 256 CUs
+// are two rounds for 1.125 rounds of work, and every split adds a 256-KB slab to write and to re-read.  Here workgroup w owns the
+// global k-step range [w Q, (w + 1) Q) of the items laid end to end (S steps each): it finishes the item it starts in, runs whole
+// items, and stops inside one -- every workgroup does the same number of steps, an item gets floor(last / Q) - floor(first / Q) + 1
+// partial slabs (slot = w - the first workgroup that touches it), and the reduce adds an item's slots in slot order: the map is
+// static, so the result is bit-reproducible.
+struct W24WgSkParams {
+    const float* yt;                      // [npl][Tp][Rp]
+    const float* v;                       // [Tp/32][Cp/8][npl][2][32][4]
+    float* partial;                       // [slot][npl][Rp][Cp]
+    int Rp, Cp, Tp, npl;
+    int S, Q, nbp;                        // k-steps (two tiles) per item, per workgroup; items
+};
+
+__global__ void __launch_bounds__(256, 1) wino24g_wgrad_sk_kernel(const W24WgSkParams p) {
+    int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i32 = lane & 31, h = lane >> 5;
+    const int rb_n = p.Rp >> 8, cb_n = p.Cp >> 8;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const long long total = (long long)p.nbp * p.S;
+    long long g = (long long)wg * p.Q;
+    const long long g_end = min(g + (long long)p.Q, total);
+    const int nk = p.Cp >> 3;
+    const unsigned a_bytes = (unsigned)p.Tp * (unsigned)p.Rp * 4u;
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc(p.v, (unsigned)((size_t)(p.Tp >> 5) * nk * p.npl * 1024));
+    const __amdgpu_buffer_rsrc_t ars_dead = make_rsrc(p.yt, 0u), brs_dead = make_rsrc(p.v, 0u);
+    const unsigned a_step = (unsigned)p.Rp * 8u;                              // two tiles
+    const unsigned b_blk = (unsigned)nk * (unsigned)p.npl * 1024u;
+    while (g < g_end) {                                                       // workgroup-uniform
+        const int b = (int)(g / p.S);
+        const int kb = (int)(g - (long long)b * p.S);
+        const int ke = (int)min((long long)p.S, (long long)kb + (g_end - g));
+        // (row block, column block) fastest: neighbouring workgroups share operand panels of one plane
+        const int cb = b % cb_n, rb = (b / cb_n) % rb_n, pl = b / (cb_n * rb_n);
+        const int r0 = rb * 256 + (w >> 1) * 128, c0 = cb * 256 + (w & 1) * 128;
+        const __amdgpu_buffer_rsrc_t ars = make_rsrc((const char*)p.yt + (size_t)pl * a_bytes, a_bytes);
+        const unsigned a_vo = (unsigned)((h * p.Rp + r0 + 4 * i32) * 4);
+        const unsigned b_vo = (unsigned)(((c0 >> 3) + (i32 >> 1)) * p.npl * 1024 + (i32 & 1) * 512 + h * 16);
+        const unsigned b_pl = (unsigned)pl * 1024u;
+
+        f32x16 acc[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+        uint4 a[W24G_D], bq[W24G_D];
+        auto load = [&](int d, int s) {                 // absolute step s of this item into set d; past the end of the range: zeros, no traffic
+            const bool live = s < ke;
+            const unsigned t = (unsigned)(2 * s);
+            a[d] = buf_ld16(live ? ars : ars_dead, a_vo, (unsigned)s * a_step);
+            bq[d] = buf_ld16(live ? brs : brs_dead, b_vo, (t >> 5) * b_blk + b_pl + (t & 31u) * 16u);
+        };
+#pragma unroll
+        for (int d = 0; d < W24G_D; ++d) {
+            load(d, kb + d);
+            asm volatile("" ::: "memory");                                   // ring order (see wino24g_wgrad_kernel)
+        }
+        for (int s0 = kb; s0 < ke; s0 += W24G_D) {
+#pragma unroll
+            for (int d = 0; d < W24G_D; ++d) {
+                const float am[4] = {__uint_as_float(a[d].x), __uint_as_float(a[d].y), __uint_as_float(a[d].z), __uint_as_float(a[d].w)};
+                const float bn[4] = {__uint_as_float(bq[d].x), __uint_as_float(bq[d].y), __uint_as_float(bq[d].z), __uint_as_float(bq[d].w)};
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(am[m], bn[n], acc[m][n], 0, 0, 0);
+                load(d, s0 + d + W24G_D);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            }
+        }
+        const int slot = wg - (int)(((long long)b * p.S) / p.Q);
+        float* const out = p.partial + (((size_t)slot * p.npl + pl) * p.Rp) * (size_t)p.Cp;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = r0 + 4 * acc_row(e, h) + m;
+                *reinterpret_cast<float4*>(out + (size_t)row * p.Cp + c0 + 4 * i32) = make_float4(acc[m][0][e], acc[m][1][e], acc[m][2][e], acc[m][3][e]);
+            }
+        g += ke - kb;
+    }
+}
+
+// out[rl][cl][3][3] = G^T (sum of an item's slots, in slot order) G for the stream-K slabs: NPL = 24: G4^T . G6 with the sign of plane row
+// 2 (wino24g_wgrad_reduce_kernel), NPL = 36: G6^T . G6.  A thread owns four consecutive (r, c) pairs of all NPL planes.
+struct W24SkReduceParams {
+    const float* partial; float* out;
+    int Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p;
+    int S, Q;
+};
+
+__device__ inline void wsk_gt6(const float (&t)[6], float (&o)[3]) {
+    const float s12 = t[1] + t[2], d12 = t[2] - t[1], s34 = t[3] + t[4], d34 = t[3] - t[4];
+    o[0] = 0.25f * t[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+    o[1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+    o[2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + t[5];
+}
+
+template <int NPL>
+__global__ void __launch_bounds__(256) wino_sk_reduce_kernel(const W24SkReduceParams p) {
+    constexpr int NI = NPL / 6;
+    const long long nquad = (long long)p.Rp * p.Cp / 4;
+    const size_t plane_sz = (size_t)p.Rp * p.Cp, slot_sz = plane_sz * NPL;
+    const int rb_n = p.Rp >> 8, cb_n = p.Cp >> 8;
+    for (long long quad = (long long)blockIdx.x * 256 + threadIdx.x; quad < nquad; quad += (long long)gridDim.x * 256) {
+        const int rp = (int)((quad * 4) / p.Cp), cp0 = (int)((quad * 4) % p.Cp);
+        const int blk = (rp >> 8) * cb_n + (cp0 >> 8);
+        float4 s[NPL];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const long long b = (long long)i * rb_n * cb_n + blk;
+            const int first = (int)((b * p.S) / p.Q), last = (int)(((b + 1) * p.S - 1) / p.Q);
+            const float* src = p.partial + (size_t)i * plane_sz + (size_t)quad * 4;
+            float4 a = *reinterpret_cast<const float4*>(src);
+            for (int k = 1; k <= last - first; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * slot_sz);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            s[i] = a;
+        }
+        const int rl = wn_phys2log(rp, p.r_seg0, p.r_seg0p, p.R);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int cl = wn_phys2log(cp0 + e, p.c_seg0, p.c_seg0p, p.C);
+            if (rl < 0 || cl < 0) continue;
+            float t[3][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float col[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const float4 v = s[6 * i + j];
+                    col[i] = e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w));
+                }
+                if constexpr (NPL == 24) {          // rows: G4^T U, plane row 2 carries the forward image's sign convention
+                    const float u2 = -col[2];
+                    t[0][j] = col[0] + 0.5f * (col[1] + u2);
+                    t[1][j] = 0.5f * (col[1] - u2);
+                    t[2][j] = col[3] + 0.5f * (col[1] + u2);
+                } else {
+                    float o3[3];
+                    const float c6[6] = {col[0], col[1], col[2], col[3], col[4], col[5]};
+                    wsk_gt6(c6, o3);
+                    t[0][j] = o3[0]; t[1][j] = o3[1]; t[2][j] = o3[2];
+                }
+            }
+            float* o = p.out + ((size_t)rl * p.C + cl) * 9;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float o3[3];
+                wsk_gt6(t[a], o3);
+                o[a * 3 + 0] = o3[0]; o[a * 3 + 1] = o3[1]; o[a * 3 + 2] = o3[2];
+            }
+        }
+    }
+}
+
 // workgroup tile of the forward kernels: 8 x 32 pixels, or 16 x 16 for images narrower than 32 (as wino24.hip)
 static inline void w24g_tile(int W, int& ph, int& pw) { if (W >= 32) { ph = 8; pw = 32; } else { ph = 16; pw = 16; } }
 static long long w24g_tiles(int B, int H, int W) {
@@ -946,6 +1111,38 @@ int launch_w24g_wgrad_gemm(const float* yt, const float* v, float* partial, int 
     W24WgGemmParams p{yt, v, partial, Rp, Cp, (int)Tp, nsplit, per, planes};
     hipLaunchKernelGGL(wino24g_wgrad_kernel, dim3((unsigned)(planes * nsplit * (Rp / 256) * (Cp / 256))), dim3(256), 0, s, p);
     return clamd_check_launch("wgrad_winograd_pre (plane GEMM)");
+}
+// stream-K plan: k-steps per workgroup (a multiple of the prefetch ring) for `cus` workgroups; slots an item can get
+void w24g_sk_plan(long long Tp, int Rp, int Cp, int planes, int cus, int* S, int* Q, int* nbp, int* nwg, int* max_slots) {
+    *S = (int)(Tp / 2);
+    *nbp = planes * (Rp / 256) * (Cp / 256);
+    const long long total = (long long)*nbp * *S;
+    long long q = (total + cus - 1) / cus;
+    q = (q + W24G_D - 1) / W24G_D * W24G_D;
+    *Q = (int)q;
+    *nwg = (int)((total + q - 1) / q);
+    *max_slots = (int)((*S + q - 1) / q) + 1;
+}
+size_t w24g_sk_workspace_bytes(long long Tp, int Rp, int Cp, int planes) {
+    // the slot count is largest on the whole chip (smallest Q): size for that; a reserve (fewer workgroups) needs no more
+    int S, Q, nbp, nwg, ms;
+    w24g_sk_plan(Tp, Rp, Cp, planes, clamd_num_cus(), &S, &Q, &nbp, &nwg, &ms);
+    return (size_t)ms * planes * Rp * Cp * sizeof(float);
+}
+int launch_w24g_wgrad_sk(const float* yt, const float* v, float* workspace, size_t ws_bytes, float* out, long long Tp, int Rp, int Cp, int planes,
+                         int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p, const clamd_tuning& tn, hipStream_t s) {
+    int S, Q, nbp, nwg, ms;
+    w24g_sk_plan(Tp, Rp, Cp, planes, clamd_usable_cus(tn), &S, &Q, &nbp, &nwg, &ms);
+    if ((size_t)ms * planes * Rp * Cp * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd_pre: workspace too small");
+    W24WgSkParams p{yt, v, workspace, Rp, Cp, (int)Tp, planes, S, Q, nbp};
+    hipLaunchKernelGGL(wino24g_wgrad_sk_kernel, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    if (int e = clamd_check_launch("wgrad_winograd_pre (stream-K plane GEMM)")) return e;
+    W24SkReduceParams rp{workspace, out, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p, S, Q};
+    const long long nquad = (long long)Rp * Cp / 4;
+    const unsigned g = (unsigned)std::min<long long>((nquad + 255) / 256, 8192);
+    if (planes == 24) hipLaunchKernelGGL(wino_sk_reduce_kernel<24>, dim3(g), dim3(256), 0, s, rp);
+    else hipLaunchKernelGGL(wino_sk_reduce_kernel<36>, dim3(g), dim3(256), 0, s, rp);
+    return clamd_check_launch("wgrad_winograd_pre (stream-K reduce)");
 }
 }  // namespace clamd
 static int w24g_wg_plan(long long Tp, int Rp, int Cp, const clamd_tuning& tn, int* per_out) { return clamd::w24g_wg_plan_planes(Tp, Rp, Cp, 24, tn, per_out); }
@@ -1050,7 +1247,7 @@ size_t clamd_wgrad_winograd24_pre_workspace_bytes(int B, int H, int W, int Rp, i
     const long long Tp = w24g_tiles(B, H, W) * 32;
     const long long nb = 24LL * (Rp / 256) * (Cp / 256);
     const long long max_split = std::max<long long>(1, std::min<long long>((3LL * clamd_num_cus()) / nb, Tp / (2 * W24G_D)));
-    return (size_t)max_split * 24 * Rp * Cp * sizeof(float);
+    return std::max((size_t)max_split * 24 * Rp * Cp * sizeof(float), clamd::w24g_sk_workspace_bytes(Tp, Rp, Cp, 24));
 }
 
 int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, float* yt, float* workspace, size_t ws_bytes, float* out,
@@ -1067,7 +1264,7 @@ int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, floa
         return clamd_fail("wgrad_winograd24_pre: an operand exceeds 2^32 bytes");
     int per = 0;
     const int nsplit = w24g_wg_plan(Tp, Rp, Cp, tn, &per);
-    if ((size_t)nsplit * 24 * Rp * Cp * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd24_pre: workspace too small");
+    if (!tn.wgrad_streamk && (size_t)nsplit * 24 * Rp * Cp * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd24_pre: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     if (gz) {                                  // gz == NULL: yt already holds the transformed gradient (clamd_wgrad_winograd24_pre_transform)
         W24WgXformParams pa{gz, gz_ldc, yt, B, H, W, Rp, (int)Tp};
@@ -1077,6 +1274,8 @@ int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, floa
         else hipLaunchKernelGGL(wino24g_wgrad_xform_kernel<4>, dim3(g), dim3(256), 0, s, pa);
         if (int e = clamd_check_launch("wgrad_winograd24_pre transform")) return e;
     }
+    if (tn.wgrad_streamk)
+        return launch_w24g_wgrad_sk(yt, v, workspace, ws_bytes, out, Tp, Rp, Cp, 24, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p, tn, s);
     if (int e = launch_w24g_wgrad_gemm(yt, v, workspace, Rp, Cp, Tp, nsplit, per, 24, s)) return e;
     W24GReduceParams rp{workspace, out, nsplit, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p};
     const long long nquad = (long long)Rp * Cp / 4;

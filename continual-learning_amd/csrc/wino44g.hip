@@ -584,6 +584,9 @@ namespace clamd {
 int w24g_wg_plan_planes(long long Tp, int Rp, int Cp, int planes, const clamd_tuning& tn, int* per_out);
 long long w24g_wg_max_split(long long Tp, int Rp, int Cp, int planes);
 int launch_w24g_wgrad_gemm(const float* yt, const float* v, float* partial, int Rp, int Cp, long long Tp, int nsplit, int per, int planes, hipStream_t s);
+size_t w24g_sk_workspace_bytes(long long Tp, int Rp, int Cp, int planes);
+int launch_w24g_wgrad_sk(const float* yt, const float* v, float* workspace, size_t ws_bytes, float* out, long long Tp, int Rp, int Cp, int planes,
+                         int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p, const clamd_tuning& tn, hipStream_t s);
 }  // namespace clamd
 
 extern "C" {
@@ -666,7 +669,7 @@ size_t clamd_wgrad_winograd44_pre_operand_elems(int B, int H, int W, int Rp) {
 size_t clamd_wgrad_winograd44_pre_workspace_bytes(int B, int H, int W, int Rp, int Cp) {
     if (B <= 0 || H <= 0 || W <= 0 || Rp < 256 || Cp < 256) return 0;
     const long long Tp = w44_blocks(B, H, W) * 32;
-    return (size_t)w24g_wg_max_split(Tp, Rp, Cp, 36) * 36 * Rp * Cp * sizeof(float);
+    return std::max((size_t)w24g_wg_max_split(Tp, Rp, Cp, 36) * 36 * Rp * Cp * sizeof(float), w24g_sk_workspace_bytes(Tp, Rp, Cp, 36));
 }
 
 static int w44_launch_yt(const float* gz, int gz_ldc, float* yt, int B, int H, int W, int Rp, long long Tp, hipStream_t s) {
@@ -692,10 +695,12 @@ int clamd_wgrad_winograd44_pre(const float* gz, int gz_ldc, const float* v, floa
         return clamd_fail("wgrad_winograd44_pre: an operand exceeds 2^32 bytes");
     int per = 0;
     const int nsplit = w24g_wg_plan_planes(Tp, Rp, Cp, 36, tn, &per);
-    if ((size_t)nsplit * 36 * Rp * Cp * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd44_pre: workspace too small");
+    if (!tn.wgrad_streamk && (size_t)nsplit * 36 * Rp * Cp * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd44_pre: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     if (gz)                                    // gz == NULL: yt already holds the transformed gradient (clamd_wgrad_winograd44_pre_transform)
         if (int e = w44_launch_yt(gz, gz_ldc, yt, B, H, W, Rp, Tp, s)) return e;
+    if (tn.wgrad_streamk)
+        return launch_w24g_wgrad_sk(yt, v, workspace, ws_bytes, out, Tp, Rp, Cp, 36, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p, tn, s);
     if (int e = launch_w24g_wgrad_gemm(yt, v, workspace, Rp, Cp, Tp, nsplit, per, 36, s)) return e;
     W44GReduceParams rp{workspace, out, nsplit, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p};
     const long long nquad = (long long)Rp * Cp / 4;

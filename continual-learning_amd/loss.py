@@ -54,11 +54,13 @@ class _CEFn(torch.autograd.Function):
             # package's UNet, d logits written a second time in the layout (and dtype) its 1x1 head's data gradient reads -- the backward
             # pass then starts without a conversion pass (unet._Engine.backward)
             from . import unet as U
-            call('clamd_ce_count', ptr(labels), B, K, H, W, int(ignore_index), ptr(ws), wsb, _lib.stream_ptr())
+            # (algorithmic bytes, SURVEY 8d: logits read + d logits written + the label; the counting pass reads the labels a second time)
+            U._hbm('loss', 0, 'clamd_ce_count', ptr(labels), B, K, H, W, int(ignore_index), ptr(ws), wsb, _lib.stream_ptr())
             eng = U.dlogits_sink(logits_in, B, K, H, W) if HANDOVER else None
             nh, ldc, dcode = (eng.dl, eng.Kp, eng.dcode) if eng is not None else (None, 0, 0)
-            call('clamd_ce_fwd_bwd_counted', ptr(logits), ptr(labels), ptr(dl), ptr(nh), ldc, dcode, ptr(out3), ptr(ws), wsb, B, K, H, W,
-                 int(ignore_index), 1.0, _lib.stream_ptr())
+            U._hbm('loss', B * H * W * (2 * K * 4 + 8 + (ldc * eng.esize if eng is not None else 0)),
+                   'clamd_ce_fwd_bwd_counted', ptr(logits), ptr(labels), ptr(dl), ptr(nh), ldc, dcode, ptr(out3), ptr(ws), wsb, B, K, H, W,
+                   int(ignore_index), 1.0, _lib.stream_ptr())
             if eng is not None:
                 ctx.sink = eng
                 # a STRONG reference: while the engine waits for this gradient its storage cannot be freed and handed to another

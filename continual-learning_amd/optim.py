@@ -77,6 +77,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._tensors_dev = torch.from_numpy(t.view(np.uint8).copy()).to(dev)
         self._chunks_dev = torch.tensor(chunks, dtype=torch.int32, device=dev)
         self._nchunks = len(chunks)
+        self._numel = int(sum(p.numel() for p in params))
         self._l2acc = torch.zeros(1 + self._nchunks, dtype=torch.float32, device=dev)
         self._table = [(p.data_ptr(), p.grad.data_ptr()) for p in params]
 
@@ -134,8 +135,10 @@ class FusedAdam(torch.optim.Optimizer):
                 self._init_state(params)
             self._build_table(params)
         self.sync_hyper()
-        call('clamd_adam_step', ptr(self._tensors_dev), ptr(self._chunks_dev), self._nchunks, ptr(self._hyper),
-             ptr(self._step_dev), ptr(self._derived), ptr(self._l2acc) if self._anchor is not None else None,
-             _lib.stream_ptr())
+        from . import unet as U
+        U._hbm('adam', 28 * self._numel,      # p, g, m, v read; p, m, v written
+               'clamd_adam_step', ptr(self._tensors_dev), ptr(self._chunks_dev), self._nchunks, ptr(self._hyper),
+               ptr(self._step_dev), ptr(self._derived), ptr(self._l2acc) if self._anchor is not None else None,
+               _lib.stream_ptr())
         self._step_host += 1                # host-side mirror of the device counter (shared by all param states)
         return loss

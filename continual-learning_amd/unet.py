@@ -133,6 +133,13 @@ def _timed(tag, flops, nbytes, name, *args):
     kt.append((tag, flops, e0, e1, nbytes, _TIMED_UNIT[0], _TIMED_UNIT[1]))
 
 
+def _hbm(family, nbytes, name, *args):
+    """A launch of an HBM-bound kernel family (A5 / A6 BatchNorm and pooling passes, A7 ConvTranspose, A9 head, A10 loss,
+    A13 Adam, enc1.0) with its ALGORITHMIC bytes -- every tensor it has to read or write, once: timed per launch by bench.py's instrumented
+    steps (`hbm_kernels` on the JSON line), a plain launch otherwise."""
+    _timed('hbm:' + family, 0.0, nbytes, name, *args)
+
+
 def stage_table(num_classes, in_dim=3, conv_dim=64):
     """Structure of models/unet.py:49-72: (name, wrapped_in_block, pool_first, conv/bn module indices, tail)."""
     d = conv_dim
@@ -774,8 +781,8 @@ class _Engine:
         self._ev_pack_late = None
         self._pack_late_pending = self.pack_late is not None      # released beside convolution PACK_LATE_AT (see _release_pack_late)
         if self.convs[0].im2col:
-            call('clamd_nchw_im2col3', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
-                 self.x_in.shape[-1], dc, s)
+            _hbm('enc1.0', B * H * W * (4 * m.in_dim + self.esize * self.x_in.shape[-1]),
+                 'clamd_nchw_im2col3', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W, self.x_in.shape[-1], dc, s)
         else:
             call('clamd_nchw_to_nhwc', ptr(x), ptr(self.x_in), self.x_in.shape[-1], B, m.in_dim, H, W,
                  self.x_in.shape[-1], 1.0, dc, s)
@@ -798,8 +805,8 @@ class _Engine:
                      ptr(t.bias_fold), t.cout, t.cin, t.cout_p, s)
                 tx, tx_ldc, tbias = fb.y, fb.cout_p, t.bias_fold
             if t.kind == 'convT':
-                call('clamd_convT2x2_fwd', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(t.y_slice), t.y_ldc,
-                     B, h, w, t.cin_p, t.cout_p, dc, s)
+                _hbm('convT', self.esize * (B * h * w * (t.cin + 4 * t.cout) + 4 * t.cin * t.cout),
+                     'clamd_convT2x2_fwd', ptr(t.x), t.x.shape[-1], ptr(t.wf), ptr(t.bias_p), ptr(t.y_slice), t.y_ldc, B, h, w, t.cin_p, t.cout_p, dc, s)
             elif predict and t.cout_p <= 64:      # arg-max fused into the head's epilogue: the logits never reach HBM
                 logits = torch.empty(B, H, W, dtype=torch.int64, device=self.dev)
                 call('clamd_conv1x1_argmax', ptr(tx), tx_ldc, ptr(t.wf), ptr(tbias), ptr(logits), None, B, h, w,
@@ -812,8 +819,8 @@ class _Engine:
                 call('clamd_argmax_confusion', ptr(lg), None, ptr(logits), None, B, self.K, 1, H, W, s)
             else:
                 logits = torch.empty(B, self.K, H, W, dtype=torch.float32, device=self.dev)
-                call('clamd_conv1x1_logits', ptr(tx), tx_ldc, ptr(t.wf), ptr(tbias), ptr(logits), B, h, w,
-                     t.cin_p, t.cout_p, self.K, dc, s)
+                _hbm('head', B * h * w * (self.esize * t.cin + 4 * self.K),
+                     'clamd_conv1x1_logits', ptr(tx), tx_ldc, ptr(t.wf), ptr(tbias), ptr(logits), B, h, w, t.cin_p, t.cout_p, self.K, dc, s)
         if self._pack_pending == 2:     # no Winograd layer ran at all: the late part was never enqueued
             for t in self.wino_late:
                 t.run(self.wg_stream.cuda_stream)
@@ -915,7 +922,8 @@ class _Engine:
         flops = 2.0 * Bl * u.h * u.w_ * 9 * u.cin * u.cout
         nbytes = self.esize * (Bl * u.h * u.w_ * (u.cin + u.cout) + 9 * u.cin * u.cout)
         if u.im2col:
-            call('clamd_conv1x1', ptr(xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p,
+            _hbm('enc1.0', self.esize * Bl * u.h * u.w_ * (u.cin_p + u.cout),
+                 'clamd_conv1x1', ptr(xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p,
                  ptr(st), None, None, rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
         elif u.wino:
             if self._pack_pending == 2:
@@ -952,12 +960,14 @@ class _Engine:
         if u.apply_folded:          # the only reader of the BatchNorm output is the next convolution's input transform
             return
         if u.pool_fold:             # ... or the filters and bias tables of both readers of an encoder block's output: only the pooling is left
-            call('clamd_maxpool2x2', ptr(u.y), u.y_ldc, ptr(u.vec[0]), ptr(u.pooled), u.pooled.shape[-1], self.B, u.h, u.w_, u.cout_p, self.dcode, s)
+            _hbm('bn_fwd', self.esize * self.B * u.h * u.w_ * u.cout * 5 // 4,
+                 'clamd_maxpool2x2', ptr(u.y), u.y_ldc, ptr(u.vec[0]), ptr(u.pooled), u.pooled.shape[-1], self.B, u.h, u.w_, u.cout_p, self.dcode, s)
             return
         if u.apply_in_filters:      # ... or its filters and bias table (bnfold.hip)
             return
         v = u.vec
-        call('clamd_bn_apply', ptr(u.y), u.cout_p, ptr(v[0]), ptr(v[1]), ptr(u.out), u.out_ldc,
+        _hbm('bn_fwd', self.esize * self.B * u.h * u.w_ * u.cout * (9 if u.pooled is not None else 8) // 4,
+             'clamd_bn_apply', ptr(u.y), u.cout_p, ptr(v[0]), ptr(v[1]), ptr(u.out), u.out_ldc,
              ptr(u.pooled), u.pooled.shape[-1] if u.pooled is not None else 0, self.B, u.h, u.w_, u.cout_p, self.dcode, s)
 
     # ------------------------------------------------------------------------------------------ backward
@@ -1012,28 +1022,35 @@ class _Engine:
                         # not the tensor this package's loss wrote beside its NHWC copy (another loss, a hook, a sum of gradients): convert
                         call('clamd_nchw_to_nhwc', ptr(gout), ptr(self.dl), self.Kp, B, self.K, H, W, self.Kp, 1.0, dc, s)
                     self.dl_src = None
-                    call('clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], None,
+                    _hbm('head', self.esize * B * h * w * (self.Kp + t.cin),
+                         'clamd_conv1x1', ptr(self.dl), self.Kp, ptr(t.wd), None, ptr(t.g_x), t.g_x.shape[-1], None,
                          ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
                          t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cout_p, t.cin_p, 0, dc, s)
                     sw = self._wg_stream_ptr()      # parameter gradients on the second stream, behind the data gradient (see _conv_bwd)
                     fb = t.fold_b
                     tx, tx_ldc = (fb.y, fb.cout_p) if fb is not None else (t.x, t.x.shape[-1])
-                    call('clamd_wgrad', _lib.WGRAD_PW, ptr(self.dl), self.Kp, ptr(tx), tx_ldc, ptr(self.ws),
+                    _hbm('head', self.esize * B * h * w * (self.Kp + t.cin),
+                         'clamd_wgrad', _lib.WGRAD_PW, ptr(self.dl), self.Kp, ptr(tx), tx_ldc, ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cout_p, t.cin_p, t.cout, t.cin,
                          t.cout, t.cout_p, t.cin, t.cin_p, dc, tp, sw)
-                    call('clamd_channel_sum', ptr(self.dl), self.Kp, g[t.keys[1]], B * h * w, self.Kp, t.cout, dc,
+                    _hbm('head', 0,                # algorithmically free: d logits was just streamed by the weight gradient above
+                         'clamd_channel_sum', ptr(self.dl), self.Kp, g[t.keys[1]], B * h * w, self.Kp, t.cout, dc,
                          ptr(self.ws), self.ws_bytes, tp, sw)
                     if fb is not None:      # the weight gradient ran on the un-normalised tensor: dW = scale * dW + shift * (bias gradient)
                         call('clamd_bn_fold_wgrad_pointwise', g[t.keys[1]], ptr(fb.vec[0]), ptr(fb.vec[1]), g[t.keys[0]], t.cout, t.cin, sw)
                 else:
-                    call('clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
+                    ctb = self.esize * (B * h * w * (t.cin + 4 * t.cout) + 4 * t.cin * t.cout)
+                    _hbm('convT', ctb,
+                         'clamd_convT2x2_dgrad', ptr(t.gy_slice), t.y_ldc, ptr(t.wd), ptr(t.g_x), t.g_x.shape[-1],
                          ptr(t.consumer.y) if t.consumer else None, ptr(t.consumer.sums) if t.consumer else None,
                          t.consumer.sum_rows if t.consumer else 0, B, h, w, t.cin_p, t.cout_p, dc, s)
                     sw = self._wg_stream_ptr()
-                    call('clamd_wgrad', _lib.WGRAD_UP2, ptr(t.x), t.x.shape[-1], ptr(t.gy_slice), t.y_ldc, ptr(self.ws),
+                    _hbm('convT', ctb,
+                         'clamd_wgrad', _lib.WGRAD_UP2, ptr(t.x), t.x.shape[-1], ptr(t.gy_slice), t.y_ldc, ptr(self.ws),
                          self.ws_bytes, g[t.keys[0]], B, h, w, t.cin_p, t.cout_p, t.cin, t.cout,
                          t.cin, t.cin_p, t.cout, t.cout_p, dc, tp, sw)
-                    call('clamd_channel_sum', ptr(t.gy_slice), t.y_ldc, g[t.keys[1]], B * 4 * h * w, t.cout_p,
+                    _hbm('convT', 0,               # algorithmically free: the gradient was just streamed by the weight gradient above
+                         'clamd_channel_sum', ptr(t.gy_slice), t.y_ldc, g[t.keys[1]], B * 4 * h * w, t.cout_p,
                          t.cout, dc, ptr(self.ws), self.ws_bytes, tp, sw)
             for u in reversed(st['convs']):
                 self._conv_bwd(u, s)
@@ -1076,17 +1093,20 @@ class _Engine:
         count = float(B * u.h * u.w_)
         g = self._gp
         if not u.fused_reduce:     # otherwise the five sums were accumulated by the epilogue of the kernel that wrote `ga`
-            call('clamd_bn_bwd_reduce', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.y_ldc,
+            _hbm('bn_bwd', 0,                      # algorithmically free: one backward pass reads g and y once (the apply pass below is charged for it)
+                 'clamd_bn_bwd_reduce', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.y_ldc,
                  ptr(v[0]), ptr(v[1]), ptr(u.sums), u.sum_rows, B, u.h, u.w_, u.cout_p, dc, tp, s)
         two = u.fused_reduce and u.gz_nrows > 0      # the producing launch took sum g and sum g y only: d conv-bias = sum g_z, from the apply pass
         call('clamd_bn_bwd_finalize', ptr(u.sums), u.sum_rows, ptr(u.gamma), ptr(v[2]), ptr(v[3]), ptr(v[4]), g[u.keys[2]],
              g[u.keys[3]], None if two else g[u.keys[1]], u.cout_p, u.cout, count, s)
         if two:
             assert gp is None
-            call('clamd_bn_bwd_apply_sums', ptr(ga), ga_ldc, ptr(u.y), u.y_ldc, ptr(v[4]), ptr(u.gz), u.cout_p, ptr(u.gz_rows), u.gz_nrows,
+            _hbm('bn_bwd', self.esize * B * u.h * u.w_ * u.cout * 3,
+                 'clamd_bn_bwd_apply_sums', ptr(ga), ga_ldc, ptr(u.y), u.y_ldc, ptr(v[4]), ptr(u.gz), u.cout_p, ptr(u.gz_rows), u.gz_nrows,
                  B, u.h, u.w_, u.cout_p, dc, s)
         else:
-            call('clamd_bn_bwd_apply', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.y_ldc,
+            _hbm('bn_bwd', self.esize * B * u.h * u.w_ * u.cout * (13 if gp is not None else 12) // 4,
+                 'clamd_bn_bwd_apply', ptr(ga), ga_ldc, ptr(gp), gp.shape[-1] if gp is not None else 0, ptr(u.y), u.y_ldc,
                  ptr(v[0]), ptr(v[1]), ptr(v[4]), ptr(u.gz), u.cout_p, B, u.h, u.w_, u.cout_p, dc, s)
         if len(u.cin_segs) == 2:
             c_seg0, c_seg0p = u.cin_segs[0]
@@ -1140,7 +1160,8 @@ class _Engine:
         if two:      # off the critical chain: the fixed-order sum of the apply pass's rows, in front of this unit's weight gradient
             call('clamd_rows_sum', ptr(u.gz_rows), u.gz_nrows, g[u.keys[1]], u.cout_p, u.cout, sw)
         if u.im2col:
-            call('clamd_wgrad', _lib.WGRAD_PW, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
+            _hbm('enc1.0', self.esize * B * u.h * u.w_ * (u.cout + u.cin_p),
+                 'clamd_wgrad', _lib.WGRAD_PW, ptr(u.gz), u.cout_p, ptr(u.xin), u.xin_ldc, ptr(self.ws), self.ws_bytes,
                  g[u.keys[0]], B, u.h, u.w_, u.cout_p, u.cin_p, u.cout, 9 * u.cin, u.cout, u.cout_p, 9 * u.cin, u.cin_p, dc, tp, sw)
             return
         _TIMED_UNIT[:] = [u.name + ' wgrad', self.executed_fraction(u, 'wgrad')]

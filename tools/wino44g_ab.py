@@ -15,6 +15,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B = 16
 SH = [(128, 256, 64), (256, 256, 64), (512, 256, 64), (256, 512, 32), (512, 512, 32), (1024, 512, 32), (512, 1024, 32), (512, 1024, 16), (1024, 1024, 16)]
 PEAK = 157.3
+SK = {1: None, 0: lib.Tuning(wgrad_streamk=0).ref()}
 
 
 def timed(fn):
@@ -26,7 +27,7 @@ def timed(fn):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-print(f'{"layer":>18s} | {"xf24":>6s} {"pre24":>7s} {"exec":>5s} | {"xf44":>6s} {"TB/s":>5s} {"pre44":>7s} {"exec":>5s} | {"fwd 24/44":>9s} | {"wg24":>7s} {"wg44":>7s} {"24/44":>6s}')
+print(f'{"layer":>18s} | {"xf24":>6s} {"pre24":>7s} {"exec":>5s} | {"xf44":>6s} {"TB/s":>5s} {"pre44":>7s} {"exec":>5s} | {"fwd 24/44":>9s} | {"wg24":>7s} {"wg44":>7s} {"24/44":>6s} | split-K: {"wg24":>7s} {"wg44":>7s}')
 tot = dict(f24=0.0, f44=0.0, w24=0.0, w44=0.0)
 for cin, cout, hw in SH:
     x = torch.randn(B, hw, hw, cin, device='cuda')
@@ -60,14 +61,15 @@ for cin, cout, hw in SH:
             res[f'xf{form}'] = timed(lambda: lib.call(f'clamd_winograd{form}_transform_input', ptr(x), cin, None, None, ptr(v), B, hw, hw, cin, s))
             res[f'pre{form}'] = timed(lambda: lib.call(f'clamd_conv3x3_winograd{form}_pre', ptr(v), ptr(wf), ptr(bias), ptr(y), cout, ptr(st), rows,
                                                       B, hw, hw, cin, cout, 1, None, s))
-            res[f'wg{form}'] = timed(lambda: lib.call(f'clamd_wgrad_winograd{form}_pre', ptr(gz), cout, ptr(v), ptr(yt), ptr(ws), wsb, ptr(gw), B, hw, hw,
-                                                     cout, cin, cout, cin, cout, cout, cin, cin, None, s)) if pre_wg else float('nan')
+            for sk in (1, 0):        # stream-K plane GEMM (default) / split-K plan in whole rounds
+                res[f'wg{form}' + ('' if sk else 's')] = timed(lambda: lib.call(f'clamd_wgrad_winograd{form}_pre', ptr(gz), cout, ptr(v), ptr(yt), ptr(ws), wsb, ptr(gw),
+                                                                             B, hw, hw, cout, cin, cout, cin, cout, cout, cin, cin, SK[sk], s)) if pre_wg else float('nan')
     f24, f44 = res['xf24'] + res['pre24'], res['xf44'] + res['pre44']
     tot['f24'] += f24; tot['f44'] += f44
     if res['wg24'] == res['wg24']:
         tot['w24'] += res['wg24']; tot['w44'] += res['wg44']
     xb = (x.numel() + K[44][3].numel()) * 4
     print(f'{cin:5d}->{cout:5d} @{hw:3d} | {res["xf24"]:6.1f} {res["pre24"]:7.1f} {fl / 3 / res["pre24"] / 1e6 / PEAK:5.2f} | {res["xf44"]:6.1f} {xb / res["xf44"] / 1e6:5.2f} '
-          f'{res["pre44"]:7.1f} {fl / 4 / res["pre44"] / 1e6 / PEAK:5.2f} | {f24 / f44:9.3f} | {res["wg24"]:7.1f} {res["wg44"]:7.1f} {res["wg24"] / res["wg44"]:6.3f}')
+          f'{res["pre44"]:7.1f} {fl / 4 / res["pre44"] / 1e6 / PEAK:5.2f} | {f24 / f44:9.3f} | {res["wg24"]:7.1f} {res["wg44"]:7.1f} {res["wg24"] / res["wg44"]:6.3f} |          {res["wg24s"]:7.1f} {res["wg44s"]:7.1f}')
 print('total: transform + forward F(2x4) %.3f ms, F(4x4) %.3f ms (%.3fx) | weight gradient F(2x4) %.3f ms, F(4x4) %.3f ms (%.3fx)' %
       (tot['f24'] / 1e3, tot['f44'] / 1e3, tot['f24'] / tot['f44'], tot['w24'] / 1e3, tot['w44'] / 1e3, tot['w24'] / max(tot['w44'], 1e-9)))
