@@ -36,7 +36,7 @@ int clamd_check_tuning(const clamd_tuning* t) {
     if (t->chsum_blocks < 0 || t->chsum_blocks > 1024) return clamd_fail("tuning: chsum_blocks 0..1024");
     if (t->cu_reserve < 0 || t->cu_reserve > 128) return clamd_fail("tuning: cu_reserve 0..128");
     if (t->wino_half < 0 || t->wino_half > 1) return clamd_fail("tuning: wino_half 0..1");
-    if (t->wgrad_streamk < 0 || t->wgrad_streamk > 1) return clamd_fail("tuning: wgrad_streamk 0..1");
+    if (t->wgrad_streamk < 0 || t->wgrad_streamk > 2) return clamd_fail("tuning: wgrad_streamk 0..2");
     return 0;
 }
 

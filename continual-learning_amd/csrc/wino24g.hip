@@ -1264,7 +1264,10 @@ int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, floa
         return clamd_fail("wgrad_winograd24_pre: an operand exceeds 2^32 bytes");
     int per = 0;
     const int nsplit = w24g_wg_plan(Tp, Rp, Cp, tn, &per);
-    if (!tn.wgrad_streamk && (size_t)nsplit * 24 * Rp * Cp * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd24_pre: workspace too small");
+    // stream-K where the items alone nearly fill the chip (an item then gets 2-3 slots); with fewer, larger items the split-K plan's
+    // whole rounds are as even and its slabs are fewer (tools/wino44g_ab.py: 1.10-1.21x faster from 96 items on, 0.78-0.95x below)
+    const bool streamk = tn.wgrad_streamk == 2 || (tn.wgrad_streamk == 1 && (long long)24 * (Rp / 256) * (Cp / 256) * 8 >= 3LL * clamd_usable_cus(tn));
+    if (!streamk && (size_t)nsplit * 24 * Rp * Cp * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd24_pre: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     if (gz) {                                  // gz == NULL: yt already holds the transformed gradient (clamd_wgrad_winograd24_pre_transform)
         W24WgXformParams pa{gz, gz_ldc, yt, B, H, W, Rp, (int)Tp};
@@ -1274,7 +1277,7 @@ int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, floa
         else hipLaunchKernelGGL(wino24g_wgrad_xform_kernel<4>, dim3(g), dim3(256), 0, s, pa);
         if (int e = clamd_check_launch("wgrad_winograd24_pre transform")) return e;
     }
-    if (tn.wgrad_streamk)
+    if (streamk)
         return launch_w24g_wgrad_sk(yt, v, workspace, ws_bytes, out, Tp, Rp, Cp, 24, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p, tn, s);
     if (int e = launch_w24g_wgrad_gemm(yt, v, workspace, Rp, Cp, Tp, nsplit, per, 24, s)) return e;
     W24GReduceParams rp{workspace, out, nsplit, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p};

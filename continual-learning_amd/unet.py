@@ -926,9 +926,10 @@ class _Engine:
                  'clamd_conv1x1', ptr(xin), u.xin_ldc, ptr(u.wf), ptr(u.bias_p), ptr(y), u.cout_p,
                  ptr(st), None, None, rows, Bl, u.h, u.w_, u.cin_p, u.cout_p, 1, dc, s)
         elif u.wino:
-            if self._pack_pending == 2:
-                # the late transforms (HBM-bound, 0.15 ms) start here, under this MFMA-bound convolution, instead of beside the
-                # HBM-bound first-layer kernels
+            if self._pack_pending == 2 and (u.level >= 1 or u.pack_late):
+                # the late transforms (HBM-bound, 0.3 ms) start here, under this MFMA-bound convolution, instead of beside the
+                # HBM-bound first-layer kernels -- and, round 5, behind enc1's pooling pass (level >= 1): started under enc1's second
+                # convolution they were still running when that pass came up and it took 141 instead of 64 us (r05h trace)
                 torch.cuda.current_stream().wait_event(self._ev_early)
                 self.wg_stream.wait_stream(torch.cuda.current_stream())
                 for t in self.wino_late:

@@ -58,8 +58,9 @@ int clamd_bn_bwd_nsums(void);
  *   wino_mt        0|1|2   tile height: per-launch choice | 8 | 16 pixels
  *   bn_reduce_blocks / chsum_blocks   0 (per-launch choice) | n: grid cap of the per-channel reductions
  *   cu_reserve     CUs the persistent grids leave free (for RCCL channel workgroups under data parallelism)
- *   wgrad_streamk  0|1     clamd_wgrad_winograd24_pre / 44_pre: split-K plan in whole rounds of the chip | the k-steps of all (plane, block)
- *                          items dealt evenly to one workgroup per CU (static map, slots added in order: deterministic)
+ *   wgrad_streamk  0|1|2   clamd_wgrad_winograd24_pre / 44_pre: split-K plan in whole rounds of the chip | per launch (stream-K from 96 items on) |
+ *                          always the k-steps of all (plane, block) items dealt evenly to one workgroup per CU (static map, an item's slots
+ *                          added in slot order: deterministic)
  *   wino_half      0|1     clamd_conv3x3_winograd24: 32 tiles x 64 channels, one workgroup per CU | 32 x 32, two per CU (wino24n.hip) */
 typedef struct clamd_tuning {
     int igemm_pws, igemm_ws, igemm_variant, pws_wres;

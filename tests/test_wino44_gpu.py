@@ -142,8 +142,9 @@ def test_wgrad_winograd44_pretransformed(C, shape):
     c_seg0, c_seg0p = (segs[0][0], segs[0][1]) if len(segs) == 2 else (cin, cin_p)
     rgw = O.conv3x3_bwd(x, w, gz)[1]
     outs = []
-    # default: the stream-K plane GEMM; wgrad_streamk = 0: the split-K plan in whole rounds of the chip
-    for tn in (None, None, lib.Tuning(cu_reserve=100), lib.Tuning(wgrad_streamk=0), lib.Tuning(wgrad_streamk=0, cu_reserve=100)):
+    # wgrad_streamk: 1 (default) per launch, 0 the split-K plan in whole rounds of the chip, 2 the stream-K plane GEMM
+    for tn in (None, None, lib.Tuning(cu_reserve=100), lib.Tuning(wgrad_streamk=0), lib.Tuning(wgrad_streamk=0, cu_reserve=100), lib.Tuning(wgrad_streamk=2),
+               lib.Tuning(wgrad_streamk=2, cu_reserve=100)):
         gw = torch.full((cout, cin, 3, 3), 5.0, device='cuda')
         lib.call('clamd_wgrad_winograd44_pre', ptr(gzt), cout_p, ptr(v), ptr(yt), ptr(ws), wsb, ptr(gw), B, H, W,
                  cout_p, cin_p, cout, cin, cout, cout_p, c_seg0, c_seg0p, tn.ref() if tn else None, s)

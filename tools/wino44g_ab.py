@@ -15,7 +15,8 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B = 16
 SH = [(128, 256, 64), (256, 256, 64), (512, 256, 64), (256, 512, 32), (512, 512, 32), (1024, 512, 32), (512, 1024, 32), (512, 1024, 16), (1024, 1024, 16)]
 PEAK = 157.3
-SK = {1: None, 0: lib.Tuning(wgrad_streamk=0).ref()}
+_TN0, _TN2 = lib.Tuning(wgrad_streamk=0), lib.Tuning(wgrad_streamk=2)      # kept alive: ref() is the address
+SK = {1: _TN2.ref(), 0: _TN0.ref()}
 
 
 def timed(fn):
