@@ -449,6 +449,12 @@ class _Engine:
                                            and (WINOGRAD44 is True or blocks44 * (slab_ch // 64) >= ncu)
                                            and lib.clamd_winograd44_input_elems(B, u.h, u.w_, in_ch) * 4 < (1 << 32))
             u.f44 = u.pre_f and ok44(u.cout_p, u.cin_p)            # forward (and, with pre_w, the weight gradient: it reads the forward image)
+            # ... and the data gradients of the NARROW layers whose launch has at least 128 output (= this unit's input) channels: transform of
+            # the gradient + transform-free F(4x4) loop against the in-kernel-transform F(2x4) kernel, tools/wino44_narrow_ab.py: 64 -> 128
+            # @256x256 1.07x, 128 -> 128 @128x128 1.08x, 128 -> 256 @128x128 1.26x, 256 -> 128 @64x64 1.21x (128 -> 64 and 64 -> 64: 0.83-0.85x)
+            if (pt == 'auto' and not u.pre_d and u.w24d and not first_of_net and u.cin_p >= 128 and u.cout_p >= 64 and u.cin_p % 64 == 0
+                    and WINOGRAD44 and ok44(u.cin_p, u.cout_p)):
+                u.pre_d = True
             u.d44 = u.pre_d and ok44(u.cin_p, u.cout_p)            # data gradient
             if u.f44 and u.pre_w:
                 u.pre_w = lib.clamd_wgrad_winograd44_pre_operand_elems(B, u.h, u.w_, u.cout_p) * 4 // 36 < (1 << 32)
