@@ -139,6 +139,6 @@ def test_bench_single_gpu_line_carries_calibration_and_traffic_fields():
     assert r['bound'] == 'mfma' and r['peak'] == 157.3 and 0 < r['frac'] < 1
     assert 100 < r['sustained_mfma_tflops_measured'] < 160 and abs(r['frac_of_sustained'] - r['achieved'] / r['sustained_mfma_tflops_measured']) < 2e-3
     # 128 x 128 bs4 has no committed PMC profile: the traffic fields are there and empty, nothing is invented
-    assert d['hbm_bytes_per_step'] is None and d['algorithmic_bytes_per_step'] is None and d['hbm_over_algorithmic'] is None
+    assert 'hbm_kernels' in d and d['l2_fabric_bytes_per_step'] is None and d['algorithmic_bytes_per_step'] is None and d['fabric_over_algorithmic'] is None
     (a,) = d['also']
     assert a['dtype'] == 'bf16' and 1000 < a['mfma_sustained_tflops_measured'] < 2600 and 0 < a['conv3x3_igemm_frac_of_sustained'] < 1.2

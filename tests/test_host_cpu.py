@@ -303,13 +303,19 @@ def test_no_test_function_is_shadowed():
 
 
 def test_bench_step_traffic_reads_the_committed_profile():
-    """bench.py's driver line carries HBM bytes per step (committed PMC profile of the same workload) beside SURVEY §8d's algorithmic bytes."""
+    """bench.py's driver line carries the L2-fabric bytes per step (committed PMC profile of the same workload: everything that misses L2,
+    Infinity-Cache hits included) beside SURVEY 8d's algorithmic bytes, and HBM bytes as BOUNDS: no counter behind the Infinity Cache exists."""
     sys.path.insert(0, ROOT)
     import bench
     for dtype, e in (('fp32', 4), ('bf16', 2), ('bf16x3', 4)):
-        t = bench.step_traffic(dtype, 256, 16, 64)
+        t = bench.step_traffic(dtype, 256, 16, 64, conv_alg_bytes_per_step=6e9)
         assert t is not None and os.path.exists(os.path.join(ROOT, t['traffic_source']))
         assert t['algorithmic_bytes_per_step'] == int(16 * 250e6 * e + 31_044_821 * 28 + 3 * 31_044_821 * e)
-        assert abs(t['hbm_over_algorithmic'] - t['hbm_bytes_per_step'] / t['algorithmic_bytes_per_step']) < 1e-3
-        assert 1.0 < t['hbm_over_algorithmic'] < 6.0
+        assert abs(t['fabric_over_algorithmic'] - t['l2_fabric_bytes_per_step'] / t['algorithmic_bytes_per_step']) < 1e-3
+        assert 1.0 < t['fabric_over_algorithmic'] < 6.0
+        lo, hi = t['hbm_bytes_per_step_bounds']
+        assert 0 < lo <= hi == t['l2_fabric_bytes_per_step'] and t['mfma_kernels_fabric_bytes_per_step'] > 0
+        assert 'hbm_bytes_per_step' not in t            # the counters do not measure that
+    t512 = bench.step_traffic('bf16', 512, 32, 64)      # BASELINE configs[4] on one GPU (profiles/*traffic_bf16_512.json)
+    assert t512 is not None and 1.0 < t512['fabric_over_algorithmic'] < 6.0
     assert bench.step_traffic('fp32', 128, 16, 64) is None          # no profile of that workload: nothing invented

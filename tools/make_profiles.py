@@ -94,13 +94,13 @@ for dt in DT:
     rows = list(csv.DictReader(open(f'{P}/{dst}_{dt}_kernel_stats.csv')))
     tot = sum(float(x['TotalDurationNs']) for x in rows)
     tr = json.load(open(f'{P}/{dst}_traffic_{dt}.json'))
-    L.append(f"### {dt}: {tot / STEPS_PROF / 1e6:.2f} ms of GPU time per step, {tr['hbm_bytes_per_step_all_kernels'] / 1e9:.1f} GB of HBM traffic per step\n")
+    L.append(f"### {dt}: {tot / STEPS_PROF / 1e6:.2f} ms of GPU time per step, {tr['hbm_bytes_per_step_all_kernels'] / 1e9:.1f} GB of L2-fabric traffic per step (FETCH_SIZE x 2 + WRITE_SIZE: bytes that miss L2, Infinity-Cache hits included)\n")
     L.append('| % | avg µs | launches/step | kernel |\n|---|---|---|---|')
     for x in rows[:14]:
         name = x['Name'].replace('void ', '').replace('clamd::', '').split('(')[0]
         L.append(f"| {float(x['TotalDurationNs']) / tot * 100:.1f} | {float(x['AverageNs']) / 1e3:.1f} | {int(x['Calls']) / STEPS_PROF:.1f} | `{name}` |")
     L.append('')
-    L.append('HBM bytes per launch (PMC) of the dominant kernels:\n')
+    L.append('L2-fabric bytes per launch (PMC) of the dominant kernels:\n')
     L.append('| kernel | read MB | write MB | avg µs | GB/s |\n|---|---|---|---|---|')
     for k, v in list(tr['kernels'].items())[:8]:
         by = v['hbm_read_bytes_per_launch'] + v['hbm_write_bytes_per_launch']
