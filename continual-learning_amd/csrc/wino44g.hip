@@ -29,6 +29,16 @@
 
 namespace clamd {
 
+#ifdef CLAMD_DIAG
+// diagnostic build only (python build.py --diag; tools/w44_diag.py): cycles per phase of a tile, summed over workgroups (wave 0)
+__device__ unsigned long long g_w44_diag[8];
+#define W44_T() __builtin_amdgcn_s_memtime()
+#define W44_ADD(i_, v_) do { if (threadIdx.x == 0) atomicAdd(&g_w44_diag[i_], (unsigned long long)(v_)); } while (0)
+#else
+#define W44_T() 0ull
+#define W44_ADD(i_, v_) do { } while (0)
+#endif
+
 // B6^T of six values
 __device__ inline void w44_bt6(const float (&t)[6], float (&o)[6]) {
     const float pq = fmaf(-4.f, t[2], t[4]), qq = fmaf(-4.f, t[1], t[3]);
@@ -296,6 +306,7 @@ __global__ void __launch_bounds__(768, 1) wino44g_kernel(const WinoParams p) {
     for (int v = blockIdx.x; v < p.nblk; v += gridDim.x) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));                                        // per-tile re-derivation (hoisted constants would spill)
+        const unsigned long long dt0 = W44_T(); (void)dt0;
         const int lane = tid & 63;
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int wi = wv % 6, nt_w = wv / 6;                                 // this wave: Winograd row i, 32-channel half
@@ -335,6 +346,7 @@ __global__ void __launch_bounds__(768, 1) wino44g_kernel(const WinoParams p) {
                 asm volatile("" ::: "memory");                                 // ring order (see wino24g_wgrad_kernel)
             }
         }
+        const unsigned long long dt1 = W44_T(); (void)dt1;
         for (int k = 0; k < nk - 1; ++k) {
             // the fragments of plane j are refetched (chunk k + 1) behind the MFMAs of plane j + 1: their registers are free by then
 #pragma unroll
@@ -350,6 +362,8 @@ __global__ void __launch_bounds__(768, 1) wino44g_kernel(const WinoParams p) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) mma16<float>(A[j], Bq[j], acc[j]);        // last chunk: nothing to fetch yet (see the epilogue)
 
+        const unsigned long long dt2 = W44_T(); (void)dt2;
+        unsigned long long dph[5] = {0, 0, 0, 0, 0};
         // ---- epilogue: Y = A6^T M A6.  A6^T along the columns in-lane (j -> q), A6^T along the rows across the six waves of a
         // channel half through LDS; the two channel halves take the exchange block in turn --------------------------------------
         float* const ex = reinterpret_cast<float*>(smem);
@@ -372,6 +386,7 @@ __global__ void __launch_bounds__(768, 1) wino44g_kernel(const WinoParams p) {
                 }
             }
             __syncthreads();
+            dph[2 * nt + 1] = W44_T();
             if (nt == 1) {
                 // chunk 0 of this workgroup's next tile: requested here, where the accumulators of every wave are dead (144 of a wave's 168
                 // registers are accumulators and fragments in the K loop; the readers below need 60), it lands under the read-back,
@@ -433,7 +448,12 @@ __global__ void __launch_bounds__(768, 1) wino44g_kernel(const WinoParams p) {
                 }
             }
             __syncthreads();                                               // the exchange block is free again
+            dph[2 * nt + 2] = W44_T();
         }
+        // [0] setup + first loads  [1] K loop  [2] write 0 + barrier  [3] read 0 + barrier  [4] write 1 + barrier  [5] read 1 + barrier  [6] tiles  [7] chunks
+        W44_ADD(0, dt1 - dt0); W44_ADD(1, dt2 - dt1); W44_ADD(2, dph[1] - dt2); W44_ADD(3, dph[2] - dph[1]); W44_ADD(4, dph[3] - dph[2]);
+        W44_ADD(5, dph[4] - dph[3]); W44_ADD(6, 1); W44_ADD(7, nk);
+        (void)dph;
         if (rows_base) { cur_tn = tn; cur_tm = tm; }
     }
     if (cur_tn >= 0) fold_stats();
@@ -590,6 +610,14 @@ int launch_w24g_wgrad_sk(const float* yt, const float* v, float* workspace, size
 }  // namespace clamd
 
 extern "C" {
+
+#ifdef CLAMD_DIAG
+int clamd_debug_w44_diag(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(clamd::g_w44_diag), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(clamd::g_w44_diag), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 int clamd_wino44_pack(const void* jobs_dev, int njobs, int total_blocks, void* stream) {
     if (njobs <= 0 || total_blocks <= 0) return clamd_fail("wino44_pack: empty job table");

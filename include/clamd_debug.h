@@ -22,6 +22,7 @@ long long clamd_debug_mfma_rate(int dtype, int iters, float* sink_65536, void* s
  * library. */
 #ifdef CLAMD_DIAG
 int clamd_debug_w24_diag(unsigned long long* out8, int reset);
+int clamd_debug_w44_diag(unsigned long long* out8, int reset);
 int clamd_debug_ww_diag(unsigned long long* out4, int reset);
 int clamd_debug_ws_diag(unsigned long long* out8, int reset);
 int clamd_debug_pws_diag(unsigned long long* out8, int reset);
