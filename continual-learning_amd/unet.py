@@ -24,7 +24,7 @@ BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 # 'auto' = where that kernel is the persistent bf16 kernel (sums stay in registers across tiles, one flush per workgroup,
 # the saved activation is prefetched under the last K-step); True = everywhere the kernels support it (every dgrad
 # launch of the other kernels got 30-80 us slower than the 33-us reduce pass it replaced); False = never.
-FUSE_BN_SUMS = 'auto'
+FUSE_BN_SUMS = {'0': False, 'false': False, '1': True, 'true': True}.get(os.environ.get('CLAMD_FUSE_BN_SUMS', 'auto').lower(), 'auto')
 
 # fp32 path: forward and data gradient of the 3x3 convolutions by Winograd F(2x2,3x3) (csrc/wino.hip): 2.25x fewer MFMA
 # cycles, fp32 transforms (error vs fp64 3.5e-7 against 2.3e-7 for the direct sum).  False = direct implicit GEMM.

@@ -12,8 +12,9 @@ from continual_learning_amd import unet as U
 dtype, attr = sys.argv[1], sys.argv[2]
 vals = [eval(v) if v in ('True', 'False', 'None') or v.isdigit() else v for v in sys.argv[3:]]
 dev = torch.device('cuda', 0)
-x = torch.from_numpy(C.synth.images(1234, 16, 3, 256, 256)).to(dev)
-y = torch.from_numpy(C.synth.labels(1234, 16, 256, 256, 21)).to(dev)
+SIZE, BATCH = int(os.environ.get('STEP_AB_SIZE', '256')), int(os.environ.get('STEP_AB_BATCH', '16'))      # BASELINE configs[4]: 512, 32
+x = torch.from_numpy(C.synth.images(1234, BATCH, 3, SIZE, SIZE)).to(dev)
+y = torch.from_numpy(C.synth.labels(1234, BATCH, SIZE, SIZE, 21)).to(dev)
 crit = C.CrossEntropyLoss()
 runs = []
 tuning = attr.startswith('tuning:')
@@ -39,4 +40,4 @@ for rd in range(5):
         for _ in range(10): loss = step()
         torch.cuda.synchronize()
         best[str(v)] = min(best[str(v)], (time.perf_counter() - t0) / 10)
-print(dtype, attr, '  '.join(f'{k}: {t * 1e3:.3f} ms/step ({16 / t:.1f} img/s)' for k, t in best.items()), f'loss {float(loss.detach()):.4f}')
+print(dtype, f'{SIZE}x{SIZE} bs{BATCH}', attr, '  '.join(f'{k}: {t * 1e3:.3f} ms/step ({BATCH / t:.1f} img/s)' for k, t in best.items()), f'loss {float(loss.detach()):.4f}')
