@@ -869,6 +869,36 @@ def test_batchnorm_of_an_encoder_block_folded_into_both_readers(C, monkeypatch):
         assert torch.equal(m_on.predict(x), torch.max(lo_on, 1)[1])
 
 
+def test_winograd44_engine_paths_agree(C, monkeypatch):
+    """unet.WINOGRAD44 (round 5): the wide 3x3 layers -- forward, data gradient, weight gradient on the kept forward image, the BatchNorm folded
+    into the input transform -- and the narrow layers' data gradients by the pre-transformed F(4x4,3x3) kernels (csrc/wino44g.hip) instead of
+    F(2x4).  'auto' takes them only where a launch fills the chip (BASELINE configs[1]: the full-size golden tests run that); here they are
+    FORCED onto a small problem (conv_dim 64 at 64x64: 256- to 1024-channel layers at 16x16 down to 4x4, ragged tile blocks included) and
+    compared with the F(2x4) engine: loss to rounding, gradients to the conditioning floor, bit-reproducible over two steps, eval mode."""
+    from continual_learning_amd import unet as U
+    nc, cd, B, size = 6, 64, 2, 64
+    monkeypatch.setattr(U, 'WINOGRAD44', False)
+    ref = _one_step(C, 'fp32', nc, cd, B, size)
+    e0 = next(iter(ref[3]._engines.values()))
+    assert not any(u.f44 or u.d44 for u in e0.convs) and any(u.pre_f for u in e0.convs)
+    monkeypatch.setattr(U, 'WINOGRAD44', True)
+    one = _one_step(C, 'fp32', nc, cd, B, size)
+    eng = next(iter(one[3]._engines.values()))
+    # (at this size every data gradient has too few F(2x4) work items and runs F(2x2): the F(4x4) data gradients are exercised by the
+    # full-size golden tests and, kernel by kernel, by tests/test_wino44_gpu.py)
+    assert sum(u.f44 for u in eng.convs) >= 4 and any(u.f44 and u.pre_w for u in eng.convs), [(u.name, u.f44, u.d44, u.pre_w) for u in eng.convs]
+    assert any(u.apply_folded for u in eng.convs)                  # a BatchNorm applied by the F(4x4) input transform
+    assert abs(float(one[0]) - float(ref[0])) < 2e-6 * abs(float(ref[0])), (float(one[0]), float(ref[0]))
+    assert float((one[1] - ref[1]).norm() / ref[1].norm()) < 1e-2
+    a, a2 = _one_step(C, 'fp32', nc, cd, B, size, steps=2), _one_step(C, 'fp32', nc, cd, B, size, steps=2)
+    assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1]) and torch.equal(a[2], a2[2])
+    x = torch.from_numpy(C.synth.images(5, B, 3, size, size)).cuda()
+    m_on, m_off = a[3].eval(), ref[3].eval()
+    m_off.load_state_dict(m_on.state_dict())
+    with torch.no_grad():
+        assert rel_l2(m_on(x).cpu().numpy(), m_off(x).cpu().numpy()) < 2e-5
+
+
 def test_engine_buffers_are_released_with_the_model(C):
     """A model's engine (activations, gradients, workspaces: GBs at full size) must go when the model goes, by reference
     counting -- not whenever the cyclic garbage collector next runs (a trainer that rebuilds models, or begin_task2's
