@@ -991,6 +991,112 @@ __global__ void __launch_bounds__(256, 1) wino24g_wgrad_sk_kernel(const W24WgSkP
     }
 }
 
+// The same stream-K GEMM with the WAVE as the unit of work, for channel counts that are multiples of 128 but not of 256 (round 5: the
+// 128- / 256-channel layers at 128 x 128 and 64 x 64 -- dec4, enc2.block.4, enc3.block.1 -- whose weight gradients ran the in-kernel-transform
+// kernel at 0.42-0.50 of the pipe).  An item is a (plane, 128 x 128 block) wave tile; wave (4 wg + w) owns the global k-step range
+// [(4 wg + w) Q, ...) of the items laid end to end.  Nothing is shared between the waves of a workgroup (there never was a barrier in this
+// kernel), a wave's two loads per 16 MFMAs are 8 B per cycle and CU: panel sharing in L1 was never what it lived on.
+__global__ void __launch_bounds__(256, 1) wino24g_wgrad_skw_kernel(const W24WgSkParams p) {
+    int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i32 = lane & 31, h = lane >> 5;
+    const int rb_n = p.Rp >> 7, cb_n = p.Cp >> 7;
+    const int wvg = xcd_remap(blockIdx.x, gridDim.x) * 4 + w;
+    const long long total = (long long)p.nbp * p.S;
+    long long g = (long long)wvg * p.Q;
+    const long long g_end = min(g + (long long)p.Q, total);
+    const int nk = p.Cp >> 3;
+    const unsigned a_bytes = (unsigned)p.Tp * (unsigned)p.Rp * 4u;
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc(p.v, (unsigned)((size_t)(p.Tp >> 5) * nk * p.npl * 1024));
+    const __amdgpu_buffer_rsrc_t ars_dead = make_rsrc(p.yt, 0u), brs_dead = make_rsrc(p.v, 0u);
+    const unsigned a_step = (unsigned)p.Rp * 8u;                              // two tiles
+    const unsigned b_blk = (unsigned)nk * (unsigned)p.npl * 1024u;
+    while (g < g_end) {                                                       // wave-uniform
+        const int b = (int)(g / p.S);
+        const int kb = (int)(g - (long long)b * p.S);
+        const int ke = (int)min((long long)p.S, (long long)kb + (g_end - g));
+        const int cb = b % cb_n, rb = (b / cb_n) % rb_n, pl = b / (cb_n * rb_n);
+        const int r0 = rb * 128, c0 = cb * 128;
+        const __amdgpu_buffer_rsrc_t ars = make_rsrc((const char*)p.yt + (size_t)pl * a_bytes, a_bytes);
+        const unsigned a_vo = (unsigned)((h * p.Rp + r0 + 4 * i32) * 4);
+        const unsigned b_vo = (unsigned)(((c0 >> 3) + (i32 >> 1)) * p.npl * 1024 + (i32 & 1) * 512 + h * 16);
+        const unsigned b_pl = (unsigned)pl * 1024u;
+
+        f32x16 acc[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+        uint4 a[W24G_D], bq[W24G_D];
+        auto load = [&](int d, int s) {
+            const bool live = s < ke;
+            const unsigned t = (unsigned)(2 * s);
+            a[d] = buf_ld16(live ? ars : ars_dead, a_vo, (unsigned)s * a_step);
+            bq[d] = buf_ld16(live ? brs : brs_dead, b_vo, (t >> 5) * b_blk + b_pl + (t & 31u) * 16u);
+        };
+#pragma unroll
+        for (int d = 0; d < W24G_D; ++d) {
+            load(d, kb + d);
+            asm volatile("" ::: "memory");
+        }
+        for (int s0 = kb; s0 < ke; s0 += W24G_D) {
+#pragma unroll
+            for (int d = 0; d < W24G_D; ++d) {
+                const float am[4] = {__uint_as_float(a[d].x), __uint_as_float(a[d].y), __uint_as_float(a[d].z), __uint_as_float(a[d].w)};
+                const float bn[4] = {__uint_as_float(bq[d].x), __uint_as_float(bq[d].y), __uint_as_float(bq[d].z), __uint_as_float(bq[d].w)};
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(am[m], bn[n], acc[m][n], 0, 0, 0);
+                load(d, s0 + d + W24G_D);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            }
+        }
+        const int slot = wvg - (int)(((long long)b * p.S) / p.Q);
+        float* const out = p.partial + (((size_t)slot * p.npl + pl) * p.Rp) * (size_t)p.Cp;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = r0 + 4 * acc_row(e, h) + m;
+                *reinterpret_cast<float4*>(out + (size_t)row * p.Cp + c0 + 4 * i32) = make_float4(acc[m][0][e], acc[m][1][e], acc[m][2][e], acc[m][3][e]);
+            }
+        g += ke - kb;
+    }
+}
+
+// first reduce stage of the wave-level plan (an item there has tens of slots): thread = (plane, four consecutive (r, c) pairs) adds the
+// item's slots in slot order into reduced[plane][Rp][Cp]; wino_sk_reduce_kernel (S = Q = 1: one slot per item) then applies G^T . G
+struct W24SkwSumParams {
+    const float* partial; float* reduced;
+    int Rp, Cp, npl, S, Q;
+};
+
+__global__ void __launch_bounds__(256) wino_skw_sum_kernel(const W24SkwSumParams p) {
+    const long long nquad = (long long)p.Rp * p.Cp / 4;
+    const size_t plane_sz = (size_t)p.Rp * p.Cp, slot_sz = plane_sz * p.npl;
+    const int rb_n = p.Rp >> 7, cb_n = p.Cp >> 7;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nquad * p.npl; idx += (long long)gridDim.x * 256) {
+        const int pl = (int)(idx / nquad);
+        const long long quad = idx - (long long)pl * nquad;
+        const int rp = (int)((quad * 4) / p.Cp), cp0 = (int)((quad * 4) % p.Cp);
+        const long long b = ((long long)pl * rb_n + (rp >> 7)) * cb_n + (cp0 >> 7);
+        const int first = (int)((b * p.S) / p.Q), last = (int)(((b + 1) * p.S - 1) / p.Q);
+        const float* src = p.partial + (size_t)pl * plane_sz + (size_t)quad * 4;
+        float4 a = *reinterpret_cast<const float4*>(src);
+        for (int k = 1; k <= last - first; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * slot_sz);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        *reinterpret_cast<float4*>(p.reduced + (size_t)pl * plane_sz + (size_t)quad * 4) = a;
+    }
+}
+
 // out[rl][cl][3][3] = G^T (sum of an item's slots, in slot order) G for the stream-K slabs: NPL = 24: G4^T . G6 with the sign of plane row
 // 2 (wino24g_wgrad_reduce_kernel), NPL = 36: G6^T . G6.  A thread owns four consecutive (r, c) pairs of all NPL planes.
 struct W24SkReduceParams {
@@ -1144,6 +1250,43 @@ int launch_w24g_wgrad_sk(const float* yt, const float* v, float* workspace, size
     else hipLaunchKernelGGL(wino_sk_reduce_kernel<36>, dim3(g), dim3(256), 0, s, rp);
     return clamd_check_launch("wgrad_winograd_pre (stream-K reduce)");
 }
+// wave-level plan (channel counts that are multiples of 128): items = planes x (Rp/128) x (Cp/128) wave tiles, four waves per CU
+static void w24g_skw_plan(long long Tp, int Rp, int Cp, int planes, int cus, int* S, int* Q, int* nitems, int* nwg, int* max_slots) {
+    *S = (int)(Tp / 2);
+    *nitems = planes * (Rp / 128) * (Cp / 128);
+    const long long total = (long long)*nitems * *S, waves = 4LL * cus;
+    long long q = (total + waves - 1) / waves;
+    q = (q + W24G_D - 1) / W24G_D * W24G_D;
+    *Q = (int)q;
+    *nwg = (int)((((total + q - 1) / q) + 3) / 4);
+    *max_slots = (int)((*S + q - 1) / q) + 1;
+}
+size_t w24g_skw_workspace_bytes(long long Tp, int Rp, int Cp, int planes) {
+    int S, Q, ni, nwg, ms;
+    w24g_skw_plan(Tp, Rp, Cp, planes, clamd_num_cus(), &S, &Q, &ni, &nwg, &ms);
+    return (size_t)(ms + 1) * planes * Rp * Cp * sizeof(float);            // the slots + the reduced planes
+}
+int launch_w24g_wgrad_skw(const float* yt, const float* v, float* workspace, size_t ws_bytes, float* out, long long Tp, int Rp, int Cp, int planes,
+                          int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p, const clamd_tuning& tn, hipStream_t s) {
+    int S, Q, ni, nwg, ms;
+    w24g_skw_plan(Tp, Rp, Cp, planes, clamd_usable_cus(tn), &S, &Q, &ni, &nwg, &ms);
+    const size_t slot_floats = (size_t)planes * Rp * Cp;
+    if ((size_t)(ms + 1) * slot_floats * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd_pre: workspace too small");
+    W24WgSkParams p{yt, v, workspace, Rp, Cp, (int)Tp, planes, S, Q, ni};
+    hipLaunchKernelGGL(wino24g_wgrad_skw_kernel, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    if (int e = clamd_check_launch("wgrad_winograd_pre (wave-level stream-K plane GEMM)")) return e;
+    float* reduced = workspace + (size_t)ms * slot_floats;
+    W24SkwSumParams sp{workspace, reduced, Rp, Cp, planes, S, Q};
+    const long long nthr = (long long)Rp * Cp / 4 * planes;
+    hipLaunchKernelGGL(wino_skw_sum_kernel, dim3((unsigned)std::min<long long>((nthr + 255) / 256, 16384)), dim3(256), 0, s, sp);
+    if (int e = clamd_check_launch("wgrad_winograd_pre (slot sum)")) return e;
+    W24SkReduceParams rp{reduced, out, Rp, Cp, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p, 1, 1};
+    const long long nquad = (long long)Rp * Cp / 4;
+    const unsigned g = (unsigned)std::min<long long>((nquad + 255) / 256, 8192);
+    if (planes == 24) hipLaunchKernelGGL(wino_sk_reduce_kernel<24>, dim3(g), dim3(256), 0, s, rp);
+    else hipLaunchKernelGGL(wino_sk_reduce_kernel<36>, dim3(g), dim3(256), 0, s, rp);
+    return clamd_check_launch("wgrad_winograd_pre (G^T . G)");
+}
 }  // namespace clamd
 static int w24g_wg_plan(long long Tp, int Rp, int Cp, const clamd_tuning& tn, int* per_out) { return clamd::w24g_wg_plan_planes(Tp, Rp, Cp, 24, tn, per_out); }
 
@@ -1243,8 +1386,9 @@ size_t clamd_wgrad_winograd24_pre_operand_elems(int B, int H, int W, int Rp) {
 }
 
 size_t clamd_wgrad_winograd24_pre_workspace_bytes(int B, int H, int W, int Rp, int Cp) {
-    if (B <= 0 || H <= 0 || W <= 0 || Rp < 256 || Cp < 256) return 0;
+    if (B <= 0 || H <= 0 || W <= 0 || Rp < 128 || Cp < 128) return 0;
     const long long Tp = w24g_tiles(B, H, W) * 32;
+    if ((Rp % 256) || (Cp % 256)) return clamd::w24g_skw_workspace_bytes(Tp, Rp, Cp, 24);      // multiples of 128: the wave-level plan
     const long long nb = 24LL * (Rp / 256) * (Cp / 256);
     const long long max_split = std::max<long long>(1, std::min<long long>((3LL * clamd_num_cus()) / nb, Tp / (2 * W24G_D)));
     return std::max((size_t)max_split * 24 * Rp * Cp * sizeof(float), clamd::w24g_sk_workspace_bytes(Tp, Rp, Cp, 24));
@@ -1256,17 +1400,18 @@ int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, floa
     if (int e = clamd_check_tuning(tune)) return e;
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("wgrad_winograd24_pre: empty problem");
     if ((H & 1) || (W & 3)) return clamd_fail("wgrad_winograd24_pre: H must be even and W a multiple of 4");
-    if (Rp % 256 || Cp % 256 || Rp <= 0 || Cp <= 0 || gz_ldc % 4) return clamd_fail("wgrad_winograd24_pre: needs Rp and Cp multiples of 256");
+    if (Rp % 128 || Cp % 128 || Rp <= 0 || Cp <= 0 || gz_ldc % 4) return clamd_fail("wgrad_winograd24_pre: needs Rp and Cp multiples of 128");
+    const bool wave_level = (Rp % 256) || (Cp % 256);          // a wave owns a 128 x 128 block; 256 x 256 workgroup blocks where both counts allow
     if (gz && (long long)H * W * gz_ldc * 4 >= (1ll << 31)) return clamd_fail("wgrad_winograd24_pre: one image exceeds 2^31 bytes");
     const clamd_tuning& tn = clamd_tune(tune);
     const long long ntm = w24g_tiles(B, H, W), Tp = ntm * 32;
     if (Tp * Rp * 4 >= (1ll << 32) || (unsigned long long)ntm * (Cp / 8) * 24 * 1024 >= (1ull << 32))
         return clamd_fail("wgrad_winograd24_pre: an operand exceeds 2^32 bytes");
     int per = 0;
-    const int nsplit = w24g_wg_plan(Tp, Rp, Cp, tn, &per);
+    const int nsplit = wave_level ? 1 : w24g_wg_plan(Tp, Rp, Cp, tn, &per);
     // stream-K where the items alone nearly fill the chip (an item then gets 2-3 slots); with fewer, larger items the split-K plan's
     // whole rounds are as even and its slabs are fewer (tools/wino44g_ab.py: 1.10-1.21x faster from 96 items on, 0.78-0.95x below)
-    const bool streamk = tn.wgrad_streamk == 2 || (tn.wgrad_streamk == 1 && (long long)24 * (Rp / 256) * (Cp / 256) * 8 >= 3LL * clamd_usable_cus(tn));
+    const bool streamk = wave_level || tn.wgrad_streamk == 2 || (tn.wgrad_streamk == 1 && (long long)24 * (Rp / 256) * (Cp / 256) * 8 >= 3LL * clamd_usable_cus(tn));
     if (!streamk && (size_t)nsplit * 24 * Rp * Cp * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd24_pre: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     if (gz) {                                  // gz == NULL: yt already holds the transformed gradient (clamd_wgrad_winograd24_pre_transform)
@@ -1277,6 +1422,8 @@ int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, floa
         else hipLaunchKernelGGL(wino24g_wgrad_xform_kernel<4>, dim3(g), dim3(256), 0, s, pa);
         if (int e = clamd_check_launch("wgrad_winograd24_pre transform")) return e;
     }
+    if (wave_level)
+        return launch_w24g_wgrad_skw(yt, v, workspace, ws_bytes, out, Tp, Rp, Cp, 24, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p, tn, s);
     if (streamk)
         return launch_w24g_wgrad_sk(yt, v, workspace, ws_bytes, out, Tp, Rp, Cp, 24, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p, tn, s);
     if (int e = launch_w24g_wgrad_gemm(yt, v, workspace, Rp, Cp, Tp, nsplit, per, 24, s)) return e;

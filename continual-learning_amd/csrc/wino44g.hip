@@ -605,6 +605,9 @@ int w24g_wg_plan_planes(long long Tp, int Rp, int Cp, int planes, const clamd_tu
 long long w24g_wg_max_split(long long Tp, int Rp, int Cp, int planes);
 int launch_w24g_wgrad_gemm(const float* yt, const float* v, float* partial, int Rp, int Cp, long long Tp, int nsplit, int per, int planes, hipStream_t s);
 size_t w24g_sk_workspace_bytes(long long Tp, int Rp, int Cp, int planes);
+size_t w24g_skw_workspace_bytes(long long Tp, int Rp, int Cp, int planes);
+int launch_w24g_wgrad_skw(const float* yt, const float* v, float* workspace, size_t ws_bytes, float* out, long long Tp, int Rp, int Cp, int planes,
+                          int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p, const clamd_tuning& tn, hipStream_t s);
 int launch_w24g_wgrad_sk(const float* yt, const float* v, float* workspace, size_t ws_bytes, float* out, long long Tp, int Rp, int Cp, int planes,
                          int R, int C, int r_seg0, int r_seg0p, int c_seg0, int c_seg0p, const clamd_tuning& tn, hipStream_t s);
 }  // namespace clamd
@@ -695,8 +698,9 @@ size_t clamd_wgrad_winograd44_pre_operand_elems(int B, int H, int W, int Rp) {
 }
 
 size_t clamd_wgrad_winograd44_pre_workspace_bytes(int B, int H, int W, int Rp, int Cp) {
-    if (B <= 0 || H <= 0 || W <= 0 || Rp < 256 || Cp < 256) return 0;
+    if (B <= 0 || H <= 0 || W <= 0 || Rp < 128 || Cp < 128) return 0;
     const long long Tp = w44_blocks(B, H, W) * 32;
+    if ((Rp % 256) || (Cp % 256)) return w24g_skw_workspace_bytes(Tp, Rp, Cp, 36);      // multiples of 128: the wave-level plan
     return std::max((size_t)w24g_wg_max_split(Tp, Rp, Cp, 36) * 36 * Rp * Cp * sizeof(float), w24g_sk_workspace_bytes(Tp, Rp, Cp, 36));
 }
 
@@ -715,21 +719,24 @@ int clamd_wgrad_winograd44_pre(const float* gz, int gz_ldc, const float* v, floa
     if (int e = clamd_check_tuning(tune)) return e;
     if (B <= 0 || H <= 0 || W <= 0) return clamd_fail("wgrad_winograd44_pre: empty problem");
     if ((H & 3) || (W & 3)) return clamd_fail("wgrad_winograd44_pre: H and W must be multiples of 4");
-    if (Rp % 256 || Cp % 256 || Rp <= 0 || Cp <= 0 || gz_ldc % 4) return clamd_fail("wgrad_winograd44_pre: needs Rp and Cp multiples of 256");
+    if (Rp % 128 || Cp % 128 || Rp <= 0 || Cp <= 0 || gz_ldc % 4) return clamd_fail("wgrad_winograd44_pre: needs Rp and Cp multiples of 128");
+    const bool wave_level = (Rp % 256) || (Cp % 256);          // a wave owns a 128 x 128 block; 256 x 256 workgroup blocks where both counts allow
     if (gz && (long long)H * W * gz_ldc * 4 >= (1ll << 31)) return clamd_fail("wgrad_winograd44_pre: one image exceeds 2^31 bytes");
     const clamd_tuning& tn = clamd_tune(tune);
     const long long ntm = w44_blocks(B, H, W), Tp = ntm * 32;
     if (Tp * Rp * 4 >= (1ll << 32) || (unsigned long long)ntm * (Cp / 8) * 36 * 1024 >= (1ull << 32))
         return clamd_fail("wgrad_winograd44_pre: an operand exceeds 2^32 bytes");
     int per = 0;
-    const int nsplit = w24g_wg_plan_planes(Tp, Rp, Cp, 36, tn, &per);
+    const int nsplit = wave_level ? 1 : w24g_wg_plan_planes(Tp, Rp, Cp, 36, tn, &per);
     // stream-K where the items alone nearly fill the chip (an item then gets 2-3 slots); with fewer, larger items the split-K plan's
     // whole rounds are as even and its slabs are fewer (tools/wino44g_ab.py: 1.10-1.21x faster from 96 items on, 0.78-0.95x below)
-    const bool streamk = tn.wgrad_streamk == 2 || (tn.wgrad_streamk == 1 && (long long)36 * (Rp / 256) * (Cp / 256) * 8 >= 3LL * clamd_usable_cus(tn));
+    const bool streamk = wave_level || tn.wgrad_streamk == 2 || (tn.wgrad_streamk == 1 && (long long)36 * (Rp / 256) * (Cp / 256) * 8 >= 3LL * clamd_usable_cus(tn));
     if (!streamk && (size_t)nsplit * 36 * Rp * Cp * sizeof(float) > ws_bytes) return clamd_fail("wgrad_winograd44_pre: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     if (gz)                                    // gz == NULL: yt already holds the transformed gradient (clamd_wgrad_winograd44_pre_transform)
         if (int e = w44_launch_yt(gz, gz_ldc, yt, B, H, W, Rp, Tp, s)) return e;
+    if (wave_level)
+        return launch_w24g_wgrad_skw(yt, v, workspace, ws_bytes, out, Tp, Rp, Cp, 36, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p, tn, s);
     if (streamk)
         return launch_w24g_wgrad_sk(yt, v, workspace, ws_bytes, out, Tp, Rp, Cp, 36, R, C, r_seg0, r_seg0p, c_seg0, c_seg0p, tn, s);
     if (int e = launch_w24g_wgrad_gemm(yt, v, workspace, Rp, Cp, Tp, nsplit, per, 36, s)) return e;

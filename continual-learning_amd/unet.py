@@ -53,6 +53,8 @@ WINOGRAD44 = {'0': False, 'false': False, '1': True, 'true': True}.get(str(WINOG
 # BatchNorm output (the first unit of enc3/enc4/dec1/dec2/dec3): one HBM pass less per unit.  False = always run clamd_bn_apply.
 FOLD_BN_INTO_TRANSFORM = os.environ.get('CLAMD_FOLD_BN', '1') != '0'
 NARROW_DIRECT = os.environ.get('CLAMD_NARROW_DIRECT', '1') != '0'
+WGRAD_TAIL_EARLY = os.environ.get('CLAMD_WGRAD_TAIL_EARLY', '1') != '0'      # see _Engine._conv_bwd
+NARROW_PRE_WGRAD = os.environ.get('CLAMD_NARROW_PRE_WGRAD', '1') != '0'      # the 128-channel layers pre-transformed (forward + weight gradient), see _Engine
 # The narrow layers (in-kernel transform / bf16 direct kernels) cannot take the affine on load -- their loops are VALU-bound -- so there
 # the BatchNorm between the two convolutions of a block (models/unet.py:13-18) is folded ALGEBRAICALLY into the second one
 # (csrc/bnfold.hip): filters packed with scale[ci] once the statistics are final, the shift as a border-class bias table in the
@@ -433,6 +435,12 @@ class _Engine:
             # with Cin x Cout: 512 -> 256 @64x64 loses 6 %, 256 -> 128 @128x128 26 %, tools/wino24g_ab.py).  Data gradient: the
             # same with the roles of the channel counts exchanged; the transformed gradient is used once and not kept.
             pt = PRETRANSFORM
+            # F(4x4,3x3) applies where the launch fills the chip with (16x32-pixel tile block, 64-channel slab) work items (WINOGRAD44)
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == 'cuda' else 256
+            blocks44 = B * u.h * u.w_ // 512                       # FULL tile blocks (a 16x16 image fills half of a 32x16 block)
+            ok44 = lambda slab_ch, in_ch: (bool(WINOGRAD44) and u.h % 4 == 0 and u.w_ % 4 == 0 and slab_ch % 64 == 0
+                                           and (WINOGRAD44 is True or blocks44 * (slab_ch // 64) >= ncu)
+                                           and lib.clamd_winograd44_input_elems(B, u.h, u.w_, in_ch) * 4 < (1 << 32))
             u.pre_w = bool(pt) and u.w24 and u.cin_p % 256 == 0 and u.cout_p % 256 == 0
             u.pre_f = bool(pt) and u.w24 and u.cin_p >= 64 and u.cout_p % 64 == 0 and (
                 pt is True or (u.cin_p >= 256 and (u.pre_w or 2 * u.cout_p > u.cin_p)) or (u.cin_p >= 128 and u.cout_p >= 2 * u.cin_p))
@@ -442,12 +450,13 @@ class _Engine:
             u.pre_w = u.pre_w and u.pre_f and lib.clamd_wgrad_winograd24_pre_operand_elems(B, u.h, u.w_, u.cout_p) * 4 // 24 < (1 << 32)
             u.pre_d = bool(pt) and u.w24d and not first_of_net and u.cout_p >= 64 and u.cin_p % 64 == 0 and fits(u.cout_p) and (
                 pt is True or (u.cout_p >= 256 and (2 * u.cin_p > u.cout_p or (2 * u.cin_p == u.cout_p and u.cin_p >= 256))))
-            # ... by F(4x4,3x3) where the launch fills the chip with (16x32-pixel tile block, 64-channel slab) work items (WINOGRAD44)
-            ncu = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == 'cuda' else 256
-            blocks44 = B * u.h * u.w_ // 512                       # FULL tile blocks (a 16x16 image fills half of a 32x16 block)
-            ok44 = lambda slab_ch, in_ch: (bool(WINOGRAD44) and u.h % 4 == 0 and u.w_ % 4 == 0 and slab_ch % 64 == 0
-                                           and (WINOGRAD44 is True or blocks44 * (slab_ch // 64) >= ncu)
-                                           and lib.clamd_winograd44_input_elems(B, u.h, u.w_, in_ch) * 4 < (1 << 32))
+            # ... the 128-channel layers too (round 5: enc2.block.4, enc3.block.1, dec4 at config 2): their weight gradients ran the
+            # in-kernel-transform kernel at 0.42-0.50 of the pipe; with channel counts that are multiples of 128 the plane GEMM runs them as
+            # 128 x 128 wave tiles (wave-level stream-K) on the forward image, so forward AND weight gradient go pre-transformed F(4x4) and the
+            # BatchNorm in front is applied by the transform (FOLD_BN_INTO_TRANSFORM) instead of by folded filters and a border-class table
+            if (pt == 'auto' and WINOGRAD44 and u.w24 and not (u.pre_f and u.pre_w) and min(u.cin_p, u.cout_p) >= 128
+                    and u.cin_p % 128 == 0 and u.cout_p % 128 == 0 and ok44(u.cout_p, u.cin_p) and NARROW_PRE_WGRAD):
+                u.pre_f = u.pre_w = True
             u.f44 = u.pre_f and ok44(u.cout_p, u.cin_p)            # forward (and, with pre_w, the weight gradient: it reads the forward image)
             # ... and the data gradients of the NARROW layers whose launch has at least 128 output (= this unit's input) channels: transform of
             # the gradient + transform-free F(4x4) loop against the in-kernel-transform F(2x4) kernel, tools/wino44_narrow_ab.py: 64 -> 128
@@ -1162,8 +1171,14 @@ class _Engine:
         # passes (tools/trace_gaps.py: 1.80 instead of 2.16 ms per fp32 step without an MFMA kernel).  A/B in one process:
         # bf16 +0.7 %, bf16x3 +1.0 %, fp32 unchanged (the kernels that share the chip with the passes run that much longer).
         # The issue ORDER of the two launches alone makes no difference.
+        # ... except for the LAST weight gradients of the backward pass (the level-0 encoder block: nothing of the critical chain is left to run
+        # beside them, the step ends with the main stream waiting for the second one -- 249 us in the r05h trace): those start as soon as
+        # their gradient is ready, beside their own unit's data gradient
+        early = WGRAD_TAIL_EARLY and self.dcode != _lib.BF16 and u.level == 0 and u.name.startswith('enc1')      # (bf16: 6.418 against 6.397 ms: off)
+        sw = self._wg_stream_ptr() if early else None
         dgrad()
-        sw = self._wg_stream_ptr()
+        if sw is None:
+            sw = self._wg_stream_ptr()
         if two:      # off the critical chain: the fixed-order sum of the apply pass's rows, in front of this unit's weight gradient
             call('clamd_rows_sum', ptr(u.gz_rows), u.gz_nrows, g[u.keys[1]], u.cout_p, u.cout, sw)
         if u.im2col:

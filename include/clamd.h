@@ -188,7 +188,8 @@ int clamd_conv3x3_winograd24_direct_filters(const float* x, int x_ldc, const flo
  * read in place as the x-side operand), yt = caller-provided scratch of clamd_wgrad_winograd24_pre_operand_elems(B,H,W,Rp)
  * floats for A4 dY A6^T of gz ([24][tiles][Rp], written here).  Every wave owns a 128 x 128 block of one plane (16 MFMAs per
  * two 16-byte loads, no LDS); split-K slabs in `workspace` (>= clamd_wgrad_winograd24_pre_workspace_bytes), fixed-order
- * reduce with G4^T . G6: deterministic.  Rp and Cp multiples of 256; other arguments as clamd_wgrad_winograd24. */
+ * reduce with G4^T . G6: deterministic.  Rp and Cp multiples of 128 (round 5; multiples of 256 before); other arguments as
+ * clamd_wgrad_winograd24. */
 size_t clamd_wgrad_winograd24_pre_operand_elems(int B, int H, int W, int Rp);
 /* the gradient-side transform alone (a caller with several streams can run it beside another launch's GEMM); clamd_wgrad_winograd24_pre
  * with gz == NULL then takes yt as already transformed */
@@ -209,7 +210,8 @@ int clamd_wgrad_winograd24_pre(const float* gz, int gz_ldc, const float* v, floa
  *                                       statistics rows (stat_rows = clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD44, ...)); Cout_p % 64 == 0
  *   clamd_wgrad_winograd44_pre[_transform|_operand_elems|_workspace_bytes]   weight gradient as the batched plane GEMM of
  *                                       clamd_wgrad_winograd24_pre over 36 planes: v = the kept forward image, yt = A6 dY A6^T scratch,
- *                                       fixed-order reduce with G6^T . G6 (deterministic); Rp, Cp multiples of 256 */
+ *                                       fixed-order reduce with G6^T . G6 (deterministic); Rp, Cp multiples of 128 (256 x 256 workgroup blocks where both are
+ *                                       multiples of 256, 128 x 128 wave blocks dealt k-step by k-step otherwise) */
 int clamd_wino44_pack(const void* jobs_dev, int njobs, int total_blocks, void* stream);
 size_t clamd_winograd44_input_elems(int B, int H, int W, int Cp);
 int clamd_winograd44_transform_input(const float* x, int x_ldc, const float* scale, const float* shift, float* v, int B, int H, int W,

@@ -823,6 +823,8 @@ W24G_WGRAD_SHAPES = [  # B, Cin segs, Cout, H, W (Cin_p, Cout_p multiples of 256
     (1, [(100, 256), (130, 256)], 200, 12, 20),      # concat input with padding, padded output channels, ragged 16x16 tile blocks
     (3, [(256, 256)], 512, 32, 32),                  # several splits
     (2, [(256, 256)], 256, 20, 72),                  # ragged 8x32 tile blocks in both directions
+    (2, [(128, 128)], 128, 16, 32),                  # multiples of 128 (round 5): the wave-level stream-K plan
+    (1, [(60, 64), (50, 64)], 200, 24, 40),          # 256 x 128 with a concat input, padding on both sides
 ]
 
 
@@ -837,7 +839,7 @@ def test_wgrad_winograd24_pretransformed(C, shape):
     x = rnd(rng, B, cin, H, W)
     w = rnd(rng, cout, cin, 3, 3) * (1.0 / np.sqrt(9 * cin))
     gz = rnd(rng, B, cout, H, W)
-    cin_p, cout_p = sum(s[1] for s in segs), (cout + 255) // 256 * 256
+    cin_p, cout_p = sum(s[1] for s in segs), (cout + 127) // 128 * 128
     xt = nhwc_with_segs(C, x, segs, 0)
     gzt = C.ops.to_nhwc(dev(gz), 0, cp=cout_p)
     lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()

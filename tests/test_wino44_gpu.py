@@ -115,6 +115,9 @@ W44_WGRAD_SHAPES = [  # B, Cin segs, Cout, H, W (Cin_p, Cout_p multiples of 256)
     (1, [(100, 256), (130, 256)], 200, 12, 20),      # concat input with padding, padded output channels, ragged narrow blocks
     (3, [(256, 256)], 512, 32, 32),                  # several splits
     (2, [(256, 256)], 256, 20, 72),                  # ragged wide blocks in both directions
+    (2, [(128, 128)], 128, 16, 32),                  # multiples of 128: the wave-level stream-K plan (one 128 x 128 wave tile per plane)
+    (3, [(256, 256)], 128, 32, 32),                  # 128 x 256: two wave tiles per plane
+    (1, [(60, 64), (50, 64)], 200, 24, 40),          # 256 x 128 with a concat input, padding on both sides, ragged blocks
 ]
 
 
@@ -129,7 +132,7 @@ def test_wgrad_winograd44_pretransformed(C, shape):
     x = rnd(rng, B, cin, H, W)
     w = rnd(rng, cout, cin, 3, 3) * (1.0 / np.sqrt(9 * cin))
     gz = rnd(rng, B, cout, H, W)
-    cin_p, cout_p = sum(s[1] for s in segs), (cout + 255) // 256 * 256
+    cin_p, cout_p = sum(s[1] for s in segs), (cout + 127) // 128 * 128
     xt = nhwc_with_segs(C, x, segs, 0)
     gzt = C.ops.to_nhwc(dev(gz), 0, cp=cout_p)
     lib, ptr, s = C._lib, C._lib.ptr, C._lib.stream_ptr()

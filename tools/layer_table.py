@@ -43,6 +43,8 @@ for _ in range(3):
     torch.cuda.synchronize()
     U.KERNEL_TIMING = None
     for tag, flops, e0, e1, nbytes, unit, frac in ev:
+        if tag.startswith('hbm:'):              # the HBM-bound families bench.py reports as `hbm_kernels`: not rows of this table
+            continue
         xf = tag == 'wino_transform'            # the input transform of a pre-transformed launch: its own (HBM-bound) row
         a = acc.setdefault(unit + (' xform' if xf else ''), [0.0, nbytes if xf else flops, 0, frac])
         a[0] += e0.elapsed_time(e1) * 1e-3
