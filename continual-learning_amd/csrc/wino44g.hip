@@ -251,7 +251,8 @@ __global__ void __launch_bounds__(768, 1) wino44g_kernel(const WinoParams p) {
         for (int i = 0; i < 4; ++i) sacc[i * 512 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     int cur_tn = -1, cur_tm = 0;
-    auto fold_stats = [&]() {         // every thread of the workgroup; the exchange block must be free
+    auto fold_stats = [&]() {         // every thread of the workgroup
+        __syncthreads();              // the readers of the last tile's second half are done with the exchange block (no barrier behind that phase)
         float* sb = reinterpret_cast<float*>(smem);                            // [reader wave 0..7][2][64]
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         if (w < 8) {
@@ -371,40 +372,52 @@ __global__ void __launch_bounds__(768, 1) wino44g_kernel(const WinoParams p) {
         const float relu_lo = p.relu ? 0.f : -__builtin_inff();
         const bool plain = !p.relu && !p.bias && !p.stats;
         const int oty = tl / TXN, otx = tl % TXN;
+        // the in-lane half of the output transform for EVERY wave first: 96 accumulators become 64 values, so that the waves of the second
+        // channel half can read back the first half's block without spilling (with the accumulators alive across that phase every output store
+        // was followed by a spill reload and `s_waitcnt vmcnt(0)`: the reader stood behind each of its eight stores -- 8.9 k cycles per phase)
+        // The barrier that frees the exchange block for THIS tile's first write sits here, behind the K loop, not behind the previous tile's
+        // last read-back: a wave that is done reading (or stands at the issue of its output stores: 131 KB per CU and tile, every CU at the same
+        // moment -- the stores take 9 k cycles to issue, ablation builds -DW44_ABLATE_ST) goes straight on into the next tile's K loop, and the
+        // store drain runs under the MFMAs of whichever waves of the SIMD are already there.  Waiting here costs nothing: the waves finish their K
+        // loops a third of the phase apart (oldest first) and waited at the next barrier anyway.
+        __syncthreads();
+        float4 bias_a = make_float4(0.f, 0.f, 0.f, 0.f), bias_b = bias_a;      // the reader's bias of either channel half (4 ng .. 4 ng + 3)
+        if (p.bias && tid < 512) {
+            bias_a = *reinterpret_cast<const float4*>(p.bias + n0 + 4 * ng);
+            bias_b = *reinterpret_cast<const float4*>(p.bias + n0 + 32 + 4 * ng);
+        }
+        float tq[4][16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
+            const float sa = m1 + m2, sb = m1 - m2, sc = m3 + m4, sd = m3 - m4;
+            tq[0][e] = m0 + sa + sc;
+            tq[1][e] = fmaf(2.f, sd, sb);
+            tq[2][e] = fmaf(4.f, sc, sa);
+            tq[3][e] = fmaf(8.f, sd, sb) + m5;
+        }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             if (nt_w == nt) {                                                  // wave-uniform
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float m0 = acc[0][e], m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e];
-                    const float sa = m1 + m2, sb = m1 - m2, sc = m3 + m4, sd = m3 - m4;
                     const int row = acc_row(e, h);
-                    ex[((wi * 4 + 0) * 32 + row) * W44_EXP + r] = m0 + sa + sc;
-                    ex[((wi * 4 + 1) * 32 + row) * W44_EXP + r] = fmaf(2.f, sd, sb);
-                    ex[((wi * 4 + 2) * 32 + row) * W44_EXP + r] = fmaf(4.f, sc, sa);
-                    ex[((wi * 4 + 3) * 32 + row) * W44_EXP + r] = fmaf(8.f, sd, sb) + m5;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ex[((wi * 4 + q) * 32 + row) * W44_EXP + r] = tq[q][e];
                 }
             }
             __syncthreads();
             dph[2 * nt + 1] = W44_T();
-            if (nt == 1) {
-                // chunk 0 of this workgroup's next tile: requested here, where the accumulators of every wave are dead (144 of a wave's 168
-                // registers are accumulators and fragments in the K loop; the readers below need 60), it lands under the read-back,
-                // row transform and stores of the second channel half.  An empty descriptor behind the last tile: zeros, no traffic --
-                // the registers are redefined on every path
-                const __amdgpu_buffer_rsrc_t vr = has_next ? vrs : vrs_dead, ur = has_next ? wrs : wrs_dead;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    load_j(j, vr, ur, vb_nxt, ub_nxt, 0);
-                    asm volatile("" ::: "memory");
-                }
-                pre = has_next;
+            if (nt == 0) {
+                // both bias vectors have arrived by now; taking them HERE keeps the second phase from waiting for them behind the first phase's
+                // output stores (loads and stores share one in-order counter: `s_waitcnt vmcnt(12)` in phase 1 stood for the store drain, 6 k cycles)
+                asm volatile("" : "+v"(bias_a.x), "+v"(bias_a.y), "+v"(bias_a.z), "+v"(bias_a.w), "+v"(bias_b.x), "+v"(bias_b.y), "+v"(bias_b.z), "+v"(bias_b.w));
             }
             if (tid < 512) {
                 const int n = n0 + 32 * nt + 4 * ng;
-                float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+                const float4 bias4 = nt ? bias_b : bias_a;                 // loaded behind the K loop: no memory latency inside the phase
                 float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+                float4 outv[2][4];                                         // the phase's eight outputs: stored LAST, behind the LDS traffic
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
                     const int q = 2 * qh + qq;
@@ -428,16 +441,14 @@ __global__ void __launch_bounds__(768, 1) wino44g_kernel(const WinoParams p) {
                         if (!plain) {
                             oo.x = fmaxf(oo.x + bias4.x, relu_lo); oo.y = fmaxf(oo.y + bias4.y, relu_lo);
                             oo.z = fmaxf(oo.z + bias4.z, relu_lo); oo.w = fmaxf(oo.w + bias4.w, relu_lo);
-                        }
-                        const int yy = y0 + 4 * oty + pp, xx = x0 + 4 * otx + q;
-                        if (!RAGGED || (yy < p.H && xx < p.W)) {
-                            *reinterpret_cast<float4*>(p.y + (((size_t)b * p.H + yy) * p.W + xx) * p.y_ldc + n) = oo;
-                            if (!plain) {
+                            const int yy = y0 + 4 * oty + pp, xx = x0 + 4 * otx + q;
+                            if (!RAGGED || (yy < p.H && xx < p.W)) {
                                 s1[0] += oo.x; s1[1] += oo.y; s1[2] += oo.z; s1[3] += oo.w;
                                 s2[0] = fmaf(oo.x, oo.x, s2[0]); s2[1] = fmaf(oo.y, oo.y, s2[1]);
                                 s2[2] = fmaf(oo.z, oo.z, s2[2]); s2[3] = fmaf(oo.w, oo.w, s2[3]);
                             }
                         }
+                        outv[qq][pp] = oo;
                     }
                 }
                 if (p.stats) {                                             // running sums of this thread: tile after tile, in a fixed order
@@ -446,8 +457,39 @@ __global__ void __launch_bounds__(768, 1) wino44g_kernel(const WinoParams p) {
                     q.x += s2[0]; q.y += s2[1]; q.z += s2[2]; q.w += s2[3];
                     sacc[(nt * 2 + 0) * 512 + tid] = a; sacc[(nt * 2 + 1) * 512 + tid] = q;
                 }
+                // one descriptor per image, the pixel part of the address from scalar strides: a store costs two VALU, not a 64-bit multiply-add chain
+                const unsigned img_bytes = (unsigned)p.H * (unsigned)p.W * (unsigned)p.y_ldc * 4u;
+                const __amdgpu_buffer_rsrc_t yrs = make_rsrc((const char*)p.y + (size_t)b * img_bytes, img_bytes);
+                const unsigned row_b = (unsigned)p.W * (unsigned)p.y_ldc * 4u, pix_b = (unsigned)p.y_ldc * 4u;
+                const unsigned vo0 = (unsigned)(y0 + 4 * oty) * row_b + (unsigned)(x0 + 4 * otx + 2 * qh) * pix_b + (unsigned)n * 4u;
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) {
+                        const int yy = y0 + 4 * oty + pp, xx = x0 + 4 * otx + 2 * qh + qq;
+                        const unsigned vo = (!RAGGED || (yy < p.H && xx < p.W)) ? vo0 + pp * row_b + qq * pix_b : BUF_OOB;
+                        const float4 oo = outv[qq][pp];
+#ifdef W44_ABLATE_ST            // timing ablation (variant builds only): no output stores in phase W44_ABLATE_ST - 1
+                        if (nt != W44_ABLATE_ST - 1)
+#endif
+                        buf_st16(yrs, vo, 0u, make_uint4(__float_as_uint(oo.x), __float_as_uint(oo.y), __float_as_uint(oo.z), __float_as_uint(oo.w)));
+                    }
             }
-            __syncthreads();                                               // the exchange block is free again
+            if (nt == 1) {
+                // chunk 0 of this workgroup's next tile: requested here -- BEHIND the read-back of the second half (in front of it, the 144 KB of requests of the twelve waves stood
+                // in the memory pipeline ahead of the readers' stores: 9.5 k instead of 3.5 k cycles for the phase) --, where the accumulators of every wave are dead (144 of a wave's 168
+                // registers are accumulators and fragments in the K loop; the readers below need 60), it lands under the read-back,
+                // row transform and stores of the second channel half.  An empty descriptor behind the last tile: zeros, no traffic --
+                // the registers are redefined on every path
+                const __amdgpu_buffer_rsrc_t vr = has_next ? vrs : vrs_dead, ur = has_next ? wrs : wrs_dead;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    load_j(j, vr, ur, vb_nxt, ub_nxt, 0);
+                    asm volatile("" ::: "memory");
+                }
+                pre = has_next;
+            }
+            if (nt == 0) __syncthreads();                                  // the exchange block is free for the second half (behind the second half: see above)
             dph[2 * nt + 2] = W44_T();
         }
         // [0] setup + first loads  [1] K loop  [2] write 0 + barrier  [3] read 0 + barrier  [4] write 1 + barrier  [5] read 1 + barrier  [6] tiles  [7] chunks
@@ -677,6 +719,7 @@ int clamd_conv3x3_winograd44_pre(const float* v, const float* w_wino, const floa
     if (stats && stat_rows != clamd_winograd44_stat_rows(B, H, W, Cout_p, tn))
         return clamd_fail("conv3x3_winograd44_pre: stat_rows does not match clamd_stat_rows(CLAMD_OP_CONV3X3_WINOGRAD44, ...)");
     if (relu & ~1) return clamd_fail("conv3x3_winograd44_pre: relu must be 0 or 1 (no border-class bias here)");
+    if ((long long)H * W * y_ldc * 4 >= (1ll << 31)) return clamd_fail("conv3x3_winograd44_pre: one output image exceeds 2^31 bytes");
     WinoParams p{v, 0, w_wino, bias, y, y_ldc, stats, B, H, W, Cin_p, Cout_p, relu, 1, 0};
     p.band = wino_band(tiles, ntn, 2.25 * B * H * W * Cin_p, 36.0 * Cin_p * Cout_p, tn.wino_band);
     p.nblk = (int)(tiles * ntn);
