@@ -67,7 +67,7 @@ if os.path.exists(f'{G}/{src}_prof_fp32_overlap/{src}_kernel_stats.csv'):
     shutil.copy(f'{G}/{src}_bench_fp32_overlap_under_rocprof.json', f'{P}/{dst}_bench_fp32_overlap_under_rocprof.json')
     L.append(f'| `{dst}_fp32_overlap_kernel_stats.csv`, `{dst}_bench_fp32_overlap_under_rocprof.json` | the fp32 trace again with the shipped two-stream overlap (weight gradients + filter pack on the second stream): begin-to-end times of kernels that share the chip are longer, the step is shorter |')
 L.append(f'| `{dst}_bench_<dtype>_under_rocprof.json` | the JSON line that same profiled command printed (clocks are lower under the profiler) |')
-L.append(f'| `{dst}_traffic_<dtype>.json` | per-kernel HBM bytes from two separate `--pmc` passes (FETCH_SIZE, WRITE_SIZE), `tools/pmc_summary.py`; FETCH_SIZE doubled per the gfx950 rule in MI355X_MICROARCH.md §HBM |\n')
+L.append(f'| `{dst}_traffic_<dtype>.json` | per-kernel L2-fabric bytes (what misses L2; Infinity-Cache hits included: no counter behind it is exposed) from two separate `--pmc` passes (FETCH_SIZE, WRITE_SIZE), `tools/pmc_summary.py`; FETCH_SIZE doubled per the gfx950 rule in MI355X_MICROARCH.md §HBM; the keys keep their historical `hbm_*` names |\n')
 L.append(f'| `{dst}_trace_gaps_<dtype>.txt` | `tools/trace_gaps.py` on a two-stream `rocprofv3 --kernel-trace` of `bench.py --steps 4 --warmup 1 --dtype <dtype> --no-kernel-timing`: the intervals of one step in which no convolution / weight-gradient kernel is running, and what runs instead |\n')
 L.append('## Headline (un-profiled run)\n')
 L.append('| dtype | images/s | ms/step | step FLOP/s ÷ MFMA peak | conv3x3 fwd+dgrad kernels | conv3x3 wgrad (+reduce) |\n|---|---|---|---|---|---|')
@@ -107,6 +107,17 @@ for dt in DT:
         L.append(f"| `{k}` | {v['hbm_read_bytes_per_launch'] / 1e6:.1f} | {v['hbm_write_bytes_per_launch'] / 1e6:.1f} | {v['avg_launch_us']} | {by / max(v['avg_launch_us'], 1e-9) / 1e3:.0f} |")
     L.append('')
 # side evidence that is not regenerated by profile_round.sh: listed when present
+side = [('wino44g_ab.txt', '`tools/wino44g_ab.py` — F(4x4,3x3) against F(2x4,3x3), both with pre-transformed operands: input transform, forward launch, weight gradient (stream-K) on the wide layer shapes, interleaved in one process'),
+        ('wino44_narrow_ab.txt', '`tools/wino44_narrow_ab.py` — transform + transform-free F(4x4) loop against the in-kernel-transform F(2x4) kernels on the narrow layer shapes (which data gradients take the pre-transformed path)'),
+        ('w44_diag.txt', '`tools/w44_diag.py` (diagnostic build) — cycle stamps of a `wino44g_kernel` tile by phase, first version and after the epilogue rework, and the store ablations'),
+        ('wino24n_ab.txt', '`tools/wino24n_ab.py` — half-width F(2x4) workgroups (two per CU, `clamd_tuning::wino_half`) against the shipped kernels on the narrow layer shapes: 0.92x'),
+        ('wino24n_counters.txt', '`tools/wino24n_pmc.sh` — SQ counters of the same launches: VALU / LDS instructions per MFMA and MFMA pipe utilisation of `wino24n_kernel` beside `wino24_kernel` / `wino24h_kernel`'),
+        ('timeline_fp32.txt', '`tools/trace_timeline.py` on a two-stream kernel trace of the fp32 step: start, duration, queue of every kernel (the main stream is never idle)'),
+        ('step_ab.txt', '`tools/step_ab.py` lines of the round: whole-step interleaved A/Bs of the engine switches (WINOGRAD44, wgrad_streamk, NARROW_PRE_WGRAD, WGRAD_TAIL_EARLY, FUSE_BN_SUMS incl. config 5, WGRAD_STREAM)'),
+        ('config5_summary.md', '`tools/make_profiles_c5.py` — BASELINE configs[4] on one GPU (512x512, bs32, bf16): time and L2-fabric bytes by kernel family; with `*_bf16_512_kernel_stats.csv`, `*_traffic_bf16_512.json`, `*_trace_gaps_bf16_512.txt`, `*_layers_bf16_config5.txt`')]
+for f, what in side:
+    if os.path.exists(f'{P}/{dst}_{f}'):
+        L.append(f'`{dst}_{f}`: {what}.\n')
 if os.path.exists(f'{P}/{dst}_wino24g_band.txt'):
     L.append(f"`{dst}_wino24g_band.txt`: `tools/wino24g_band.sh` — launch time and FETCH_SIZE (x2 corrected) of `wino24g_kernel` under every block order "
              "(`clamd_tuning::wino_band`) on three wide layer shapes: the traffic model of DESIGN §4 (V·slabs/b + F·tiles/a, a·b = 32) to 1 %, and launch "
