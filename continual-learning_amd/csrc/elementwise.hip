@@ -8,6 +8,17 @@
 
 namespace clamd {
 
+// The HBM-bound passes of the critical chain (BatchNorm statistics / apply / backward, pooling) run beside the weight-gradient kernels of the
+// second stream, whose waves keep the fp32 MFMA -- and with it the SIMD's vector issue -- busy for 64 cycles per instruction: at equal priority
+// the (older) MFMA wave wins the arbitration whenever it is ready and a pass wave issues in what is left.  In the round-5 two-stream trace the
+// passes of the main stream took 7.9 ms for 3.6 ms of work (bn_bwd_finalize: 42 us for 7).  They are few instructions per byte: with a raised
+// wave priority they take the slots they need when their data arrives, and the MFMA kernel beside them loses a few per cent of its issue slots.
+#ifndef CLAMD_NO_PASS_PRIO
+#define PASS_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define PASS_PRIO() do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // The finalize kernels sit on the critical chain between two HBM-bound passes and, in the backward pass, run BESIDE a weight-gradient
 // kernel of the second stream that keeps 352-384 of a SIMD's 512 registers (wgrad_dma.hip: 2 waves x 192): a workgroup must fit into what
@@ -50,6 +61,7 @@ __global__ void __launch_bounds__(FIN_THREADS) bn_finalize_kernel(const float* _
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    float* scale, float* shift, float* save_mean, float* save_istd,
                                    int Cp, int C, double count, double momentum, double eps, long long* num_batches_tracked) {
+    PASS_PRIO();
     __shared__ double red[FIN_THREADS], tot[2 * FIN_CH];
     const int c0 = blockIdx.x * FIN_CH;
     if (stats) sum_partial_rows<2>(stats, nrows, Cp, c0, red, tot);
@@ -86,6 +98,7 @@ template <typename T, bool POOL>
 __global__ void bn_apply_kernel(const T* __restrict__ y, int y_ldc, const float* __restrict__ scale,
                                 const float* __restrict__ shift, T* out, int out_ldc, T* pooled, int p_ldc,
                                 int B, int H, int W, int Cp) {
+    PASS_PRIO();
     const int G = Cp >> 3;
     const long long nitem = POOL ? (long long)B * (H / 2) * (W / 2) * G : (long long)B * H * W * G;
     // G is a power of two <= 256 and the grid stride a multiple of 256: a thread keeps its channel group for the whole
@@ -134,6 +147,7 @@ template <typename T, bool BWD>
 __global__ void __launch_bounds__(256) maxpool2x2_kernel(const T* __restrict__ x, int x_ldc, T* __restrict__ out, int o_ldc,
                                                         const T* __restrict__ gp, int gp_ldc, const float* __restrict__ sign,
                                                         int B, int H, int W, int Cp) {
+    PASS_PRIO();
     const int G = Cp >> 3, w2 = W / 2, h2 = H / 2;
     const long long nitem = (long long)B * h2 * w2 * G;
     for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < nitem; it += (long long)gridDim.x * blockDim.x) {
@@ -214,6 +228,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, float* sums,
                                                             int B, int H, int W, int Cp) {
+    PASS_PRIO();
     __shared__ float red[256 * 8];
     const int G = Cp >> 3;
     const int tid = threadIdx.x;
@@ -293,6 +308,7 @@ __global__ void __launch_bounds__(FIN_THREADS) bn_bwd_finalize_kernel(const floa
                                        const float* __restrict__ save_mean, const float* __restrict__ save_istd,
                                        float* k012, float* dgamma, float* dbeta, float* dbias, int Cp, int C,
                                        double count) {
+    PASS_PRIO();
     __shared__ double red[FIN_THREADS], tot[NSUM * FIN_CH];
     const int c0 = blockIdx.x * FIN_CH;
     sum_partial_rows<NSUM>(sums, nrows, Cp, c0, red, tot);
@@ -325,6 +341,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ ga, int ga_ldc, const 
                                     const T* __restrict__ y, int y_ldc, const float* __restrict__ scale,
                                     const float* __restrict__ shift, const float* __restrict__ k012, T* gz,
                                     int gz_ldc, int B, int H, int W, int Cp) {
+    PASS_PRIO();
     const int G = Cp >> 3;
     const long long nitem = POOL ? (long long)B * (H / 2) * (W / 2) * G : (long long)B * H * W * G;
     if constexpr (!POOL) {
@@ -394,6 +411,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_apply_sums_kernel(const T* __restrict__ ga, int ga_ldc, const T* __restrict__ y, int y_ldc,
                                                                 const float* __restrict__ k012, T* gz, int gz_ldc, float* rows,
                                                                 long long npix, int Cp) {
+    PASS_PRIO();
     __shared__ float red[256 * 8];
     const int G = Cp >> 3, tid = threadIdx.x;
     const long long nitem = npix * G;

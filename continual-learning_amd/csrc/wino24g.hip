@@ -64,6 +64,9 @@ struct W24XformParams {
 // 1-KB unit [h][r][4], exactly what one buffer_load_dwordx4 of wino24g_kernel fetches.
 template <int TXN>
 __global__ void __launch_bounds__(256) wino24_xform_kernel(const W24XformParams p) {
+#ifndef CLAMD_NO_PASS_PRIO
+    __builtin_amdgcn_s_setprio(3);      // a pass of the critical chain beside the second stream's MFMA kernels: see elementwise.hip, PASS_PRIO
+#endif
     constexpr int TYN = 32 / TXN, PW = 4 * TXN, PH = 2 * TYN;
     constexpr int HW_ = PW + 2, HH_ = PH + 2, PIX = HW_ * HH_;
     constexpr int PITCH = 9;                                           // 16-byte slots per pixel: 8 used + 1 (spreads the tiles over the banks)

@@ -87,6 +87,9 @@ struct W44XformParams {
 // V = B6^T d B6; a store instruction of a wave covers 2 planes x 2 halves x 256 contiguous bytes.
 template <int TXN>
 __global__ void __launch_bounds__(256) wino44_xform_kernel(const W44XformParams p) {
+#ifndef CLAMD_NO_PASS_PRIO
+    __builtin_amdgcn_s_setprio(3);      // a pass of the critical chain beside the second stream's MFMA kernels: see elementwise.hip, PASS_PRIO
+#endif
     constexpr int TYN = 32 / TXN, PW = 4 * TXN, PH = 4 * TYN;
     constexpr int HPH = PH / 2;                                        // pixel rows of a half block
     constexpr int HW_ = PW + 2, HH_ = HPH + 2, PIX = HW_ * HH_;
