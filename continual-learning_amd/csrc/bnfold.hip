@@ -19,6 +19,7 @@
 namespace clamd {
 
 __global__ void __launch_bounds__(256) bn_fold_bias_kernel(const FoldBias f) {
+    SIDE_PRIO();
     __shared__ float T[9];
     fold_bias_block(f, blockIdx.x, T);
 }
@@ -30,6 +31,7 @@ constexpr int FOLD_NCH = 8;
 template <typename T>
 __global__ void __launch_bounds__(256) bn_fold_border_kernel(const T* __restrict__ gz, int ldc, float* __restrict__ part,
                                                             int H, int W, int Cp) {
+    SIDE_PRIO();
     __shared__ float red[256];
     const int b = blockIdx.x >> 2, edge = blockIdx.x & 3, ch = blockIdx.y;
     const int n = edge < 2 ? W : H, per = (n + FOLD_NCH - 1) / FOLD_NCH;
@@ -95,6 +97,7 @@ __global__ void __launch_bounds__(256) bn_fold_wgrad_kernel(const T* __restrict_
 // pointwise consumer (the 1x1 head): dW[co][ci] = scale[ci] * dW[co][ci] + shift[ci] * (sum of the gradient over all pixels)[co]
 __global__ void __launch_bounds__(256) bn_fold_wgrad_pw_kernel(const float* __restrict__ total, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float* __restrict__ dw, int Cout, int Cin) {
+    SIDE_PRIO();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Cout * Cin) return;
     const int co = i / Cin, ci = i - co * Cin;

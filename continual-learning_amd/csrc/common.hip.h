@@ -4,6 +4,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// PASS_PRIO(): raised wave priority for the HBM-bound passes of the critical chain (elementwise.hip has the measurement).
+#ifndef CLAMD_NO_PASS_PRIO
+#define PASS_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define PASS_PRIO() do { } while (0)
+#endif
+// SIDE_PRIO(): the same for the small passes of the weight-gradient streams (operand transforms, partial-row reductions, bias-gradient sums):
+// beside the F(4x4) convolution of the critical chain they ran at a sixth of their speed (tools/corun_lab.py), and the weight-gradient GEMM
+// behind them waits for every one of them.  fp32 step 19.05 -> 18.95 ms in two interleaved pairs (profiles/r05_step_ab.txt).
+#define SIDE_PRIO() PASS_PRIO()
+
 namespace clamd {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

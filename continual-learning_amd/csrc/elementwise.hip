@@ -13,11 +13,6 @@ namespace clamd {
 // the (older) MFMA wave wins the arbitration whenever it is ready and a pass wave issues in what is left.  In the round-5 two-stream trace the
 // passes of the main stream took 7.9 ms for 3.6 ms of work (bn_bwd_finalize: 42 us for 7).  They are few instructions per byte: with a raised
 // wave priority they take the slots they need when their data arrives, and the MFMA kernel beside them loses a few per cent of its issue slots.
-#ifndef CLAMD_NO_PASS_PRIO
-#define PASS_PRIO() __builtin_amdgcn_s_setprio(3)
-#else
-#define PASS_PRIO() do { } while (0)
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // The finalize kernels sit on the critical chain between two HBM-bound passes and, in the backward pass, run BESIDE a weight-gradient
@@ -454,6 +449,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_sums_kernel(const T* __restr
 template <typename T>
 __global__ void __launch_bounds__(256) channel_sum_kernel(const T* __restrict__ g, int ldc, float* partial,
                                                           long long npix, int Cp) {
+    SIDE_PRIO();
     __shared__ float red[256 * 8];
     const int G = Cp >> 3, tid = threadIdx.x;
     const int cg = tid % G, rows = 256 / G, prow = tid / G;
@@ -476,6 +472,7 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const T* __restrict__ 
 }
 
 __global__ void __launch_bounds__(FIN_THREADS) channel_sum_final_kernel(const float* __restrict__ partial, int nrows, float* out, int Cp, int C) {
+    SIDE_PRIO();
     __shared__ double red[FIN_THREADS], tot[FIN_CH];
     const int c0 = blockIdx.x * FIN_CH;
     sum_partial_rows<1>(partial, nrows, Cp, c0, red, tot);

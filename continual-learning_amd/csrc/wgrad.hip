@@ -431,6 +431,7 @@ __device__ inline int wg_phys2log(int p, int seg0, int seg0p, int L) {
 
 template <int KP>
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const ReduceParams p) {
+    SIDE_PRIO();
     constexpr int LE = 256 / KP;
     __shared__ float4 red[KP > 1 ? 256 : 1];
     const int le = threadIdx.x % LE, kp = threadIdx.x / LE;

@@ -741,6 +741,7 @@ struct WinoReduceParams {
 };
 
 __global__ void __launch_bounds__(256) wino_wgrad_reduce_kernel(const WinoReduceParams p) {
+    SIDE_PRIO();
     __shared__ float4 red[4][4][16];                                   // [phase][plane][pair]
     const int pr = threadIdx.x & 15, pl = (threadIdx.x >> 4) & 3, ph = threadIdx.x >> 6;
     const long long npair = (long long)p.Rp * p.Cp;

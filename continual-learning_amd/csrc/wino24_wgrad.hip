@@ -244,6 +244,7 @@ struct Wino24ReduceParams {
 };
 
 __global__ void __launch_bounds__(256) wino24_wgrad_reduce_kernel(const Wino24ReduceParams p) {
+    SIDE_PRIO();
     __shared__ float red[4][4][16][6];                                 // [phase][plane][pair][j]
     const int pr = threadIdx.x & 15, pl = (threadIdx.x >> 4) & 3, ph = threadIdx.x >> 6;
     const long long npair = (long long)p.Rp * p.Cp;

@@ -64,9 +64,7 @@ struct W24XformParams {
 // 1-KB unit [h][r][4], exactly what one buffer_load_dwordx4 of wino24g_kernel fetches.
 template <int TXN>
 __global__ void __launch_bounds__(256) wino24_xform_kernel(const W24XformParams p) {
-#ifndef CLAMD_NO_PASS_PRIO
-    __builtin_amdgcn_s_setprio(3);      // a pass of the critical chain beside the second stream's MFMA kernels: see elementwise.hip, PASS_PRIO
-#endif
+    PASS_PRIO();      // a pass of the critical chain beside the second stream's MFMA kernels (elementwise.hip)
     constexpr int TYN = 32 / TXN, PW = 4 * TXN, PH = 2 * TYN;
     constexpr int HW_ = PW + 2, HH_ = PH + 2, PIX = HW_ * HH_;
     constexpr int PITCH = 9;                                           // 16-byte slots per pixel: 8 used + 1 (spreads the tiles over the banks)
@@ -686,6 +684,7 @@ struct W24WgXformParams {
 // reads and writes are contiguous along the channels.  Tiles of a ragged block that lie outside the image read zeros.
 template <int TXN>
 __global__ void __launch_bounds__(256) wino24g_wgrad_xform_kernel(const W24WgXformParams p) {
+    SIDE_PRIO();
     constexpr int TYN = 32 / TXN, PW = 4 * TXN, PH = 2 * TYN;
     const int ng = p.Rp >> 2;
     const long long total = (long long)p.Tp * ng;
@@ -835,6 +834,7 @@ struct W24GReduceParams {
 
 template <int PHS>
 __global__ void __launch_bounds__(256) wino24g_wgrad_reduce_kernel(const W24GReduceParams p) {
+    SIDE_PRIO();
     constexpr int QW = 64 / PHS;                                       // quads per wave
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = lane % QW, ph = lane / QW;
@@ -1081,6 +1081,7 @@ struct W24SkwSumParams {
 };
 
 __global__ void __launch_bounds__(256) wino_skw_sum_kernel(const W24SkwSumParams p) {
+    SIDE_PRIO();
     const long long nquad = (long long)p.Rp * p.Cp / 4;
     const size_t plane_sz = (size_t)p.Rp * p.Cp, slot_sz = plane_sz * p.npl;
     const int rb_n = p.Rp >> 7, cb_n = p.Cp >> 7;
@@ -1117,6 +1118,7 @@ __device__ inline void wsk_gt6(const float (&t)[6], float (&o)[3]) {
 
 template <int NPL>
 __global__ void __launch_bounds__(256) wino_sk_reduce_kernel(const W24SkReduceParams p) {
+    SIDE_PRIO();
     constexpr int NI = NPL / 6;
     const long long nquad = (long long)p.Rp * p.Cp / 4;
     const size_t plane_sz = (size_t)p.Rp * p.Cp, slot_sz = plane_sz * NPL;

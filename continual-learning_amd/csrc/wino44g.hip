@@ -87,9 +87,7 @@ struct W44XformParams {
 // V = B6^T d B6; a store instruction of a wave covers 2 planes x 2 halves x 256 contiguous bytes.
 template <int TXN>
 __global__ void __launch_bounds__(256) wino44_xform_kernel(const W44XformParams p) {
-#ifndef CLAMD_NO_PASS_PRIO
-    __builtin_amdgcn_s_setprio(3);      // a pass of the critical chain beside the second stream's MFMA kernels: see elementwise.hip, PASS_PRIO
-#endif
+    PASS_PRIO();      // a pass of the critical chain beside the second stream's MFMA kernels (elementwise.hip)
     constexpr int TYN = 32 / TXN, PW = 4 * TXN, PH = 4 * TYN;
     constexpr int HPH = PH / 2;                                        // pixel rows of a half block
     constexpr int HW_ = PW + 2, HH_ = HPH + 2, PIX = HW_ * HH_;
@@ -516,6 +514,7 @@ struct W44WgXformParams {
 
 template <int TXN>
 __global__ void __launch_bounds__(256) wino44g_wgrad_xform_kernel(const W44WgXformParams p) {
+    SIDE_PRIO();
     constexpr int TYN = 32 / TXN, PW = 4 * TXN, PH = 4 * TYN;
     const int ng = p.Rp >> 2;
     const long long total = (long long)p.Tp * ng;
@@ -578,6 +577,7 @@ struct W44GReduceParams {
 
 template <int PHS>
 __global__ void __launch_bounds__(256) wino44g_wgrad_reduce_kernel(const W44GReduceParams p) {
+    SIDE_PRIO();
     constexpr int QW = 64 / PHS;                                       // quads per wave
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = lane % QW, ph = lane / QW;
