@@ -697,8 +697,9 @@ __global__ void __launch_bounds__(512, 2) igemm_pws_kernel(const IgemmParams p, 
                 if constexpr (CLM == 2) p.stats[((size_t)mg * 2 + k) * p.Np + n0 + c] = t;
                 else p.bn_sums[((size_t)mg * 5 + k) * p.Np + n0 + c] = t;
             }
-            if constexpr (CLM == 3) {      // rows 2-4 of the five-sum layout: not taken here (the conv-bias gradient comes from clamd_bn_bwd_apply)
-                if (tid < 192 && n0 + (tid & 63) < p.Np) p.bn_sums[((size_t)mg * 5 + 2 + (tid >> 6)) * p.Np + n0 + (tid & 63)] = 0.f;
+            if constexpr (CLM == 3) {      // rows 2-4 of the five-sum layout: not taken here (the conv-bias gradient comes from clamd_bn_bwd_apply_sums).
+                // Written as NaN, not zeros: a caller that still asks clamd_bn_bwd_finalize for dbias gets NaN, not a silent 0
+                if (tid < 192 && n0 + (tid & 63) < p.Np) p.bn_sums[((size_t)mg * 5 + 2 + (tid >> 6)) * p.Np + n0 + (tid & 63)] = __builtin_nanf("");
             }
         }
         return;

@@ -108,7 +108,8 @@ int clamd_conv3x3(const void* x, int x_ldc, const void* w_packed, const float* b
 int clamd_conv3x3_border_bias_ok(int B, int H, int W, int Cin_p, int Cout_p, int dtype, const clamd_tuning* tune);
 /* How many of the five sums a PLAIN (no bias, ReLU, statistics) clamd_conv3x3 launch with bn_y / bn_sums takes: 5, or 2 where the
  * persistent bf16 kernel runs it (channels-in-the-lane epilogue: sum g and sum g y as running sums per accumulator register; rows
- * k = 2..4 are written as zeros and the convolution's bias gradient comes from clamd_bn_bwd_apply_sums, below).  0 on bad arguments. */
+ * k = 2..4 are written as NaN -- clamd_bn_bwd_finalize with dbias != NULL on such rows returns NaN bias gradients instead of silent zeros --
+ * and the convolution's bias gradient comes from clamd_bn_bwd_apply_sums, below).  0 on bad arguments. */
 int clamd_conv3x3_bn_sums(int B, int H, int W, int Cin_p, int Cout_p, int dtype, const clamd_tuning* tune);
 /* ---- nn.BatchNorm2d folded into the nn.Conv2d(k3,p1) behind it (models/unet.py:15-16,30-31; bnfold.hip) ---------------------
  * x = scale * r + shift with r the producer's saved conv+ReLU output and scale / shift from clamd_bn_finalize:
@@ -290,7 +291,7 @@ int clamd_bn_bwd_apply(const void* ga, int ga_ldc, const void* gp, int gp_ldc, c
                        const float* scale, const float* shift, const float* k012, void* gz, int gz_ldc, int B,
                        int H, int W, int Cp, int dtype, void* stream);
 /* Two-sum form (the persistent bf16 convolution kernel, see clamd_conv3x3_bn_sums): the producing data-gradient launch wrote only
- * sum g and sum g y (rows k = 0, 1; k = 2..4 zero), which is all k0, k1, k2, d gamma and d beta need; pass dbias = NULL to
+ * sum g and sum g y (rows k = 0, 1; k = 2..4 NaN), which is all k0, k1, k2, d gamma and d beta need; pass dbias = NULL to
  * clamd_bn_bwd_finalize and take the convolution's bias gradient (models/unet.py:13,16: d conv-bias = sum of g_z) where g_z is formed:
  * clamd_bn_bwd_apply_sums = clamd_bn_bwd_apply without pooling + partial rows gz_rows[nrows][Cp] of sum g_z (nrows =
  * clamd_bn_bwd_apply_sums_rows(B, H, W, Cp), one row per workgroup, plain stores), then clamd_rows_sum adds rows 0..nrows-1 in a

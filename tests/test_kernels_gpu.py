@@ -311,8 +311,10 @@ def test_conv3x3_dgrad_and_wgrad(C, name, dcode, shape):
     nsums = lib.load().clamd_conv3x3_bn_sums(B, H, W, cout_p, cin_p, dcode, None)
     assert nsums in (2, 5) and (nsums == 5 or dcode == 1)
     assert lib.load().clamd_conv3x3_bn_sums(B, H, W, cout_p, cin_p, dcode, lib.Tuning(igemm_pws=0).ref()) == 5      # the other structures: all five
-    if nsums == 2:      # the persistent bf16 kernel: sum g and sum g y only, rows 2-4 written as zeros (clamd_bn_bwd_apply_sums gives d conv-bias)
-        assert not np.isnan(bsums.cpu().numpy()).any() and float(bsums[:, 2:].abs().max()) == 0.0
+    if nsums == 2:      # the persistent bf16 kernel: sum g and sum g y only, rows 2-4 written as NaN (clamd_bn_bwd_apply_sums gives d conv-bias;
+        #                 a finalize that still asks for dbias from these rows gets NaN, not a silent zero)
+        bs = bsums.cpu().numpy()
+        assert not np.isnan(bs[:, :2]).any() and np.isnan(bs[:, 2:]).all()
         want, got = want[:2], got[:2]
     scale = np.abs(want).max(1, keepdims=True) + 1e-6
     assert np.abs(got - want).max() <= (2e-2 if dcode == 1 else 1e-3) * scale.max(), np.abs(got - want).max()
